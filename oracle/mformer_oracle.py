@@ -1,0 +1,489 @@
+"""CPU oracle for the mFormerV1 forward/backward path (TEST INFRASTRUCTURE ONLY).
+
+This file is a plain-PyTorch, fp32, CPU restatement of what the reference computes on
+the path named by BASELINE.json's north_star.  It is the *checker* for the HIP path:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+The product (linnaeus_amd/) never imports anything from oracle/.
+
+Parity pinning: every function here is checked against outputs of the reference itself
+(imported in the build container by tests/golden/gen/make_golden.py) through the
+fixtures committed under tests/golden/ -- see tests/test_oracle_golden.py.
+
+All citations are path:line under /root/reference/.  The restatement is functional: the
+model is a dict of tensors keyed exactly like the reference's state_dict
+ plus a small `Spec` describing the architecture.
+
+Reference semantics that are matched, not "fixed" (SURVEY.md section 0):
+  F1  mixed 2D-RoPE multiplies each (even, odd) channel pair of q,k by cos(theta) only
+  F2  attention is global over all H*W + E tokens
+  F3  hierarchical heads reduce to one shared Linear per task
+  F7  a single head_dim**-0.5 scale, fp32 scores and softmax
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+StateDict = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# architecture description
+# --------------------------------------------------------------------------------------
+@dataclass
+class Spec:
+    """Shape description of one mFormerV1 instance.
+
+    Mirrors what mFormerV1.__init__ reads from the config (models/mFormerV1.py:49-130):
+    CONVNEXT_STAGES.{DEPTHS,DIMS}, ROPE_STAGES.{DEPTHS,DIMS,NUM_HEADS,MLP_RATIO},
+    DATA.META components (name, dim) ordered by IDX, ONLY_LAST_CLS, head class counts.
+    """
+
+    in_chans: int = 3
+    conv_dims: Tuple[int, int, int, int] = (96, 192, 384, 768)
+    conv_depths: Tuple[int, int] = (3, 3)  # only DEPTHS[0:2] are ever built (F10)
+    rope_depths: Tuple[int, int] = (5, 2)
+    rope_heads: Tuple[int, int] = (6, 12)
+    mlp_ratio: Tuple[float, float] = (4.0, 4.0)
+    meta: Tuple[Tuple[str, int], ...] = (("TEMPORAL", 2), ("SPATIAL", 3))
+    only_last_cls: bool = False
+    heads: Tuple[Tuple[str, int], ...] = ()  # (task, num_classes); effective Linear (F3)
+    drop_path_rate: float = 0.0
+
+    @property
+    def rope_dims(self) -> Tuple[int, int]:
+        return (self.conv_dims[2], self.conv_dims[3])
+
+    @property
+    def extra_tokens(self) -> int:
+        return 1 + len(self.meta)  # mFormerV1.py:130
+
+    @property
+    def meta_width(self) -> int:
+        return sum(d for _, d in self.meta)
+
+    def drop_path_probs(self) -> List[float]:
+        """linspace(0, DROP_PATH_RATE, total_depth) in block order (mFormerV1.py:134-139)."""
+        n = sum(self.conv_depths) + sum(self.rope_depths)
+        return [x.item() for x in torch.linspace(0, self.drop_path_rate, n)]
+
+
+SM = Spec()
+
+
+def n_drop_calls(spec: Spec) -> int:
+    return sum(spec.conv_depths) + 2 * sum(spec.rope_depths)
+
+
+def drop_call_probs(spec: Spec) -> List[float]:
+    """DropPath probability of every call in execution order (RoPE blocks call twice)."""
+    p = spec.drop_path_probs()
+    nc = sum(spec.conv_depths)
+    return p[:nc] + [q for q in p[nc:] for _ in range(2)]
+
+
+# --------------------------------------------------------------------------------------
+# primitive ops
+# --------------------------------------------------------------------------------------
+def layer_norm_last(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    """LayerNorm over the last dim, biased variance, eps inside the sqrt.
+
+    nn.LayerNorm semantics; eps=1e-6 inside ConvNeXtBlock (blocks/convnext.py:59) and
+    1e-5 (torch default) everywhere else (mFormerV1.py:271-273,294,320-328;
+    blocks/rope_2d_mhsa.py:546-547; normalization/res_norm_layer.py:18-19).
+    """
+    mu = x.mean(-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdim=True)
+    return xc * torch.rsqrt(var + eps) * w + b
+
+
+def layer_norm_channels_first(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    """LayerNormChannelsFirst.forward (blocks/convnext.py:32-43): LN over dim 1 of NCHW."""
+    mu = x.mean(1, keepdim=True)
+    var = (x - mu).pow(2).mean(1, keepdim=True)
+    xh = (x - mu) / torch.sqrt(var + eps)
+    return w.view(1, -1, 1, 1) * xh + b.view(1, -1, 1, 1)
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """nn.GELU() default = exact erf form (blocks/convnext.py:63, blocks/mlp.py:38)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def patchify_conv(x: Tensor, w: Tensor, b: Tensor, k: int) -> Tensor:
+    """Conv2d(kernel=k, stride=k, no padding) -- stem k=4 (mFormerV1.py:146), downsample
+    k=2 (blocks/convnext.py:110).  Non-overlapping, so it is a GEMM on k*k*Cin patches."""
+    return F.conv2d(x, w, b, stride=k)
+
+
+def depthwise_conv7(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """Conv2d(C, C, 7, padding=3, groups=C) with bias (blocks/convnext.py:56-58)."""
+    return F.conv2d(x, w, b, padding=3, groups=x.shape[1])
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    return F.linear(x, w, b)
+
+
+def apply_drop(branch: Tensor, scale: Optional[Tensor]) -> Tensor:
+    """DropPath with an injected per-sample multiplier (blocks/drop_path.py:29-33).
+
+    `scale[b]` is floor(keep + u_b) / keep, i.e. 0 or 1/keep; None means identity
+    (eval mode, or p == 0 which the reference builds as nn.Identity)."""
+    if scale is None:
+        return branch
+    return branch * scale.view(-1, *([1] * (branch.dim() - 1)))
+
+
+# --------------------------------------------------------------------------------------
+# RoPE (cos-only, F1)
+# --------------------------------------------------------------------------------------
+def rope_cos_table(freqs: Tensor, H: int, W: int) -> Tensor:
+    """cos(theta)[n, h, j] with theta = t_x * freqs[0,h,j] + t_y * freqs[1,h,j].
+
+    t_x = n % W, t_y = n // W over the row-major H*W grid (rope_2d_mhsa.py:56-73);
+    angles in fp32 (:129-142); torch.polar then a complex->real cast keeps only the real
+    part = cos(theta) (:152, :408 -- finding F1)."""
+    n = torch.arange(H * W, dtype=torch.float32, device=freqs.device)
+    tx = n % W
+    ty = torch.div(n, W, rounding_mode="floor")
+    theta = tx[:, None, None] * freqs[0].float()[None] + ty[:, None, None] * freqs[1].float()[None]
+    return torch.cos(theta)  # (H*W, heads, d/2)
+
+
+def rope_scale_pairs(t: Tensor, cos: Tensor) -> Tensor:
+    """Multiply each (2j, 2j+1) channel pair of t[B,h,N_img,d] by cos[n,h,j].
+
+    This is what apply_rotary_emb (rope_2d_mhsa.py:176-218) computes once freqs_cis has
+    lost its imaginary part: (a + ib) * c = ac + i bc."""
+    B, h, n, d = t.shape
+    c = cos.permute(1, 0, 2)  # (h, N_img, d/2)
+    return (t.reshape(B, h, n, d // 2, 2) * c[None, :, :, :, None]).reshape(B, h, n, d)
+
+
+def init_mixed_freqs(head_dim: int, heads: int, theta: float, gen: torch.Generator) -> Tensor:
+    """Shape/recipe of the learnable freqs init (rope_2d_mhsa.py:76-111): per head a random
+    direction phi, fx = inv_freq*cos(phi), fy = inv_freq*sin(phi), inv_freq_j = theta^(-2j/d)."""
+    j = torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim
+    inv = 1.0 / (theta**j)
+    phi = torch.rand(heads, 1, generator=gen) * 2 * math.pi
+    return torch.stack([inv[None] * torch.cos(phi), inv[None] * torch.sin(phi)], 0)
+
+
+# --------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------
+def convnext_block(sd: StateDict, p: str, x: Tensor, drop: Optional[Tensor]) -> Tensor:
+    """ConvNeXtBlock._forward_impl (blocks/convnext.py:73-87), x is NCHW."""
+    y = depthwise_conv7(x, sd[p + "dwconv.weight"], sd[p + "dwconv.bias"])
+    y = y.permute(0, 2, 3, 1)
+    y = layer_norm_last(y, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    y = linear(y, sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"])
+    y = gelu_erf(y)
+    y = linear(y, sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"])
+    if (p + "gamma") in sd:
+        y = sd[p + "gamma"] * y
+    y = y.permute(0, 3, 1, 2)
+    return x + apply_drop(y, drop)
+
+
+def downsample(sd: StateDict, p: str, x: Tensor) -> Tensor:
+    """ConvNeXtDownsampleLayer.forward (blocks/convnext.py:112-115)."""
+    y = layer_norm_channels_first(x, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    return patchify_conv(y, sd[p + "conv.weight"], sd[p + "conv.bias"], 2)
+
+
+def rope_attention(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: int) -> Tensor:
+    """RoPE2DAttention.forward, standard (non-flash) path (rope_2d_mhsa.py:422-505)."""
+    B, N, C = x.shape
+    d = C // heads
+    qkv = linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"])
+    qkv = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)  # :432-437
+    q, k, v = qkv[0], qkv[1], qkv[2]  # (B, heads, N, d)
+    cos = rope_cos_table(sd[p + "freqs"], H, W)
+    q = torch.cat([q[:, :, :E], rope_scale_pairs(q[:, :, E:], cos)], 2)  # :440-452
+    k = torch.cat([k[:, :, :E], rope_scale_pairs(k[:, :, E:], cos)], 2)
+    q = q * (d**-0.5)  # :456 (scale applied exactly once, F7)
+    s = q.float() @ k.float().transpose(-2, -1)  # :495
+    a = torch.softmax(s, dim=-1)  # :496
+    o = a @ v  # :498
+    o = o.transpose(1, 2).reshape(B, N, C)  # :501
+    return linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])  # :502
+
+
+def mlp(sd: StateDict, p: str, x: Tensor) -> Tensor:
+    """Mlp.forward with drop=0 (blocks/mlp.py:61-66)."""
+    return linear(gelu_erf(linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+
+
+def rope_block(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: int,
+               drop_attn: Optional[Tensor], drop_mlp: Optional[Tensor]) -> Tensor:
+    """RoPE2DMHSABlock.forward (rope_2d_mhsa.py:584-645); LayerNorm eps = 1e-5.
+    The same DropPath module is called twice (:630, :643) so the two residual branches draw
+    independent per-sample masks."""
+    a = rope_attention(sd, p + "attn.", layer_norm_last(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5), H, W, heads, E)
+    x = x + apply_drop(a, drop_attn)
+    m = mlp(sd, p + "mlp.", layer_norm_last(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5))
+    return x + apply_drop(m, drop_mlp)
+
+
+def meta_head(sd: StateDict, p: str, m: Tensor) -> Tensor:
+    """nn.Sequential(Linear, ReLU, LayerNorm, ResNormLayer) (mFormerV1.py:291-296);
+    ResNormLayer.forward = x + LN2(ReLU(W2 LN1(ReLU(W1 x)))) (res_norm_layer.py:23-30)."""
+    x = torch.relu(linear(m, sd[p + "0.weight"], sd[p + "0.bias"]))
+    x = layer_norm_last(x, sd[p + "2.weight"], sd[p + "2.bias"], 1e-5)
+    y = torch.relu(linear(x, sd[p + "3.w1.weight"], sd[p + "3.w1.bias"]))
+    y = layer_norm_last(y, sd[p + "3.norm_fn1.weight"], sd[p + "3.norm_fn1.bias"], 1e-5)
+    y = torch.relu(linear(y, sd[p + "3.w2.weight"], sd[p + "3.w2.bias"]))
+    y = layer_norm_last(y, sd[p + "3.norm_fn2.weight"], sd[p + "3.norm_fn2.bias"], 1e-5)
+    return x + y
+
+
+# --------------------------------------------------------------------------------------
+# whole model
+# --------------------------------------------------------------------------------------
+def forward_features(
+    sd: StateDict,
+    spec: Spec,
+    x: Tensor,
+    meta: Optional[Tensor],
+    drop_scales: Optional[Sequence[Optional[Tensor]]] = None,
+    tap: Optional[Callable[[str, Tensor], None]] = None,
+) -> Tensor:
+    """mFormerV1.forward_features (models/mFormerV1.py:407-529).
+
+    drop_scales: one entry per DropPath *call* in execution order: one per ConvNeXt block
+    (s0b0.., s1b0..) then two per RoPE block (attn branch, mlp branch) -- 6 + 2*7 = 20 for
+    sm; each is None or a [B] multiplier (see apply_drop).  tap(name, tensor) receives the
+    activation after every stage boundary for stage-wise parity checks."""
+    ncall = n_drop_calls(spec)
+    ds = list(drop_scales) if drop_scales is not None else [None] * ncall
+    assert len(ds) == ncall
+    t = tap or (lambda n, v: None)
+    E = spec.extra_tokens
+    if spec.meta and meta is None:
+        # the reference asserts N == H*W + extra_token_num inside attention (:427-429)
+        raise ValueError("metadata components are configured but meta is None")
+    B = x.shape[0]
+    bi = 0
+
+    x = patchify_conv(x, sd["stem.0.weight"], sd["stem.0.bias"], 4)  # :424
+    x = layer_norm_channels_first(x, sd["stem.1.weight"], sd["stem.1.bias"], 1e-6)
+    t("stem", x)
+    for s in range(2):  # :429-443
+        for i in range(spec.conv_depths[s]):
+            x = convnext_block(sd, f"stages.{s}.{i}.", x, ds[bi])
+            bi += 1
+        t(f"stage{s}", x)
+        x = downsample(sd, f"downsample_layers.{s}.", x)
+        t(f"down{s}", x)
+
+    cls_final = []
+    for s in range(2):  # RoPE stages :445-510
+        H, W = x.shape[2], x.shape[3]
+        tok = x.flatten(2).transpose(1, 2)
+        extras = [sd[f"cls_token_{s + 1}"].expand(B, -1, -1)]
+        if meta is not None and spec.meta:
+            off = 0
+            for name, dim in spec.meta:  # components in IDX order (:107-113,:452-458)
+                extras.append(meta_head(sd, f"meta_{name.lower()}_head_{s + 1}.", meta[:, off : off + dim]).unsqueeze(1))
+                off += dim
+        tok = torch.cat([*extras, tok], 1)
+        t(f"tokens{s}", tok)
+        for i in range(spec.rope_depths[s]):
+            tok = rope_block(sd, f"stages.{s + 2}.{i}.", tok, H, W, spec.rope_heads[s], E, ds[bi], ds[bi + 1])
+            bi += 2
+        t(f"rope{s}", tok)
+        tok = layer_norm_last(tok, sd[f"norm_{s + 1}.weight"], sd[f"norm_{s + 1}.bias"], 1e-5)
+        cls_final.append(tok[:, 0:1, :])
+        if s == 0:
+            x = tok[:, E:, :].transpose(1, 2).reshape(B, -1, H, W)  # :479-480
+            x = downsample(sd, "downsample_layers.2.", x)
+            t("down2", x)
+
+    if not spec.only_last_cls:  # :513-524
+        c1 = mlp(sd, "cl_1_fc.0.", cls_final[0])
+        c1 = layer_norm_last(c1, sd["cl_1_fc.1.weight"], sd["cl_1_fc.1.bias"], 1e-5)
+        aw = sd["aggregate.weight"]  # Conv1d(2, 1, 1): [1, 2, 1]
+        agg = aw[0, 0, 0] * c1[:, 0] + aw[0, 1, 0] * cls_final[1][:, 0] + sd["aggregate.bias"][0]
+    else:  # :527
+        agg = cls_final[1][:, 0]
+    feats = layer_norm_last(agg, sd["final_norm.weight"], sd["final_norm.bias"], 1e-5)
+    t("feats", feats)
+    return feats
+
+
+def head_weight_key(sd: StateDict, task: str) -> str:
+    """Locate the effective Linear of a task head inside a reference state_dict.
+
+    LinearHead -> head.{task}.fc.* (heads/linear_head.py:27); hierarchical heads ->
+    head.{task}.level_classifiers.{task}.* (shared ModuleDict, heads/utils.py:217-229)."""
+    for k in (f"head.{task}.fc.", f"head.{task}.level_classifiers.{task}."):
+        if k + "weight" in sd:
+            return k
+    raise KeyError(f"no head weights for task {task}")
+
+
+def forward(sd: StateDict, spec: Spec, x: Tensor, meta: Optional[Tensor], drop_scales=None, tap=None) -> Dict[str, Tensor]:
+    """mFormerV1.forward (models/mFormerV1.py:531-541) with the effective head math (F3)."""
+    feats = forward_features(sd, spec, x, meta, drop_scales, tap)
+    out = {}
+    for task, _ in spec.heads:
+        k = head_weight_key(sd, task)
+        out[task] = linear(feats, sd[k + "weight"], sd.get(k + "bias"))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory + deterministic fills (shared by the golden generator and tests)
+# --------------------------------------------------------------------------------------
+def param_shapes(spec: Spec, head_style: str = "Linear") -> "Dict[str, Tuple[int, ...]]":
+    """state_dict names and shapes in the reference's registration order (SURVEY 8b;
+    mFormerV1.py:145-343).  head_style: 'Linear' -> head.{t}.fc.*"""
+    D = spec.conv_dims
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def add(n, *s):
+        out[n] = tuple(int(v) for v in s)
+
+    add("cls_token_1", 1, 1, D[2])
+    add("cls_token_2", 1, 1, D[3])
+    add("stem.0.weight", D[0], spec.in_chans, 4, 4)
+    add("stem.0.bias", D[0])
+    add("stem.1.weight", D[0])
+    add("stem.1.bias", D[0])
+    for i in range(3):
+        add(f"downsample_layers.{i}.norm.weight", D[i])
+        add(f"downsample_layers.{i}.norm.bias", D[i])
+        add(f"downsample_layers.{i}.conv.weight", D[i + 1], D[i], 2, 2)
+        add(f"downsample_layers.{i}.conv.bias", D[i + 1])
+    for s in range(2):
+        C = D[s]
+        for i in range(spec.conv_depths[s]):
+            p = f"stages.{s}.{i}."
+            add(p + "gamma", C)
+            add(p + "dwconv.weight", C, 1, 7, 7)
+            add(p + "dwconv.bias", C)
+            add(p + "norm.weight", C)
+            add(p + "norm.bias", C)
+            add(p + "pwconv1.weight", 4 * C, C)
+            add(p + "pwconv1.bias", 4 * C)
+            add(p + "pwconv2.weight", C, 4 * C)
+            add(p + "pwconv2.bias", C)
+    for s in range(2):
+        C = D[2 + s]
+        h = spec.rope_heads[s]
+        hid = int(C * spec.mlp_ratio[s])
+        for i in range(spec.rope_depths[s]):
+            p = f"stages.{s + 2}.{i}."
+            add(p + "norm1.weight", C)
+            add(p + "norm1.bias", C)
+            add(p + "norm2.weight", C)
+            add(p + "norm2.bias", C)
+            add(p + "attn.freqs", 2, h, (C // h) // 2)
+            add(p + "attn.qkv.weight", 3 * C, C)
+            add(p + "attn.qkv.bias", 3 * C)
+            add(p + "attn.proj.weight", C, C)
+            add(p + "attn.proj.bias", C)
+            add(p + "mlp.fc1.weight", hid, C)
+            add(p + "mlp.fc1.bias", hid)
+            add(p + "mlp.fc2.weight", C, hid)
+            add(p + "mlp.fc2.bias", C)
+    add("norm_1.weight", D[2])
+    add("norm_1.bias", D[2])
+    add("norm_2.weight", D[3])
+    add("norm_2.bias", D[3])
+    for name, dim in spec.meta:
+        for s in range(2):
+            C = D[2 + s]
+            p = f"meta_{name.lower()}_head_{s + 1}."
+            add(p + "0.weight", C, dim)
+            add(p + "0.bias", C)
+            add(p + "2.weight", C)
+            add(p + "2.bias", C)
+            for sub in ("norm_fn1", "norm_fn2"):
+                add(p + f"3.{sub}.weight", C)
+                add(p + f"3.{sub}.bias", C)
+            for sub in ("w1", "w2"):
+                add(p + f"3.{sub}.weight", C, C)
+                add(p + f"3.{sub}.bias", C)
+    if not spec.only_last_cls:
+        add("cl_1_fc.0.fc1.weight", D[2], D[2])
+        add("cl_1_fc.0.fc1.bias", D[2])
+        add("cl_1_fc.0.fc2.weight", D[3], D[2])
+        add("cl_1_fc.0.fc2.bias", D[3])
+        add("cl_1_fc.1.weight", D[3])
+        add("cl_1_fc.1.bias", D[3])
+        add("aggregate.weight", 1, 2, 1)
+        add("aggregate.bias", 1)
+    add("final_norm.weight", D[3])
+    add("final_norm.bias", D[3])
+    for task, ncls in spec.heads:
+        add(f"head.{task}.fc.weight", ncls, D[3])
+        add(f"head.{task}.fc.bias", ncls)
+    return out
+
+
+def seeded_fill(name: str, shape: Sequence[int], seed: int) -> Tensor:
+    """Deterministic, name-keyed fill used for every parity run (never the reference's
+    init: gamma=1e-6 would make the conv branches numerically invisible).
+
+    The stream depends only on (seed, name), so the generator, the oracle tests and the
+    GPU tests build identical weights without shipping them."""
+    h = seed
+    for ch in name.encode():
+        h = (h * 1000003 + ch) % (2**31 - 1)
+    g = torch.Generator().manual_seed(h)
+    t = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    last = name.rsplit(".", 1)[-1]
+    if name.endswith("gamma"):
+        return 0.5 + 0.25 * t
+    if name.endswith("freqs"):
+        d2 = shape[-1]
+        inv = 1.0 / (10000.0 ** (torch.arange(d2, dtype=torch.float32) * 2.0 / (2 * d2)))
+        return t * inv  # random directions at the reference's frequency scales
+    if name.startswith("cls_token"):
+        return 0.5 * t
+    if name.startswith("aggregate"):
+        return 0.6 + 0.2 * t
+    is_norm = (
+        ".norm" in name or name.startswith("norm_") or name.startswith("final_norm") or name.startswith("stem.1")
+        or name.startswith("cl_1_fc.1") or ".2." in name and name.startswith("meta_")
+    )
+    if is_norm:
+        return (1.0 + 0.1 * t) if last == "weight" else 0.05 * t
+    if last == "bias":
+        return 0.05 * t
+    fan_in = 1
+    for v in shape[1:]:
+        fan_in *= v
+    return t * (1.0 / math.sqrt(max(fan_in, 1)))
+
+
+def seeded_state_dict(shapes: Dict[str, Sequence[int]], seed: int) -> StateDict:
+    return {k: seeded_fill(k, s, seed) for k, s in shapes.items()}
+
+
+def seeded_inputs(spec: Spec, batch: int, img: int, seed: int) -> Tuple[Tensor, Optional[Tensor]]:
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, spec.in_chans, img, img, generator=g)
+    m = torch.rand(batch, spec.meta_width, generator=g) * 2 - 1 if spec.meta else None
+    return x, m
+
+
+def probe_loss(out: Dict[str, Tensor], feats_like: Optional[Tensor] = None) -> Tensor:
+    """Fixed scalar used for gradient parity: sum_t mean(logits_t * ramp_t) where ramp is a
+    deterministic non-symmetric weighting (so every logit gets a distinct cotangent)."""
+    tot = None
+    for i, (task, lg) in enumerate(sorted(out.items())):
+        B, C = lg.shape
+        ramp = torch.sin(torch.arange(B * C, dtype=torch.float32, device=lg.device).reshape(B, C) * 0.37 + i)
+        v = (lg.float() * ramp).mean()
+        tot = v if tot is None else tot + v
+    return tot

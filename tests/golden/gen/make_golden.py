@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the *reference itself*.
+
+Runs ONLY in the build container, where /root/reference is mounted:
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen/make_golden.py
+
+It imports `linnaeus` from /root/reference (read-only) with two tiny stand-ins for absent
+third-party modules (yacs.config.CfgNode, termcolor.colored -- tests/golden/gen/_stubs/,
+our own code), builds mFormerV1 through the reference's own build_model(), loads the
+deterministic name-keyed weights of oracle.mformer_oracle.seeded_fill, and records inputs
+and reference outputs as small .npz files.  Nothing from the reference is copied: the
+fixtures hold numbers only (inputs, outputs, checksums, gradient norms).
+
+Cases:
+  tiny_a   dims 32..256, depths (1,1)/(1,1), E=3 (TEMPORAL+SPATIAL), 2 Linear heads, img 64
+  tiny_b   depths (2,1)/(2,1), E=4 (+ELEVATION), ONLY_LAST_CLS, img 96
+  tiny_c   metadata inactive (E=1), ConditionalClassifier heads on a real TaxonomyTree (F3)
+  tiny_dp  tiny_a in train mode with DROP_PATH_RATE=0.5 and recorded per-call masks
+  sm       the real mFormerV1_sm config at 224, B=2, 4 Linear heads (1000/300/80/20)
+plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
+sys.path[:0] = [os.path.join(HERE, "_stubs"), "/root/reference", REPO]
+sys.dont_write_bytecode = True
+
+import logging  # noqa: E402
+import warnings  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+warnings.filterwarnings("ignore")
+logging.disable(logging.CRITICAL)
+
+from linnaeus.config import get_default_config  # noqa: E402
+from linnaeus.models import build_model  # noqa: E402
+from linnaeus.utils.config_utils import load_config, merge_configs  # noqa: E402
+from yacs.config import CfgNode as CN  # noqa: E402
+
+from oracle import mformer_oracle as O  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+SEED = 20251003
+
+
+def base_cfg(img):
+    cfg = get_default_config()
+    arch = load_config("/root/reference/configs/model/archs/mFormerV1/mFormerV1_sm.yaml")
+    cfg.MODEL = merge_configs(cfg.MODEL, arch.MODEL)
+    cfg.MODEL.IMG_SIZE = img
+    cfg.MODEL.USE_FLASH_ATTN = False
+    cfg.TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS = False
+    cfg.MODEL.DROP_PATH_RATE = 0.0
+    return cfg
+
+
+def apply_spec(cfg, spec: O.Spec, head_type="Linear"):
+    cfg.MODEL.CONVNEXT_STAGES.DIMS = list(spec.conv_dims)
+    cfg.MODEL.CONVNEXT_STAGES.DEPTHS = [spec.conv_depths[0], spec.conv_depths[1], 9, 3]
+    cfg.MODEL.ROPE_STAGES.DIMS = list(spec.rope_dims)
+    cfg.MODEL.ROPE_STAGES.DEPTHS = list(spec.rope_depths)
+    cfg.MODEL.ROPE_STAGES.NUM_HEADS = list(spec.rope_heads)
+    cfg.MODEL.ROPE_STAGES.MLP_RATIO = list(spec.mlp_ratio)
+    cfg.MODEL.ONLY_LAST_CLS = spec.only_last_cls
+    cfg.MODEL.DROP_PATH_RATE = spec.drop_path_rate
+    names = [n for n, _ in spec.meta]
+    cfg.DATA.META.ACTIVE = bool(names)
+    for comp in ("TEMPORAL", "SPATIAL", "ELEVATION"):
+        cfg.DATA.META.COMPONENTS[comp].ENABLED = comp in names
+    for n, d in spec.meta:
+        assert cfg.DATA.META.COMPONENTS[n].DIM == d
+    tasks = [t for t, _ in spec.heads]
+    cfg.DATA.TASK_KEYS_H5 = tasks
+    if head_type == "Linear":
+        cfg.MODEL.CLASSIFICATION.HEADS = CN({t: {"TYPE": "Linear"} for t in tasks})
+    else:
+        cfg.MODEL.CLASSIFICATION.HEADS = CN(
+            {t: {"TYPE": head_type, "ROUTING_STRATEGY": "soft", "TEMPERATURE": 1.0, "USE_BIAS": True} for t in tasks}
+        )
+    return cfg
+
+
+def checksum(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().max().item(), t.mean().item(), (t * t).sum().sqrt().item()])
+
+
+def first_slice(t, n=16):
+    return t.detach().reshape(-1)[:n].float().numpy().copy()
+
+
+def load_seeded(model, seed):
+    sd = model.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and "hmatrix" not in k:
+            new[k] = O.seeded_fill(canonical_name(k), v.shape, seed)
+        else:
+            new[k] = v
+    model.load_state_dict(new, strict=True)
+    return {k: v.clone() for k, v in model.state_dict().items()}
+
+
+def canonical_name(k):
+    """Hierarchical heads alias the shared Linear under every task
+    (head.{t}.level_classifiers.{t'}.*); key the fill by the target task only so all aliases
+    agree, and so the same numbers land in head.{t'}.fc.* of the Linear-head layout."""
+    parts = k.split(".")
+    if parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers":
+        return f"head.{parts[3]}.fc.{parts[4]}"
+    return k
+
+
+TAP_MODULES = {
+    "stem": "stem",
+    "stage0": "stages.0.{last0}",
+    "down0": "downsample_layers.0",
+    "stage1": "stages.1.{last1}",
+    "down1": "downsample_layers.1",
+    "rope0": "stages.2.{last2}",
+    "down2": "downsample_layers.2",
+    "rope1": "stages.3.{last3}",
+}
+
+
+def run_case(name, spec, img, batch, head_type="Linear", taxonomy=None, train_drop=False, grads=True):
+    cfg = apply_spec(base_cfg(img), spec, head_type)
+    kwargs = {}
+    if spec.heads:
+        kwargs["num_classes"] = {t: c for t, c in spec.heads}
+    if taxonomy is not None:
+        kwargs["taxonomy_tree"] = taxonomy
+    model = build_model(cfg, **kwargs)
+    ref_sd = load_seeded(model, SEED)
+
+    # the oracle's inventory must reproduce the reference's names/shapes/order (Linear layout)
+    if head_type == "Linear":
+        shapes = O.param_shapes(spec)
+        assert list(shapes.keys()) == list(ref_sd.keys()), (
+            [k for k in shapes if k not in ref_sd], [k for k in ref_sd if k not in shapes],
+            [(a, b) for a, b in zip(shapes, ref_sd) if a != b][:5])
+        for k in shapes:
+            assert tuple(ref_sd[k].shape) == shapes[k], (k, ref_sd[k].shape, shapes[k])
+
+    x, meta = O.seeded_inputs(spec, batch, img, SEED + 1)
+    rec = {"x": x.numpy(), "img": np.array(img), "batch": np.array(batch)}
+    if meta is not None:
+        rec["meta"] = meta.numpy()
+
+    taps = {}
+    hooks = []
+    mods = dict(model.named_modules())
+    last = {f"last{i}": len(model.stages[i]) - 1 for i in range(4)}
+    for tname, path in TAP_MODULES.items():
+        m = mods[path.format(**last)]
+        hooks.append(m.register_forward_hook(lambda mod, inp, out, tname=tname: taps.__setitem__(tname, out.detach())))
+
+    drop_scales = None
+    if train_drop:
+        model.train()
+        torch.manual_seed(777)
+        # replay the draws DropPath makes, call by call (blocks/drop_path.py:31-32): one
+        # rand(B,1,..) per call whose prob > 0 (prob==0 -> nn.Identity, no draw)
+        probs = O.drop_call_probs(spec)
+        drop_scales = []
+        for p in probs:
+            if p == 0.0:
+                drop_scales.append(None)
+            else:
+                keep = 1.0 - p
+                r = torch.rand(batch)
+                drop_scales.append(torch.floor(keep + r) / keep)
+        torch.manual_seed(777)
+        for i, s in enumerate(drop_scales):
+            if s is not None:
+                rec[f"drop_scale_{i}"] = s.numpy()
+    else:
+        model.eval()
+
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    feats = model.forward_features(x, meta)
+    for h in hooks:
+        h.remove()
+    rec["feats"] = feats.detach().numpy()
+    for tname, v in taps.items():
+        rec["tap_" + tname] = checksum(v)
+        rec["tapslice_" + tname] = first_slice(v)
+
+    if spec.heads:
+        if train_drop:
+            torch.manual_seed(777)
+        out = model(x, meta)
+        for t, lg in out.items():
+            rec["logits_" + t] = lg.detach().numpy()
+        if grads:
+            loss = O.probe_loss(out)
+            rec["loss"] = np.array(loss.item())
+            model.zero_grad()
+            loss.backward()
+            seen = {}
+            for k, p_ in model.named_parameters():  # remove_duplicate -> shared heads once
+                if p_.grad is None:
+                    continue
+                ck = canonical_name(k)
+                seen[ck] = p_.grad
+            names = sorted(seen)
+            rec["grad_names"] = np.array(names)
+            rec["grad_norms"] = np.array([seen[k].double().norm().item() for k in names])
+            rec["grad_sums"] = np.array([seen[k].double().sum().item() for k in names])
+            for k in names:
+                rec["gradslice_" + k] = first_slice(seen[k], 8)
+
+    # cross-check the oracle right here, against the live reference (pins the restatement)
+    osd = {canonical_name(k): v for k, v in ref_sd.items() if "hmatrix" not in k}
+    with torch.no_grad():
+        ofe = O.forward_features(osd, spec, x, meta, drop_scales)
+    err = (ofe - feats.detach()).abs().max().item()
+    print(f"[{name}] params={sum(p.numel() for p in model.parameters()):,} oracle-vs-reference max|dfeats| = {err:.3e}")
+    assert err < 5e-5, err
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+    return model
+
+
+def per_op_known_answers():
+    """Small known-answer vectors produced by the reference's own functions/modules."""
+    from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
+    from linnaeus.models.blocks.rope_2d_mhsa import RoPE2DAttention, RoPE2DMHSABlock, apply_rotary_emb, compute_mixed_cis, init_t_xy
+    from linnaeus.models.normalization import ResNormLayer
+
+    g = torch.Generator().manual_seed(SEED + 7)
+    rec = {}
+    # cos table (F1)
+    freqs = O.seeded_fill("x.attn.freqs", (2, 2, 32), SEED)
+    tx, ty = init_t_xy(5, 3)
+    cis = compute_mixed_cis(freqs, tx, ty).to(torch.float32)
+    rec["rope_freqs"] = freqs.numpy()
+    rec["rope_cos_3x5"] = cis.numpy()
+    q = torch.randn(2, 2, 15, 64, generator=g)
+    k = torch.randn(2, 2, 15, 64, generator=g)
+    qr, kr = apply_rotary_emb(q, k, cis)
+    rec.update(rope_q=q.numpy(), rope_k=k.numpy(), rope_q_out=qr.numpy(), rope_k_out=kr.numpy())
+    # LayerNormChannelsFirst
+    ln = LayerNormChannelsFirst(8, eps=1e-6)
+    ln.weight.data = O.seeded_fill("a.norm.weight", (8,), SEED)
+    ln.bias.data = O.seeded_fill("a.norm.bias", (8,), SEED)
+    xi = torch.randn(2, 8, 3, 5, generator=g)
+    rec.update(lncf_x=xi.numpy(), lncf_w=ln.weight.data.numpy(), lncf_b=ln.bias.data.numpy(), lncf_y=ln(xi).detach().numpy())
+    # ConvNeXtBlock (border taps included: 6x5 image is smaller than the 7x7 window)
+    blk = ConvNeXtBlock(8, drop_path=0.0, layer_scale_init_value=1.0).eval()
+    bsd = {kk: O.seeded_fill("stages.0.0." + kk, v.shape, SEED) for kk, v in blk.state_dict().items()}
+    blk.load_state_dict(bsd)
+    xi = torch.randn(2, 8, 6, 5, generator=g)
+    rec.update(cnb_x=xi.numpy(), cnb_y=blk(xi).detach().numpy(), cnb_dw=blk.dwconv(xi).detach().numpy())
+    # Downsample
+    dsl = ConvNeXtDownsampleLayer(8, 16).eval()
+    dsd = {kk: O.seeded_fill("downsample_layers.0." + kk, v.shape, SEED) for kk, v in dsl.state_dict().items()}
+    dsl.load_state_dict(dsd)
+    xi = torch.randn(2, 8, 6, 4, generator=g)
+    rec.update(ds_x=xi.numpy(), ds_y=dsl(xi).detach().numpy())
+    # RoPE attention + block, E=3, grid 3x5, dim 128 (2 heads of 64)
+    att = RoPE2DAttention(128, (3, 5), extra_token_num=3, num_heads=2, qkv_bias=True).eval()
+    asd = {kk: O.seeded_fill("stages.2.0.attn." + kk, v.shape, SEED) for kk, v in att.state_dict().items()}
+    att.load_state_dict(asd)
+    xi = torch.randn(2, 18, 128, generator=g)
+    rec.update(att_x=xi.numpy(), att_y=att(xi, 3, 5).detach().numpy())
+    rb = RoPE2DMHSABlock(128, (3, 5), num_heads=2, qkv_bias=True, extra_token_num=3).eval()
+    rsd = {kk: O.seeded_fill("stages.2.0." + kk, v.shape, SEED) for kk, v in rb.state_dict().items()}
+    rb.load_state_dict(rsd)
+    rec.update(rb_y=rb(xi, 3, 5).detach().numpy())
+    # ResNormLayer inside a meta head
+    seq = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.ReLU(inplace=True), torch.nn.LayerNorm(32), ResNormLayer(32)).eval()
+    msd = {kk: O.seeded_fill("meta_spatial_head_1." + kk, v.shape, SEED) for kk, v in seq.state_dict().items()}
+    seq.load_state_dict(msd)
+    mi = torch.randn(4, 3, generator=g)
+    rec.update(mh_x=mi.numpy(), mh_y=seq(mi).detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "per_op.npz"), **rec)
+    print("[per_op] written")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    tiny_dims = (32, 64, 128, 256)
+    heads2 = (("taxa_L10", 7), ("taxa_L20", 5))
+    tiny_a = O.Spec(conv_dims=tiny_dims, conv_depths=(1, 1), rope_depths=(1, 1), rope_heads=(2, 4), heads=heads2)
+    run_case("tiny_a", tiny_a, 64, 2)
+    tiny_b = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4),
+                    meta=(("TEMPORAL", 2), ("SPATIAL", 3), ("ELEVATION", 10)), only_last_cls=True, heads=heads2)
+    run_case("tiny_b", tiny_b, 96, 3)
+
+    from linnaeus.utils.taxonomy.taxonomy_tree import TaxonomyTree
+    h3 = (("taxa_L10", 6), ("taxa_L20", 3), ("taxa_L30", 2))
+    tree = TaxonomyTree(
+        {"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}},
+        [t for t, _ in h3], {t: c for t, c in h3})
+    tiny_c = O.Spec(conv_dims=tiny_dims, conv_depths=(1, 1), rope_depths=(1, 1), rope_heads=(2, 4), meta=(), heads=h3)
+    run_case("tiny_c", tiny_c, 64, 2, head_type="ConditionalClassifier", taxonomy=tree)
+
+    tiny_dp = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4), heads=heads2, drop_path_rate=0.5)
+    run_case("tiny_dp", tiny_dp, 64, 4, train_drop=True)
+
+    sm = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)))
+    run_case("sm", sm, 224, 2)
+    per_op_known_answers()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""The oracle (oracle/mformer_oracle.py) against the reference's own outputs.
+
+The fixtures under tests/golden/ were produced by tests/golden/gen/make_golden.py, which
+imports the reference in the build container.  These tests pin the CPU restatement; they
+need neither a GPU nor /root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mformer_oracle as O
+from tests.cases import CASES, load_case
+
+
+def _checksum(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().max().item(), t.mean().item(), (t * t).sum().sqrt().item()])
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_dp", "sm"])
+def test_forward_matches_reference(name, golden_dir):
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    taps = {}
+    with torch.no_grad():
+        out = O.forward(sd, spec, x, meta, drops, tap=lambda n, v: taps.__setitem__(n, v))
+    np.testing.assert_allclose(taps["feats"].numpy(), z["feats"], rtol=1e-4, atol=2e-5)
+    for task, _ in spec.heads:
+        ref = z["logits_" + task]
+        np.testing.assert_allclose(out[task].numpy(), ref, rtol=1e-4, atol=2e-5)
+        # class-index argmax must be exact against the reference
+        assert (out[task].argmax(-1).numpy() == ref.argmax(-1)).all()
+    for tname in ("stem", "stage0", "down0", "stage1", "down1", "rope0", "down2", "rope1"):
+        ref = z["tap_" + tname]
+        got = _checksum(taps[tname])
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-4, err_msg=tname)
+        np.testing.assert_allclose(taps[tname].reshape(-1)[:16].numpy(), z["tapslice_" + tname], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_dp"])
+def test_backward_matches_reference(name, golden_dir):
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.forward(sd, spec, x, meta, drops)
+    loss = O.probe_loss(out)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    names = [str(n) for n in z["grad_names"]]
+    assert sorted(k for k, v in sd.items() if v.grad is not None) == names
+    for i, k in enumerate(names):
+        g = sd[k].grad
+        ref_norm = z["grad_norms"][i]
+        assert abs(g.double().norm().item() - ref_norm) <= 2e-4 * max(ref_norm, 1e-3), k
+        np.testing.assert_allclose(g.reshape(-1)[:8].numpy(), z["gradslice_" + k], rtol=2e-3, atol=2e-6, err_msg=k)
+
+
+def test_sm_backward_grad_norms(golden_dir):
+    spec, z, sd, x, meta, drops = load_case("sm", golden_dir)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = O.probe_loss(O.forward(sd, spec, x, meta, drops))
+    loss.backward()
+    names = [str(n) for n in z["grad_names"]]
+    for i, k in enumerate(names):
+        ref_norm = z["grad_norms"][i]
+        assert abs(sd[k].grad.double().norm().item() - ref_norm) <= 5e-4 * max(ref_norm, 1e-3), k
+
+
+def test_param_inventory_sm():
+    shapes = O.param_shapes(CASES["sm"])
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert n == 30_265_691  # sm with four Linear heads 1000/300/80/20
+    n_backbone = sum(int(np.prod(s)) for k, s in shapes.items() if not k.startswith("head."))
+    assert n_backbone == 29_189_091 and len([k for k in shapes if not k.startswith("head.")]) == 225
+
+
+def test_per_op_known_answers(golden_dir):
+    z = np.load(f"{golden_dir}/per_op.npz")
+    T = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    S = 20251003
+    # F1: the "rotation" is a cos-only scaling
+    cos = O.rope_cos_table(T("rope_freqs"), 3, 5)
+    np.testing.assert_allclose(cos.numpy(), z["rope_cos_3x5"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(O.rope_scale_pairs(T("rope_q"), cos).numpy(), z["rope_q_out"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(O.rope_scale_pairs(T("rope_k"), cos).numpy(), z["rope_k_out"], rtol=1e-6, atol=1e-6)
+    y = O.layer_norm_channels_first(T("lncf_x"), T("lncf_w"), T("lncf_b"), 1e-6)
+    np.testing.assert_allclose(y.numpy(), z["lncf_y"], rtol=1e-5, atol=1e-6)
+    # channels-first LN == channels-last LN on the permuted tensor
+    y2 = O.layer_norm_last(T("lncf_x").permute(0, 2, 3, 1), T("lncf_w"), T("lncf_b"), 1e-6).permute(0, 3, 1, 2)
+    np.testing.assert_allclose(y2.numpy(), z["lncf_y"], rtol=1e-5, atol=1e-6)
+    shp = {"gamma": (8,), "dwconv.weight": (8, 1, 7, 7), "dwconv.bias": (8,), "norm.weight": (8,), "norm.bias": (8,),
+           "pwconv1.weight": (32, 8), "pwconv1.bias": (32,), "pwconv2.weight": (8, 32), "pwconv2.bias": (8,)}
+    sd = {"stages.0.0." + k: O.seeded_fill("stages.0.0." + k, s, S) for k, s in shp.items()}
+    np.testing.assert_allclose(
+        O.depthwise_conv7(T("cnb_x"), sd["stages.0.0.dwconv.weight"], sd["stages.0.0.dwconv.bias"]).numpy(), z["cnb_dw"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(O.convnext_block(sd, "stages.0.0.", T("cnb_x"), None).numpy(), z["cnb_y"], rtol=1e-5, atol=2e-6)
+    shp = {"norm.weight": (8,), "norm.bias": (8,), "conv.weight": (16, 8, 2, 2), "conv.bias": (16,)}
+    sd = {"downsample_layers.0." + k: O.seeded_fill("downsample_layers.0." + k, s, S) for k, s in shp.items()}
+    np.testing.assert_allclose(O.downsample(sd, "downsample_layers.0.", T("ds_x")).numpy(), z["ds_y"], rtol=1e-5, atol=2e-6)
+    shp = {"norm1.weight": (128,), "norm1.bias": (128,), "norm2.weight": (128,), "norm2.bias": (128,), "attn.freqs": (2, 2, 32),
+           "attn.qkv.weight": (384, 128), "attn.qkv.bias": (384,), "attn.proj.weight": (128, 128), "attn.proj.bias": (128,),
+           "mlp.fc1.weight": (512, 128), "mlp.fc1.bias": (512,), "mlp.fc2.weight": (128, 512), "mlp.fc2.bias": (128,)}
+    sd = {"stages.2.0." + k: O.seeded_fill("stages.2.0." + k, s, S) for k, s in shp.items()}
+    np.testing.assert_allclose(O.rope_attention(sd, "stages.2.0.attn.", T("att_x"), 3, 5, 2, 3).numpy(), z["att_y"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(O.rope_block(sd, "stages.2.0.", T("att_x"), 3, 5, 2, 3, None, None).numpy(), z["rb_y"], rtol=1e-5, atol=3e-6)
+    shp = {"0.weight": (32, 3), "0.bias": (32,), "2.weight": (32,), "2.bias": (32,), "3.norm_fn1.weight": (32,), "3.norm_fn1.bias": (32,),
+           "3.norm_fn2.weight": (32,), "3.norm_fn2.bias": (32,), "3.w1.weight": (32, 32), "3.w1.bias": (32,), "3.w2.weight": (32, 32), "3.w2.bias": (32,)}
+    sd = {"meta_spatial_head_1." + k: O.seeded_fill("meta_spatial_head_1." + k, s, S) for k, s in shp.items()}
+    np.testing.assert_allclose(O.meta_head(sd, "meta_spatial_head_1.", T("mh_x")).numpy(), z["mh_y"], rtol=1e-5, atol=2e-6)
