@@ -1,0 +1,642 @@
+// MFMA GEMM kernels for gfx950.
+//
+//  gemm_nt : C[M,N] = epilogue(A[M,K] . W[N,K]^T)   forward + data-gradient GEMMs
+//  gemm_tn : dW[N,K] += dY[M,N]^T . A[M,K]          weight gradients (split over M)
+//
+// Tiling (both kernels): 128x128 output tile per 256-thread workgroup, 4 waves as 2x2,
+// each wave owns a 64x64 sub-tile = 4x4 MFMA 16x16 accumulators (fp32).  The K step is
+// 128 BYTES of the contraction dimension (64 bf16 / 32 fp32), so that the LDS image, the
+// 16-byte fragment reads and the swizzle are identical for both storage types; only the
+// MFMA differs (v_mfma_f32_16x16x32_bf16 vs four v_mfma_f32_16x16x4_f32).
+//
+// Orientation: the MFMA "A" operand (rows of D) is fed from W / dY^T and the "B" operand
+// (columns of D) from the activation matrix, i.e. each wave computes a tile of C^T.  A
+// lane then holds consecutive n for one m, which gives 16-element contiguous stores and
+// a vectorised epilogue (bias/gamma as float4).
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+constexpr int TILE = 128;        // rows of each operand tile
+constexpr int ROWB = 128;        // bytes of K per tile row
+constexpr int TILE_BYTES = TILE * ROWB;
+
+struct PatchGeom {
+    int Hin, Win, Cin;
+};
+
+struct GemmP {
+    const unsigned char* A;
+    const unsigned char* W;
+    unsigned char* C;
+    unsigned char* C2;
+    const unsigned char* aux;
+    const float* bias;
+    const float* gamma;
+    const float* rowscale;
+    const float* res;
+    int64_t lda, ldw, ldc, ldc2, ldaux, ldres;
+    int M, N, K;
+    int a_mode, c_mode;
+    PatchGeom pg;
+    RowMap cmap;
+    int act;
+    int rows_per_sample;
+    int tiles_m, tiles_n;
+};
+
+// XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on
+// the same XCD (blocks b and b+8 share an XCD under round-robin dispatch) so that the
+// n-tiles that re-read one A panel hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// 3-bit XOR key of an LDS tile row; chosen so that the permuted fragment reads below
+// (rows {0..3,16..19,32..35,48..51}+4i per 16-lane group) are bank-conflict free.
+__device__ __forceinline__ int row_key(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma<float> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        const float* fa = reinterpret_cast<const float*>(&a);
+        const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc, 0, 0, 0);
+    }
+};
+
+// element offset of the 2x2 patch origin of output pixel m in an NHWC tensor
+__device__ __forceinline__ int64_t patch_base(const PatchGeom& g, int m) {
+    const int Wo = g.Win >> 1, Ho = g.Hin >> 1;
+    const int wo = m % Wo;
+    const int t = m / Wo;
+    const int ho = t % Ho;
+    const int b = t / Ho;
+    return (((int64_t)b * g.Hin + 2 * ho) * g.Win + 2 * wo) * g.Cin;
+}
+// offset inside a patch for patch-column k = (kh*2 + kw)*Cin + c
+__device__ __forceinline__ int64_t patch_col(const PatchGeom& g, int k) {
+    const int two_c = 2 * g.Cin;
+    const int kh = k / two_c;
+    return (int64_t)kh * g.Win * g.Cin + (k - kh * two_c);
+}
+
+template <typename T, bool OUT_F32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmP p) {
+    constexpr int EPV = TT<T>::EPV;
+    constexpr int BK = 8 * EPV;  // elements per K tile (128 bytes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 buf][A, W][TILE_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int s = lane & 15, g = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tn = logical % p.tiles_n;
+    const int tm = logical / p.tiles_n;
+    const int m0 = tm * TILE, n0 = tn * TILE;
+
+    // ---- global -> register staging: 4 x 16B chunks per operand per thread ----
+    int ld_row[4], ld_ch[4];
+    int64_t a_base[4];
+    int64_t w_base[4];
+    bool a_ok[4], w_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        ld_row[i] = q >> 3;
+        ld_ch[i] = q & 7;
+        const int m = m0 + ld_row[i];
+        const int n = n0 + ld_row[i];
+        a_ok[i] = m < p.M;
+        w_ok[i] = n < p.N;
+        const int mc = a_ok[i] ? m : 0;
+        a_base[i] = p.a_mode == LNX_ADDR_PATCH2 ? patch_base(p.pg, mc) : (int64_t)mc * p.lda;
+        w_base[i] = (int64_t)(w_ok[i] ? n : 0) * p.ldw;
+    }
+    uint4 ra[4], rw[4];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k0 + ld_ch[i] * EPV;
+            const bool kin = kk < p.K;
+            uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
+            if (a_ok[i] && kin) {
+                const int64_t off = a_base[i] + (p.a_mode == LNX_ADDR_PATCH2 ? patch_col(p.pg, kk) : (int64_t)kk);
+                va = ld16(p.A + off * sizeof(T));
+            }
+            if (w_ok[i] && kin) vw = ld16(p.W + (w_base[i] + kk) * sizeof(T));
+            ra[i] = va;
+            rw[i] = vw;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+        unsigned char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = ld_row[i] * ROWB + ((ld_ch[i] ^ row_key(ld_row[i])) << 4);
+            st16(sa + off, ra[i]);
+            st16(sw + off, rw[i]);
+        }
+    };
+
+    // ---- fragment addressing (lane-constant) ----
+    const int frag_row = (s >> 2) * 16 + (s & 3);           // + 4*i for fragment i
+    const int frag_key = ((s >> 1) & 1) | ((s >> 2) << 1);  // == row_key(frag_row + 4*i + 64*w)
+    const int a_row0 = wm * 64 + frag_row;
+    const int w_row0 = wn * 64 + frag_row;
+
+    f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* sw = sa + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((g + 4 * kk) ^ frag_key) << 4;
+            uint4 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = ld16(sw + (w_row0 + 4 * i) * ROWB + ch);
+                af[i] = ld16(sa + (a_row0 + 4 * i) * ROWB + ch);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc[ni][mi], wf[ni], af[mi]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (s, g) holds, for each mi, 16 consecutive n of row m ----
+    const int nb = n0 + wn * 64 + g * 16;  // first n of this lane
+    if (nb >= p.N) return;
+    const int nvalid = min(16, p.N - nb);
+    float bias[16], gam[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        bias[j] = (p.bias && j < nvalid) ? p.bias[nb + j] : 0.f;
+        gam[j] = (p.gamma && j < nvalid) ? p.gamma[nb + j] : 1.f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = m0 + wm * 64 + (s >> 2) * 16 + mi * 4 + (s & 3);
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[ni][mi][r] + bias[ni * 4 + r];
+        if (p.C2) {
+            T* c2 = reinterpret_cast<T*>(p.C2) + (int64_t)m * p.ldc2 + nb;
+            if (nvalid == 16 && ((((uintptr_t)c2) & 15) == 0)) {
+                Vec16<T> o;
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                    st16(c2 + h * EPV, o.raw);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) c2[j] = from_f<T>(v[j]);
+            }
+        }
+        if (p.act == LNX_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
+        } else if (p.act == LNX_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD) {
+            const T* ax = reinterpret_cast<const T*>(p.aux) + (int64_t)m * p.ldaux + nb;
+            float a[16];
+            if (nvalid == 16 && ((((uintptr_t)ax) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+                    Vec16<T> t;
+                    t.raw = ld16(ax + h * EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) a[h * EPV + j] = t.get(j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] = j < nvalid ? to_f(ax[j]) : 0.f;
+            }
+            if (p.act == LNX_ACT_GELU_BWD) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(a[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
+            }
+        }
+        float rs = 1.f;
+        if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= gam[j] * rs;
+
+        int64_t coff;  // element offset of (m, nb) in C / res
+        int64_t roff;
+        if (p.c_mode == LNX_ADDR_PATCH2) {
+            coff = patch_base(p.pg, m) + patch_col(p.pg, nb);
+            roff = coff;
+        } else {
+            const int64_t row = map_row(p.cmap, m);
+            coff = row * p.ldc + nb;
+            roff = row * p.ldres + nb;
+        }
+        if (p.res) {
+            const float* rp = p.res + roff;
+            if (nvalid == 16 && ((((uintptr_t)rp) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
+                    v[4 * h + 0] += t.x;
+                    v[4 * h + 1] += t.y;
+                    v[4 * h + 2] += t.z;
+                    v[4 * h + 3] += t.w;
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += rp[j];
+            }
+        }
+        if (OUT_F32) {
+            float* cp = reinterpret_cast<float*>(p.C) + coff;
+            if (nvalid == 16 && ((((uintptr_t)cp) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(cp + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            } else {
+                for (int j = 0; j < nvalid; ++j) cp[j] = v[j];
+            }
+        } else {
+            T* cp = reinterpret_cast<T*>(p.C) + coff;
+            if (nvalid == 16 && ((((uintptr_t)cp) & 15) == 0)) {
+                Vec16<T> o;
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                    st16(cp + h * EPV, o.raw);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) cp[j] = from_f<T>(v[j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// weight-gradient GEMM (contraction over the row index M of both operands)
+// ------------------------------------------------------------------------------------
+struct WgradP {
+    const unsigned char* dY;
+    const unsigned char* A;
+    float* dW;
+    float* db;
+    int64_t lddy, lda, lddw;
+    int M, N, K;
+    int a_mode;
+    PatchGeom pg;
+    int k_perm_c;
+    int tiles_n, tiles_k, splits, m_per_split;
+};
+
+template <typename T> struct WgradCfg;
+template <> struct WgradCfg<bf16_t> {
+    static constexpr int BMC = 64;              // rows of M per LDS tile
+    static constexpr int ROW = 128 * 2 + 32;    // bytes per LDS row (+32B pad: tr reads conflict-free)
+};
+template <> struct WgradCfg<float> {
+    static constexpr int BMC = 32;
+    static constexpr int ROW = 128 * 4 + 64;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ uint2 ds_read_tr16_b64(const unsigned char* p) {
+    // 4 rows x 16 columns of 16-bit elements per 16-lane group, delivered column-major.
+    // EXEC must be all ones (the gather crosses lanes): only called from uniform code.
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const WgradP p) {
+    constexpr int EPV = TT<T>::EPV;
+    constexpr int BMC = WgradCfg<T>::BMC;
+    constexpr int ROW = WgradCfg<T>::ROW;
+    constexpr int OPB = BMC * ROW;             // bytes per operand tile
+    constexpr int CPR = 128 / EPV;             // 16-byte chunks per tile row
+    constexpr int NLD = BMC * CPR / 256;       // chunks per thread per operand
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 buf][dY, A][OPB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int s = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int tk = bid % p.tiles_k;
+    const int tn = bid / p.tiles_k;
+    const int n0 = tn * TILE, k0 = tk * TILE;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+
+    int ld_row[NLD], ld_ch[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int q = tid + 256 * i;
+        ld_row[i] = q / CPR;
+        ld_ch[i] = q % CPR;
+    }
+    uint4 ry[NLD], ra[NLD];
+    auto load_tile = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int m = mt + ld_row[i];
+            const int n = n0 + ld_ch[i] * EPV;
+            const int k = k0 + ld_ch[i] * EPV;
+            uint4 vy = make_uint4(0, 0, 0, 0), va = make_uint4(0, 0, 0, 0);
+            if (m < m_end) {
+                if (n < p.N) vy = ld16(p.dY + ((int64_t)m * p.lddy + n) * sizeof(T));
+                if (k < p.K) {
+                    const int64_t off = p.a_mode == LNX_ADDR_PATCH2 ? patch_base(p.pg, m) + patch_col(p.pg, k) : (int64_t)m * p.lda + k;
+                    va = ld16(p.A + off * sizeof(T));
+                }
+            }
+            ry[i] = vy;
+            ra[i] = va;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* sy = smem + buf * 2 * OPB;
+        unsigned char* sa = sy + OPB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int off = ld_row[i] * ROW + ld_ch[i] * 16;
+            st16(sy + off, ry[i]);
+            st16(sa + off, ra[i]);
+        }
+    };
+
+    f32x4_t acc[4][4];  // [ni][ki]
+    f32x4_t accb[4];    // bias: colsum(dY) via MFMA against a ones operand
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.db != nullptr && tk == 0 && wk == 0;
+
+    const int ntile = (m_end - m_begin + BMC - 1) / BMC;
+    load_tile(m_begin);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < ntile) load_tile(m_begin + (it + 1) * BMC);
+        const unsigned char* sy = smem + buf * 2 * OPB;
+        const unsigned char* sa = sy + OPB;
+        if constexpr (sizeof(T) == 2) {
+            // contraction slot (g, j) of a 32-row step <-> row 4g + j (j<4), 16 + 4g + (j-4)
+            const int q = s >> 2, pp = s & 3;
+#pragma unroll
+            for (int ks = 0; ks < BMC / 32; ++ks) {
+                uint4 yf[4], af[4];
+                const int r0 = ks * 32 + 4 * g + q;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cy = (wn * 64 + i * 16 + 4 * pp) * 2;
+                    const int ca = (wk * 64 + i * 16 + 4 * pp) * 2;
+                    const uint2 y0 = ds_read_tr16_b64(sy + r0 * ROW + cy);
+                    const uint2 y1 = ds_read_tr16_b64(sy + (r0 + 16) * ROW + cy);
+                    const uint2 a0 = ds_read_tr16_b64(sa + r0 * ROW + ca);
+                    const uint2 a1 = ds_read_tr16_b64(sa + (r0 + 16) * ROW + ca);
+                    yf[i] = make_uint4(y0.x, y0.y, y1.x, y1.y);
+                    af[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int ki = 0; ki < 4; ++ki) Mfma<T>::run(acc[ni][ki], yf[ni], af[ki]);
+                if (do_bias) {
+                    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) Mfma<T>::run(accb[ni], yf[ni], ones);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ms = 0; ms < BMC / 4; ++ms) {
+                float yf[4], af[4];
+                const int r = ms * 4 + g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    yf[i] = *reinterpret_cast<const float*>(sy + r * ROW + (wn * 64 + i * 16 + s) * 4);
+                    af[i] = *reinterpret_cast<const float*>(sa + r * ROW + (wk * 64 + i * 16 + s) * 4);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int ki = 0; ki < 4; ++ki)
+                        acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[ni], af[ki], acc[ni][ki], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[ni], 1.0f, accb[ni], 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < ntile) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[row = n slot][col = k slot]: lane (s, g) holds n = .. + 4g + r, k = .. + s
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + ni * 16 + 4 * g + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int ki = 0; ki < 4; ++ki) {
+                const int k = k0 + wk * 64 + ki * 16 + s;
+                if (k >= p.K) continue;
+                int col = k;
+                if (p.k_perm_c > 0) {
+                    const int P = p.K / p.k_perm_c;
+                    const int pp = k / p.k_perm_c;
+                    col = (k - pp * p.k_perm_c) * P + pp;
+                }
+                atomicAdd(p.dW + (int64_t)n * p.lddw + col, acc[ni][ki][r]);
+            }
+            if (do_bias && s == 0) atomicAdd(p.db + n, accb[ni][r]);
+        }
+    }
+}
+
+template <typename T, bool OUT_F32>
+int launch_nt(const GemmP& p, hipStream_t st) {
+    const int grid = p.tiles_m * p.tiles_n;
+    const size_t lds = 4 * TILE_BYTES;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, OUT_F32>), dim3(grid), dim3(256), lds, st, p);
+    return 0;
+}
+
+template <typename T>
+int launch_tn(const WgradP& p, hipStream_t st) {
+    const int grid = p.tiles_n * p.tiles_k * p.splits;
+    const size_t lds = 4 * WgradCfg<T>::BMC * WgradCfg<T>::ROW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(grid), dim3(256), lds, st, p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
+    LNX_CHECK(a != nullptr, "lnx_gemm_nt: null args");
+    LNX_CHECK(a->dtype == LNX_F32 || a->dtype == LNX_BF16, "lnx_gemm_nt: bad dtype %d", a->dtype);
+    const int epv = a->dtype == LNX_F32 ? 4 : 8;
+    LNX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "lnx_gemm_nt: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+    LNX_CHECK(a->K % epv == 0, "lnx_gemm_nt: K=%d must be a multiple of %d", a->K, epv);
+    LNX_CHECK(a->A && a->W && a->C, "lnx_gemm_nt: null operand");
+    LNX_CHECK(a->ldw % epv == 0, "lnx_gemm_nt: ldw=%lld must be a multiple of %d", (long long)a->ldw, epv);
+    LNX_CHECK((((uintptr_t)a->A) & 15) == 0 && (((uintptr_t)a->W) & 15) == 0, "lnx_gemm_nt: A/W must be 16-byte aligned");
+    if (a->a_mode == LNX_ADDR_PATCH2) {
+        LNX_CHECK(a->Hin % 2 == 0 && a->Win % 2 == 0 && a->Cin % epv == 0, "lnx_gemm_nt: bad PATCH2 geometry %dx%dx%d", a->Hin, a->Win, a->Cin);
+        LNX_CHECK(a->K == 4 * a->Cin, "lnx_gemm_nt: PATCH2 needs K == 4*Cin");
+        LNX_CHECK(a->M % ((a->Hin / 2) * (a->Win / 2)) == 0, "lnx_gemm_nt: PATCH2 needs M == B*Ho*Wo");
+    } else {
+        LNX_CHECK(a->lda % epv == 0, "lnx_gemm_nt: lda=%lld must be a multiple of %d", (long long)a->lda, epv);
+    }
+    if (a->c_mode == LNX_ADDR_PATCH2) {
+        LNX_CHECK(a->Hin % 2 == 0 && a->Win % 2 == 0 && a->Cin % 16 == 0, "lnx_gemm_nt: bad PATCH2 output geometry");
+        LNX_CHECK(a->N == 4 * a->Cin, "lnx_gemm_nt: PATCH2 output needs N == 4*Cin");
+        LNX_CHECK(a->a_mode == LNX_ADDR_PLAIN, "lnx_gemm_nt: PATCH2 on both sides is not supported");
+    }
+    if (a->act == LNX_ACT_GELU_BWD || a->act == LNX_ACT_RELU_BWD) LNX_CHECK(a->aux != nullptr, "lnx_gemm_nt: act %d needs aux", a->act);
+    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_gemm_nt: rowscale needs rows_per_sample");
+
+    GemmP p;
+    p.A = (const unsigned char*)a->A;
+    p.W = (const unsigned char*)a->W;
+    p.C = (unsigned char*)a->C;
+    p.C2 = (unsigned char*)a->c2;
+    p.aux = (const unsigned char*)a->aux;
+    p.bias = a->bias;
+    p.gamma = a->gamma;
+    p.rowscale = a->rowscale;
+    p.res = a->res;
+    p.lda = a->lda;
+    p.ldw = a->ldw;
+    p.ldc = a->ldc;
+    p.ldc2 = a->ldc2;
+    p.ldaux = a->ldaux;
+    p.ldres = a->ldres;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.a_mode = a->a_mode;
+    p.c_mode = a->c_mode;
+    p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
+    p.cmap = RowMap{a->c_map.group, a->c_map.pad, a->c_map.off};
+    p.act = a->act;
+    p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.tiles_m = cdiv(a->M, TILE);
+    p.tiles_n = cdiv(a->N, TILE);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == LNX_BF16) {
+        if (a->out_f32) launch_nt<bf16_t, true>(p, st);
+        else launch_nt<bf16_t, false>(p, st);
+    } else {
+        launch_nt<float, true>(p, st);  // T == float: both output kinds are fp32
+    }
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
+    LNX_CHECK(a != nullptr, "lnx_gemm_tn: null args");
+    LNX_CHECK(a->dtype == LNX_F32 || a->dtype == LNX_BF16, "lnx_gemm_tn: bad dtype %d", a->dtype);
+    const int epv = a->dtype == LNX_F32 ? 4 : 8;
+    LNX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "lnx_gemm_tn: empty problem");
+    LNX_CHECK(a->dY && a->A && a->dW, "lnx_gemm_tn: null operand");
+    LNX_CHECK(a->N % epv == 0 && a->lddy % epv == 0, "lnx_gemm_tn: N=%d/lddy must be multiples of %d", a->N, epv);
+    LNX_CHECK(a->K % epv == 0, "lnx_gemm_tn: K=%d must be a multiple of %d", a->K, epv);
+    LNX_CHECK((((uintptr_t)a->A) & 15) == 0 && (((uintptr_t)a->dY) & 15) == 0, "lnx_gemm_tn: operands must be 16-byte aligned");
+    if (a->a_mode == LNX_ADDR_PATCH2) {
+        LNX_CHECK(a->Hin % 2 == 0 && a->Win % 2 == 0 && a->Cin % epv == 0 && a->K == 4 * a->Cin, "lnx_gemm_tn: bad PATCH2 geometry");
+    } else {
+        LNX_CHECK(a->lda % epv == 0, "lnx_gemm_tn: lda must be a multiple of %d", epv);
+    }
+    if (a->k_perm_c > 0) LNX_CHECK(a->K % a->k_perm_c == 0, "lnx_gemm_tn: K %% k_perm_c != 0");
+    WgradP p;
+    p.dY = (const unsigned char*)a->dY;
+    p.A = (const unsigned char*)a->A;
+    p.dW = a->dW;
+    p.db = a->db;
+    p.lddy = a->lddy;
+    p.lda = a->lda;
+    p.lddw = a->lddw;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.a_mode = a->a_mode;
+    p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
+    p.k_perm_c = a->k_perm_c;
+    p.tiles_n = cdiv(a->N, TILE);
+    p.tiles_k = cdiv(a->K, TILE);
+    const int bmc = a->dtype == LNX_BF16 ? 64 : 32;
+    int splits = a->splits;
+    if (splits <= 0) {
+        // aim at ~2 workgroups per CU, but keep >= 4 M-tiles of work per split
+        const int tiles = p.tiles_n * p.tiles_k;
+        splits = cdiv(2 * 256, tiles);
+        const int max_splits = cdiv(a->M, 4 * bmc);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    int mps = cdiv(a->M, splits);
+    mps = cdiv(mps, bmc) * bmc;
+    p.splits = cdiv(a->M, mps);
+    p.m_per_split = mps;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == LNX_BF16) launch_tn<bf16_t>(p, st);
+    else launch_tn<float>(p, st);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

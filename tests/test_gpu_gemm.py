@@ -1,0 +1,216 @@
+"""GEMM kernels (lnx_gemm_nt / lnx_gemm_tn) against plain PyTorch fp32 on the same op."""
+import ctypes as C
+
+import pytest
+import torch
+
+from linnaeus_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def run_nt(A, W, dtype, out_f32, bias=None, act=0, aux=None, gamma=None, rowscale=None, rps=0, res=None, want_c2=False,
+           c_map=(0, 0, 0), out_rows=None):
+    M, K = A.shape
+    N = W.shape[0]
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    odt = torch.float32 if out_f32 else tdt
+    out = torch.full((out_rows or M, N), float("nan"), device="cuda", dtype=odt) if res is None else res.clone().to(odt)
+    c2 = torch.empty(M, N, device="cuda", dtype=tdt) if want_c2 else None
+    a = L.GemmArgs()
+    a.dtype, a.M, a.N, a.K = dtype, M, N, K
+    a.A, a.lda, a.W, a.ldw = _ptr(A), A.stride(0), _ptr(W), W.stride(0)
+    a.C, a.ldc, a.out_f32 = _ptr(out), out.stride(0), int(out_f32)
+    a.c_map = L.RowMap(*c_map)
+    a.bias = _ptr(bias)
+    a.c2, a.ldc2 = _ptr(c2), (c2.stride(0) if c2 is not None else 0)
+    a.act, a.aux, a.ldaux = act, _ptr(aux), (aux.stride(0) if aux is not None else 0)
+    a.gamma, a.rowscale, a.rows_per_sample = _ptr(gamma), _ptr(rowscale), rps
+    a.res, a.ldres = _ptr(res), (res.stride(0) if res is not None else 0)
+    L.check(L.lib().lnx_gemm_nt(C.byref(a), _stream()), "lnx_gemm_nt")
+    torch.cuda.synchronize()
+    return out, c2
+
+
+SHAPES = [(128, 128, 64), (256, 384, 96), (200, 96, 384), (333, 1000, 768), (64, 20, 768), (1, 7, 32), (777, 1152, 384)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_nt_plain(M, N, K, dtype):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = torch.randn(N, K, generator=g).cuda() / K**0.5
+    b = torch.randn(N, generator=g).cuda()
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    At, Wt = A.to(tdt), W.to(tdt)
+    out, _ = run_nt(At, Wt, dtype, True, bias=b)
+    ref = At.double() @ Wt.double().T + b.double()
+    tol = 2e-5 if dtype == L.F32 else 2e-5  # operands are already rounded; accumulation is fp32 in both modes
+    torch.testing.assert_close(out.double(), ref, rtol=tol, atol=tol * 4)
+    if dtype == L.BF16:
+        out2, _ = run_nt(At, Wt, dtype, False, bias=b)
+        torch.testing.assert_close(out2.float(), ref.float(), rtol=8e-3, atol=8e-3)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_nt_asymmetric_identity(dtype):
+    """A = I with an asymmetric W catches row/col swaps in the C write."""
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    K = 128
+    A = torch.eye(K, device="cuda", dtype=tdt)
+    W = (torch.arange(160 * K, device="cuda").reshape(160, K) % 251).to(tdt)
+    out, _ = run_nt(A, W, dtype, True)
+    assert torch.equal(out, W.float().T)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_nt_epilogues(dtype):
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    Bsz, rows, K, N = 3, 50, 192, 96
+    M = Bsz * rows
+    A = torch.randn(M, K, generator=g).cuda().to(tdt)
+    W = (torch.randn(N, K, generator=g) / K**0.5).cuda().to(tdt)
+    b = torch.randn(N, generator=g).cuda()
+    gam = torch.randn(N, generator=g).cuda()
+    rs = torch.tensor([0.0, 1.25, 1.25]).cuda()
+    res = torch.randn(M, N, generator=g).cuda()
+    z = A.double() @ W.double().T + b.double()
+    tol = dict(rtol=3e-5, atol=3e-5)
+    # GELU with second output (pre-activation)
+    out, c2 = run_nt(A, W, dtype, True, bias=b, act=L.ACT_GELU, want_c2=True)
+    torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **tol)
+    torch.testing.assert_close(c2.double(), z, rtol=1e-5 if dtype == L.F32 else 8e-3, atol=1e-5 if dtype == L.F32 else 8e-3)
+    # LayerScale * DropPath + residual, pre-gamma value saved
+    out, c2 = run_nt(A, W, dtype, True, bias=b, gamma=gam, rowscale=rs, rps=rows, res=res, want_c2=True)
+    ref = res.double() + z * gam.double() * rs.double().repeat_interleave(rows)[:, None]
+    torch.testing.assert_close(out.double(), ref, **tol)
+    # GELU backward epilogue
+    aux = torch.randn(M, N, generator=g).cuda().to(tdt)
+    out, _ = run_nt(A, W, dtype, True, act=L.ACT_GELU_BWD, aux=aux)
+    x = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    torch.testing.assert_close(out.double(), (z - b.double()) * x.grad, rtol=1e-4, atol=1e-4)
+    # ReLU / ReLU backward
+    out, _ = run_nt(A, W, dtype, True, bias=b, act=L.ACT_RELU)
+    torch.testing.assert_close(out.double(), z.clamp_min(0), **tol)
+    out, _ = run_nt(A, W, dtype, True, act=L.ACT_RELU_BWD, aux=aux)
+    torch.testing.assert_close(out.double(), (z - b.double()) * (aux.double() > 0), **tol)
+    # token row map: each sample gets E=3 extra leading rows
+    E = 3
+    canvas = torch.zeros(Bsz * (rows + E), N, device="cuda")
+    out, _ = run_nt(A, W, dtype, True, bias=b, res=canvas, c_map=(rows, E, E), out_rows=Bsz * (rows + E))
+    got = out.view(Bsz, rows + E, N)
+    assert torch.equal(got[:, :E], torch.zeros_like(got[:, :E]))
+    torch.testing.assert_close(got[:, E:].reshape(M, N).double(), z, **tol)
+
+
+def _patches_nhwc(x):  # x [B,H,W,C] -> [B*Ho*Wo, 4C] with k = (kh*2+kw)*C + c
+    B, H, W, Cc = x.shape
+    p = x.view(B, H // 2, 2, W // 2, 2, Cc).permute(0, 1, 3, 2, 4, 5)
+    return p.reshape(B * (H // 2) * (W // 2), 4 * Cc)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_nt_patch2_modes(dtype):
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    B, H, Wd, Cc, N = 2, 6, 10, 32, 48
+    x = torch.randn(B, H, Wd, Cc, generator=g).cuda().to(tdt)
+    W = (torch.randn(N, 4 * Cc, generator=g) / (4 * Cc) ** 0.5).cuda().to(tdt)
+    M = B * (H // 2) * (Wd // 2)
+    out = torch.empty(M, N, device="cuda")
+    a = L.GemmArgs()
+    a.dtype, a.M, a.N, a.K = dtype, M, N, 4 * Cc
+    a.A, a.W, a.ldw = _ptr(x), _ptr(W), W.stride(0)
+    a.a_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, H, Wd, Cc
+    a.C, a.ldc, a.out_f32 = _ptr(out), N, 1
+    L.check(L.lib().lnx_gemm_nt(C.byref(a), _stream()), "gemm patch2 A")
+    torch.cuda.synchronize()
+    ref = _patches_nhwc(x).double() @ W.double().T
+    torch.testing.assert_close(out.double(), ref, rtol=3e-5, atol=3e-5)
+    # scatter (data gradient of the 2x2 conv): dX_patches = dY . Wt^T, Wt = [4C, N]
+    dY = torch.randn(M, N, generator=g).cuda().to(tdt)
+    Wt = W.T.contiguous()
+    dx = torch.full((B, H, Wd, Cc), float("nan"), device="cuda")
+    a = L.GemmArgs()
+    a.dtype, a.M, a.N, a.K = dtype, M, 4 * Cc, N
+    a.A, a.lda, a.W, a.ldw = _ptr(dY), N, _ptr(Wt), N
+    a.c_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, H, Wd, Cc
+    a.C, a.out_f32 = _ptr(dx), 1
+    L.check(L.lib().lnx_gemm_nt(C.byref(a), _stream()), "gemm patch2 C")
+    torch.cuda.synchronize()
+    refp = dY.double() @ Wt.double().T
+    torch.testing.assert_close(_patches_nhwc(dx).double(), refp, rtol=3e-5, atol=3e-5)
+
+
+def run_tn(dY, A, dtype, bias=True, splits=0, k_perm_c=0, patch=None):
+    M, N = dY.shape
+    K = A.shape[1] if patch is None else 4 * patch[2]
+    dW = torch.zeros(N, K, device="cuda")
+    db = torch.zeros(N, device="cuda") if bias else None
+    a = L.WgradArgs()
+    a.dtype, a.M, a.N, a.K = dtype, M, N, K
+    a.dY, a.lddy, a.A = _ptr(dY), dY.stride(0), _ptr(A)
+    if patch is None:
+        a.lda = A.stride(0)
+    else:
+        a.a_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, *patch
+    a.dW, a.lddw, a.db, a.splits, a.k_perm_c = _ptr(dW), K, _ptr(db), splits, k_perm_c
+    L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+    torch.cuda.synchronize()
+    return dW, db
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 96, 384), (5000, 384, 96), (199, 1152, 384), (77, 24, 16), (4096, 768, 3072)])
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_tn(M, N, K, dtype):
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).cuda().to(tdt)
+    A = torch.randn(M, K, generator=g).cuda().to(tdt)
+    dW, db = run_tn(dY, A, dtype)
+    ref = dY.double().T @ A.double()
+    scale = M**0.5
+    torch.testing.assert_close(dW.double(), ref, rtol=1e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(db.double(), dY.double().sum(0), rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_tn_asymmetric(dtype):
+    """dY = one-hot rows picks single rows of A: catches transposed/permuted writes exactly."""
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    M, N, K = 128, 128, 256
+    A = (torch.arange(M * K, device="cuda").reshape(M, K) % 253).to(tdt)
+    dY = torch.zeros(M, N, device="cuda", dtype=tdt)
+    idx = torch.arange(N, device="cuda")
+    dY[(idx * 37) % M, idx] = 1
+    dW, db = run_tn(dY, A, dtype, splits=1)
+    assert torch.equal(dW, A.float()[(idx * 37) % M])
+    assert torch.equal(db, torch.ones(N, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_tn_patch2_conv_weight_layout(dtype):
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    B, H, Wd, Cc, N = 2, 8, 6, 32, 64
+    x = torch.randn(B, H, Wd, Cc, generator=g).cuda().to(tdt)
+    M = B * (H // 2) * (Wd // 2)
+    dY = torch.randn(M, N, generator=g).cuda().to(tdt)
+    dW, _ = run_tn(dY, x, dtype, k_perm_c=Cc, patch=(H, Wd, Cc))
+    # reference: conv2d weight gradient in torch layout [N, C, 2, 2]
+    xn = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    w = torch.zeros(N, Cc, 2, 2, device="cuda", dtype=torch.double, requires_grad=True)
+    y = torch.nn.functional.conv2d(xn, w, stride=2)
+    y.backward(dY.double().view(B, H // 2, Wd // 2, N).permute(0, 3, 1, 2))
+    torch.testing.assert_close(dW.double().view(N, Cc, 2, 2), w.grad, rtol=1e-4, atol=1e-4)
