@@ -97,9 +97,178 @@ typedef struct lnx_wgrad_args {
                        (torch conv weight layout [N, C, kh, kw]) */
     float* db;      /* [N] or NULL */
     int splits;     /* 0: choose automatically */
+    int k_store;    /* >0: only columns k < k_store are stored (zero-padded K) */
 } lnx_wgrad_args;
 
 int lnx_gemm_tn(const lnx_wgrad_args* args, void* stream);
+
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension C (biased variance, eps inside the sqrt).
+ * In NHWC memory this is also the reference's LayerNormChannelsFirst.
+ *   nn.LayerNorm: blocks/convnext.py:59, rope_2d_mhsa.py:546-547, mFormerV1.py:271-273,
+ *   294,320-328, res_norm_layer.py:18-19; LayerNormChannelsFirst: blocks/convnext.py:21-43.
+ * -----------------------------------------------------------------------------------*/
+typedef struct lnx_ln_args {
+    int M, C;
+    float eps;
+    const void* x;      /* rows via x_map, leading dimension ldx */
+    int x_dtype;
+    int64_t ldx;
+    lnx_rowmap x_map;
+    const float* w;     /* [C] */
+    const float* b;     /* [C] */
+    void* y;            /* rows via y_map */
+    int y_dtype;
+    int64_t ldy;
+    lnx_rowmap y_map;
+    const void* add;    /* optional [M, C] of x_dtype added to the output (ResNormLayer skip) */
+    int64_t ldadd;
+    float* mean;        /* [M] or NULL */
+    float* rstd;        /* [M] or NULL */
+} lnx_ln_args;
+int lnx_layernorm_fwd(const lnx_ln_args* args, void* stream);
+
+typedef struct lnx_ln_bwd_args {
+    int M, C;
+    const void* dy;     /* rows via dy_map */
+    int dy_dtype;
+    int64_t lddy;
+    lnx_rowmap dy_map;
+    const void* x;      /* forward input, rows via x_map */
+    int x_dtype;
+    int64_t ldx;
+    lnx_rowmap x_map;
+    const float* w;
+    const float* mean;
+    const float* rstd;
+    const float* gin;   /* optional fp32 gradient to add (rows via x_map, ldgin); may alias dx */
+    int64_t ldgin;
+    void* dx;           /* rows via x_map */
+    int dx_dtype;
+    int64_t lddx;
+    float* dw;          /* [C] += (fp32 atomics) or NULL */
+    float* db;
+    int relu_mask;      /* 1: x is a ReLU output feeding this LN; dx *= (x > 0) */
+} lnx_ln_bwd_args;
+int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Depthwise 7x7 convolution, padding 3, NHWC (nn.Conv2d(C, C, 7, padding=3, groups=C),
+ * blocks/convnext.py:56-58) and its two gradients.  Weights are passed as [49][C] fp32
+ * (tap-major; lnx_prep_weights produces this from torch's [C,1,7,7]).
+ * -----------------------------------------------------------------------------------*/
+typedef struct lnx_dwconv_args {
+    int B, H, W, C;       /* C % 32 == 0 */
+    const void* x;        /* [B,H,W,C] */
+    int x_dtype;
+    const float* w49;     /* [49][C] */
+    const float* bias;    /* [C] or NULL */
+    int flip;             /* 1: correlate with the flipped kernel (data gradient) */
+    const float* res;     /* optional fp32 [B,H,W,C] added to the output (may alias y) */
+    void* y;              /* [B,H,W,C] */
+    int y_dtype;
+} lnx_dwconv_args;
+int lnx_dwconv7_fwd(const lnx_dwconv_args* args, void* stream);
+
+typedef struct lnx_dwconv_wgrad_args {
+    int B, H, W, C;
+    const void* x;        /* forward input [B,H,W,C] */
+    int x_dtype;
+    const void* dy;       /* [B,H,W,C] */
+    int dy_dtype;
+    float* dw;            /* torch layout [C,1,7,7], += atomics */
+    float* db;            /* [C] += or NULL */
+} lnx_dwconv_wgrad_args;
+int lnx_dwconv7_wgrad(const lnx_dwconv_wgrad_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Attention with the reference's cos-only "2D RoPE" (SURVEY F1), global over N tokens.
+ *   cos table: rope_2d_mhsa.py:56-73,114-155,397-408; q,k scaling :176-218,440-456;
+ *   scores/softmax/AV :495-501.  head_dim is 64 for every shipped config.
+ * qkv is the raw output of the qkv Linear, [B*N, 3*C] with column = which*C + head*64 + d
+ * (:432-437); o is [B*N, C] with column = head*64 + d (:501).  The first E tokens of each
+ * sample are extra (CLS/meta) tokens and are not scaled by cos.
+ * -----------------------------------------------------------------------------------*/
+int lnx_rope_cos_table(const float* freqs /* [2,heads,32] */, int heads, int H, int W, float* cos_out /* [H*W,heads,32] */,
+                       void* stream);
+/* dfreqs[2,heads,32] += sum_n t_{x,y}[n] * (-sin(theta[n,h,j])) * sum_b (gcos_q + gcos_k)[b,n,h,j]
+ * where gcos is the [2][B, H*W, heads, 32] workspace lnx_attn_bwd filled (autograd of
+ * compute_mixed_cis / apply_rotary_emb through the real part only, finding F1) */
+int lnx_rope_freqs_bwd(const float* freqs, const float* gcos, int B, int heads, int H, int W, float* dfreqs, void* stream);
+
+typedef struct lnx_attn_args {
+    int dtype;
+    int B, N, E, heads;
+    const void* qkv;     /* [B*N, 3*heads*64] */
+    const float* cos_tab;/* [(N-E), heads, 32] */
+    void* o;             /* [B*N, heads*64] */
+    float* lse;          /* [B, heads, N] log-sum-exp of the scaled scores */
+} lnx_attn_args;
+int lnx_attn_fwd(const lnx_attn_args* args, void* stream);
+
+typedef struct lnx_attn_bwd_args {
+    int dtype;
+    int B, N, E, heads;
+    const void* qkv;
+    const float* cos_tab;
+    const void* o;
+    const float* lse;
+    const void* d_o;     /* [B*N, heads*64] */
+    void* dqkv;          /* [B*N, 3*heads*64] */
+    float* gcos;         /* workspace [2][B, N-E, heads, 32]: per-sample cos gradients of q and k (overwritten) */
+    float* delta;        /* workspace [B, heads, N] */
+} lnx_attn_bwd_args;
+int lnx_attn_bwd(const lnx_attn_bwd_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small data-movement / elementwise kernels of the path
+ * -----------------------------------------------------------------------------------*/
+/* stem im2col: x fp32 NCHW [B,Cin,H,W] -> patches [B*(H/4)*(W/4), ldp] of T with column
+ * k = c*16 + kh*4 + kw (torch conv weight order), zero padded to ldp (mFormerV1.py:146) */
+int lnx_im2col_stem(const float* x, int B, int Cin, int H, int W, void* patches, int dtype, int ldp, void* stream);
+
+/* out[m, :] = rowscale[m / rows_per_sample] * in[map(m), :]   (fp32 in, T or fp32 out) */
+int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float* rowscale, int rows_per_sample, void* out,
+                   int out_dtype, int64_t ldout, int M, int C, void* stream);
+
+/* LayerScale+DropPath backward of a ConvNeXt block branch (blocks/convnext.py:82-86):
+ * dz = rowscale * gamma * g  (T),  dgamma[c] += sum_m rowscale * g * z */
+int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* gamma, const float* rowscale,
+                       int rows_per_sample, void* dz, float* dgamma, int M, int C, void* stream);
+
+/* out[map(m), :] = vec[:]  for m in [0, M)   (CLS token expand, mFormerV1.py:448,487) */
+int lnx_fill_rows(const float* vec, float* out, int64_t ldout, lnx_rowmap map, int M, int C, void* stream);
+/* out[c] += sum_m in[map(m), c]   (fp32 atomics) */
+int lnx_colsum_rows(const float* in, int64_t ldin, lnx_rowmap map, float* out, int M, int C, void* stream);
+
+/* aggregate = Conv1d(2,1,1) over [cls_1, cls_2] (mFormerV1.py:322,515-523):
+ * out = w[0]*a + w[1]*b + bias[0] */
+int lnx_agg2_fwd(const float* a, const float* b, const float* w2, const float* bias1, float* out, int M, int C, void* stream);
+/* da = w0*dout, db = w1*dout, dw[0] += <dout,a>, dw[1] += <dout,b>, dbias += sum(dout) */
+int lnx_agg2_bwd(const float* dout, const float* a, const float* b, const float* w2, float* da, float* db_, float* dw2,
+                 float* dbias1, int M, int C, void* stream);
+
+/* meta [B, width] fp32 -> T [B, 16] holding columns [off, off+dim) zero padded */
+int lnx_pack_meta(const float* meta, int width, int off, int dim, void* out, int dtype, int B, void* stream);
+
+/* Per-step parameter preparation: cast fp32 master parameters into the T-typed operand
+ * arena the GEMMs read (plus transposed copies for the data-gradient GEMMs and the
+ * tap-major depthwise weights).  `descs` is a DEVICE array built by the caller. */
+enum { LNX_PREP_CAST = 0, LNX_PREP_CONV_PERM = 1, LNX_PREP_DW49 = 2 };
+typedef struct lnx_prep_desc {
+    const float* src;
+    void* dst;        /* [rows, ld] of T (DW49: fp32 [49][C]) */
+    void* dst_t;      /* optional transposed copy [cols_out, ld_t] of T, or NULL */
+    int rows, cols;   /* source logical shape [rows, cols]; CONV_PERM: cols = C*P */
+    int ld, ld_t;
+    int P;            /* CONV_PERM: kernel positions per channel (4 for 2x2) */
+    int mode;
+    int block_start;  /* first workgroup index of this tensor (exclusive prefix sums) */
+} lnx_prep_desc;
+int lnx_prep_weights(const lnx_prep_desc* descs_dev, int ndesc, int total_blocks, int dtype, void* stream);
+/* number of workgroups lnx_prep_weights needs for one tensor */
+int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t);
 
 #ifdef __cplusplus
 }

@@ -84,4 +84,74 @@ def check(rc: int, what: str) -> None:
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus",
     "lnx_gemm_nt", "lnx_gemm_tn",
+    "lnx_layernorm_fwd", "lnx_layernorm_bwd",
+    "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
+    "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
+    "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks",
 ]
+
+
+class LnArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("C", C.c_int), ("eps", C.c_float),
+        ("x", C.c_void_p), ("x_dtype", C.c_int), ("ldx", C.c_int64), ("x_map", RowMap),
+        ("w", C.c_void_p), ("b", C.c_void_p),
+        ("y", C.c_void_p), ("y_dtype", C.c_int), ("ldy", C.c_int64), ("y_map", RowMap),
+        ("add", C.c_void_p), ("ldadd", C.c_int64),
+        ("mean", C.c_void_p), ("rstd", C.c_void_p),
+    ]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("C", C.c_int),
+        ("dy", C.c_void_p), ("dy_dtype", C.c_int), ("lddy", C.c_int64), ("dy_map", RowMap),
+        ("x", C.c_void_p), ("x_dtype", C.c_int), ("ldx", C.c_int64), ("x_map", RowMap),
+        ("w", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("gin", C.c_void_p), ("ldgin", C.c_int64),
+        ("dx", C.c_void_p), ("dx_dtype", C.c_int), ("lddx", C.c_int64),
+        ("dw", C.c_void_p), ("db", C.c_void_p), ("relu_mask", C.c_int),
+    ]
+
+
+class DwconvArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+        ("x", C.c_void_p), ("x_dtype", C.c_int), ("w49", C.c_void_p), ("bias", C.c_void_p),
+        ("flip", C.c_int), ("res", C.c_void_p), ("y", C.c_void_p), ("y_dtype", C.c_int),
+    ]
+
+
+class DwconvWgradArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int),
+        ("x", C.c_void_p), ("x_dtype", C.c_int), ("dy", C.c_void_p), ("dy_dtype", C.c_int),
+        ("dw", C.c_void_p), ("db", C.c_void_p),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("E", C.c_int), ("heads", C.c_int),
+        ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("E", C.c_int), ("heads", C.c_int),
+        ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+        ("d_o", C.c_void_p), ("dqkv", C.c_void_p), ("gcos", C.c_void_p), ("delta", C.c_void_p),
+    ]
+
+
+class PrepDesc(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p), ("dst_t", C.c_void_p),
+        ("rows", C.c_int), ("cols", C.c_int), ("ld", C.c_int), ("ld_t", C.c_int),
+        ("P", C.c_int), ("mode", C.c_int), ("block_start", C.c_int),
+    ]
+
+
+PREP_CAST, PREP_CONV_PERM, PREP_DW49 = 0, 1, 2

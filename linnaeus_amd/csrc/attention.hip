@@ -1,0 +1,568 @@
+// Global multi-head attention with the reference's cos-only "2D RoPE" for gfx950.
+//
+// Reference: RoPE2DAttention.forward, standard path (blocks/rope_2d_mhsa.py:422-505):
+//   q,k image tokens scaled pairwise by cos(theta) (:176-218, finding F1), q *= d^-0.5
+//   (:456), S = q k^T in fp32 (:495), softmax (:496), O = P v (:498), O laid out [B,N,h*d].
+// head_dim is 64 in every shipped config.  N is small (52..580), so the whole problem of a
+// (batch, head) pair is a few 64-key tiles; parallelism comes from batch x heads x q-tiles.
+//
+// Layout trick used everywhere below: score tiles are computed TRANSPOSED (keys in the
+// accumulator registers, the query -- or in the dK/dV kernel the key -- on the lane), so
+// every per-row softmax quantity is lane-local and the probability tile is already the
+// B operand of the next MFMA ("accumulator as operand"); the other operand of that second
+// product comes from LDS through ds_read_b64_tr_b16 (bf16) or plain b32 reads (fp32).
+//
+// Kernels:  attn_fwd  -> o, lse
+//           attn_bwd_dq   (per 64 queries: delta, dq, cos-gradient part of q)
+//           attn_bwd_dkv  (per 64 keys:    dk, dv, cos-gradient part of k)
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+constexpr int HD = 64;   // head dim
+constexpr int BT = 64;   // rows per tile (queries or keys)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <typename T> struct AT {
+    static constexpr int EPV = TT<T>::EPV;
+    static constexpr int NKK = sizeof(T);               // 64-byte k-chunks per head row (2 bf16 / 4 fp32)
+    static constexpr int ROWB = HD * sizeof(T);         // bytes per row in the row image
+    static constexpr int NCH = ROWB / 16;               // 16-byte chunks per row
+    static constexpr int TRB = sizeof(T) == 2 ? 160 : 272;  // padded row bytes of the transposed-read image
+    static constexpr int ROW_IMG = BT * ROWB;
+    static constexpr int TR_IMG = BT * TRB;
+};
+
+__device__ __forceinline__ void mfma_bf16(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma_f32(f32x4_t& acc, float a, float b) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); }
+
+template <typename T> __device__ __forceinline__ void mfma_chunk(f32x4_t& acc, const uint4& a, const uint4& b) {
+    if constexpr (sizeof(T) == 2) {
+        mfma_bf16(acc, a, b);
+    } else {
+        const float* fa = reinterpret_cast<const float*>(&a);
+        const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_f32(acc, fa[j], fb[j]);
+    }
+}
+
+__device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
+// Load one 16-byte chunk (EPV consecutive head channels starting at d0) of token n for the
+// given operand column base; optionally multiply pairwise by cos and by `scale`.
+template <typename T, bool COS>
+__device__ __forceinline__ uint4 load_chunk(const T* __restrict__ base, int64_t ld, int n, int N, int E, int d0, const float* __restrict__ cos_tab,
+                                            int heads, int head, float scale) {
+    if (n >= N) return make_uint4(0, 0, 0, 0);
+    Vec16<T> v;
+    v.raw = ld16(base + (int64_t)n * ld + d0);
+    if constexpr (COS) {
+        constexpr int EPV = TT<T>::EPV;
+        if (n >= E) {
+            const float* cp = cos_tab + ((int64_t)(n - E) * heads + head) * 32 + (d0 >> 1);
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * cp[j >> 1] * scale);
+        } else if (scale != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * scale);
+        }
+    }
+    return v.raw;
+}
+
+// Stage a 64-row tile (tokens n0..n0+63) into LDS: swizzled row image (16-byte fragment
+// reads, rows = MFMA rows) and/or padded image for transposed reads.
+template <typename T, bool COS, bool ROWIMG, bool TRIMG>
+__device__ __forceinline__ void stage_tile(unsigned char* rowimg, unsigned char* trimg, const T* __restrict__ base, int64_t ld, int n0, int N, int E,
+                                           const float* __restrict__ cos_tab, int heads, int head, float scale) {
+    constexpr int NCH = AT<T>::NCH;
+    constexpr int EPV = AT<T>::EPV;
+    for (int i = threadIdx.x; i < BT * NCH; i += 256) {
+        const int r = i / NCH, c = i % NCH;
+        const uint4 v = load_chunk<T, COS>(base, ld, n0 + r, N, E, c * EPV, cos_tab, heads, head, scale);
+        if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
+        if constexpr (TRIMG) st16(trimg + r * AT<T>::TRB + c * 16, v);
+    }
+}
+
+// fragment of a row operand held in registers: lane (s, g) <- token row, chunks kk*4 + g
+template <typename T, bool COS>
+__device__ __forceinline__ void load_row_frag(uint4 (&f)[AT<T>::NKK], const T* __restrict__ base, int64_t ld, int n, int N, int E, int g,
+                                              const float* __restrict__ cos_tab, int heads, int head, float scale) {
+#pragma unroll
+    for (int kk = 0; kk < AT<T>::NKK; ++kk) f[kk] = load_chunk<T, COS>(base, ld, n, N, E, (kk * 4 + g) * AT<T>::EPV, cos_tab, heads, head, scale);
+}
+
+// acc[t] (t = 0..3, 16 rows each) = Rows(img, row0 + 16 t + s) . frag^T over the 64 channels
+template <typename T>
+__device__ __forceinline__ void rows_times_frag(f32x4_t (&acc)[4], const unsigned char* rowimg, int s, int g, const uint4 (&frag)[AT<T>::NKK]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int row = t * 16 + s;
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            const uint4 a = ld16(rowimg + row * AT<T>::ROWB + (((kk * 4 + g) ^ (row & 7)) << 4));
+            mfma_chunk<T>(acc[t], a, frag[kk]);
+        }
+    }
+}
+
+// out[dt] += Img^T . P   where P[t][r] holds, for the lane's column, the value of tile row
+// 16 t + 4 g + r (t = 0..3) -- i.e. contraction over the 64 tile rows.
+template <typename T>
+__device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigned char* trimg, int s, int g, const float (&p)[4][4]) {
+    if constexpr (sizeof(T) == 2) {
+        uint4 pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Vec16<bf16_t> v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.set(j, p[2 * ks + (j >> 2)][j & 3]);
+            pf[ks] = v.raw;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = ks * 32 + 4 * g + (s >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = (dt * 16 + 4 * (s & 3)) * 2;
+                const uint2 a0 = tr_read(trimg + r0 * AT<T>::TRB + col);
+                const uint2 a1 = tr_read(trimg + (r0 + 16) * AT<T>::TRB + col);
+                mfma_bf16(out[dt], make_uint4(a0.x, a0.y, a1.x, a1.y), pf[ks]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + 4 * g + r;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float a = *reinterpret_cast<const float*>(trimg + row * AT<T>::TRB + (dt * 16 + s) * 4);
+                    mfma_f32(out[dt], a, p[t][r]);
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ float group_max(float v) {  // over the 4 lanes s, s+16, s+32, s+48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttnP {
+    const void* qkv;
+    const float* cos_tab;
+    void* o;
+    float* lse;
+    const void* d_o;
+    void* dqkv;
+    float* gcos;   // [2][B, N-E, heads, 32]
+    float* delta;
+    int B, N, E, heads;
+    int qtiles;
+};
+
+// ---------------------------------------------------------------------------------
+// forward: one workgroup = 64 queries of one (b, head); wave = 16 queries (lane s)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* kimg = smem;                       // K~ row image
+    unsigned char* vimg = smem + AT<T>::ROW_IMG;      // V transposed-read image
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int qt = blockIdx.x % p.qtiles;
+    const int bh = blockIdx.x / p.qtiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const float scale = 0.125f;  // 64^-0.5
+
+    const int q = qt * BT + wave * 16 + s;
+    uint4 qf[AT<T>::NKK];
+    load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
+
+    f32x4_t oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = (p.N + BT - 1) / BT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile<T, true, true, false>(kimg, nullptr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+        stage_tile<T, false, false, true>(nullptr, vimg, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        __syncthreads();
+        f32x4_t sacc[4];
+        rows_times_frag<T>(sacc, kimg, s, g, qf);  // S^T[key = 16t + 4g + r][query = s]
+        float pv[4][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * BT + t * 16 + 4 * g + r;
+                const float v = key < p.N ? sacc[t][r] : -INFINITY;
+                pv[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = group_max(mx);
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(pv[t][r] - m_new);
+                pv[t][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+        imgT_times_regs<T>(oacc, vimg, s, g, pv);  // O^T[d = 16dt + 4g + r][query = s]
+    }
+    const float l_tot = group_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    if (q < p.N) {
+        T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) op[dt * 16 + 4 * g + r] = from_f<T>(oacc[dt][r] * inv);
+        if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward, query side: delta, dq (and the q part of the cos gradient)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* kimg = smem;                                        // K~ rows
+    unsigned char* vimg = smem + AT<T>::ROW_IMG;                       // V rows
+    unsigned char* ktr = smem + 2 * AT<T>::ROW_IMG;                    // K~ transposed-read image
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int qt = blockIdx.x % p.qtiles;
+    const int bh = blockIdx.x / p.qtiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
+    const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
+    const float scale = 0.125f;
+
+    const int q = qt * BT + wave * 16 + s;
+    uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
+    load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
+    load_row_frag<T, false>(dof, dob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+    // delta = sum_d dO * O  (each lane holds 1/4 of the row)
+    float dl = 0.f;
+    {
+        uint4 of[AT<T>::NKK];
+        load_row_frag<T, false>(of, ob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            Vec16<T> a, bb;
+            a.raw = dof[kk];
+            bb.raw = of[kk];
+#pragma unroll
+            for (int j = 0; j < AT<T>::EPV; ++j) dl += a.get(j) * bb.get(j);
+        }
+    }
+    const float delta = group_sum(dl);
+    const float lse = q < p.N ? p.lse[((int64_t)b * p.heads + head) * p.N + q] : 0.f;
+    if (q < p.N && g == 0) p.delta[((int64_t)b * p.heads + head) * p.N + q] = delta;
+
+    f32x4_t dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (p.N + BT - 1) / BT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        stage_tile<T, true, true, true>(kimg, ktr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+        stage_tile<T, false, true, false>(vimg, nullptr, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        __syncthreads();
+        f32x4_t sacc[4], dpacc[4];
+        rows_times_frag<T>(sacc, kimg, s, g, qf);    // S^T[key][q]
+        rows_times_frag<T>(dpacc, vimg, s, g, dof);  // dP^T[key][q] = V[key] . dO[q]
+        float ds[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * BT + t * 16 + 4 * g + r;
+                const float pr = (key < p.N && q < p.N) ? expf(sacc[t][r] - lse) : 0.f;
+                ds[t][r] = pr * (dpacc[t][r] - delta);
+            }
+        imgT_times_regs<T>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
+    }
+    if (q < p.N) {
+        // dq = dQ~ * cos * scale ; gcos_q[b, n, head, j] = scale * (dQ~[2j] q[2j] + dQ~[2j+1] q[2j+1])
+        T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
+        const T* qraw = qb + (int64_t)q * ld;
+        const bool img = q >= p.E;
+        const float* cp = img ? p.cos_tab + ((int64_t)(q - p.E) * p.heads + head) * 32 : nullptr;
+        float* gq = img ? p.gcos + (((int64_t)b * (p.N - p.E) + (q - p.E)) * p.heads + head) * 32 : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = dt * 16 + 4 * g;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int d = d0 + 2 * pr;
+                const float c = img ? cp[d >> 1] : 1.0f;
+                const float g0 = dq[dt][2 * pr], g1 = dq[dt][2 * pr + 1];
+                dqp[d] = from_f<T>(g0 * c * scale);
+                dqp[d + 1] = from_f<T>(g1 * c * scale);
+                if (img) gq[d >> 1] = scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward, key side: dk, dv (and the k part of the cos gradient)
+// wave = 16 keys (lane s); loops over 64-query tiles
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* qimg = smem;                                   // Q~ rows
+    unsigned char* doimg = smem + AT<T>::ROW_IMG;                 // dO rows
+    unsigned char* qtr = smem + 2 * AT<T>::ROW_IMG;               // Q~ transposed-read image
+    unsigned char* dotr = qtr + AT<T>::TR_IMG;                    // dO transposed-read image
+    float* lse_s = reinterpret_cast<float*>(dotr + AT<T>::TR_IMG);
+    float* del_s = lse_s + BT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int ktile = blockIdx.x % p.qtiles;  // same tiling for keys
+    const int bh = blockIdx.x / p.qtiles;
+    const int head = bh % p.heads, b = bh / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
+    const float scale = 0.125f;
+    const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
+
+    const int key = ktile * BT + wave * 16 + s;
+    uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
+    load_row_frag<T, true>(kf, kb, ld, key, p.N, p.E, g, p.cos_tab, p.heads, head, 1.0f);
+    load_row_frag<T, false>(vf, vb, ld, key, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dk[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nqt = (p.N + BT - 1) / BT;
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        stage_tile<T, true, true, true>(qimg, qtr, qb, ld, qt * BT, p.N, p.E, p.cos_tab, p.heads, head, scale);
+        stage_tile<T, false, true, true>(doimg, dotr, dob, C, qt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        if (threadIdx.x < BT) {
+            const int qq = qt * BT + threadIdx.x;
+            lse_s[threadIdx.x] = qq < p.N ? p.lse[statbase + qq] : 0.f;
+            del_s[threadIdx.x] = qq < p.N ? p.delta[statbase + qq] : 0.f;
+        }
+        __syncthreads();
+        f32x4_t sacc[4], dpacc[4];
+        rows_times_frag<T>(sacc, qimg, s, g, kf);     // S[q = 16t + 4g + r][key = s]
+        rows_times_frag<T>(dpacc, doimg, s, g, vf);   // dP[q][key]
+        float pr[4][4], ds[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = t * 16 + 4 * g + r;
+                const int qq = qt * BT + ql;
+                const float pp = (qq < p.N && key < p.N) ? expf(sacc[t][r] - lse_s[ql]) : 0.f;
+                pr[t][r] = pp;
+                ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
+            }
+        imgT_times_regs<T>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
+        imgT_times_regs<T>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
+    }
+    if (key < p.N) {
+        T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
+        T* dvp = dkp + C;
+        const T* kraw = kb + (int64_t)key * ld;
+        const bool img = key >= p.E;
+        const float* cp = img ? p.cos_tab + ((int64_t)(key - p.E) * p.heads + head) * 32 : nullptr;
+        float* gk = img ? p.gcos + (int64_t)p.B * (p.N - p.E) * p.heads * 32 + (((int64_t)b * (p.N - p.E) + (key - p.E)) * p.heads + head) * 32 : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = dt * 16 + 4 * g;
+#pragma unroll
+            for (int pq = 0; pq < 2; ++pq) {
+                const int d = d0 + 2 * pq;
+                const float c = img ? cp[d >> 1] : 1.0f;
+                const float g0 = dk[dt][2 * pq], g1 = dk[dt][2 * pq + 1];
+                dkp[d] = from_f<T>(g0 * c);
+                dkp[d + 1] = from_f<T>(g1 * c);
+                dvp[d] = from_f<T>(dv[dt][2 * pq]);
+                dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
+                if (img) gk[d >> 1] = g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// cos table and its backward to the learnable freqs
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out) {
+    const int total = H * W * heads * 32;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = i & 31;
+    const int h = (i >> 5) % heads;
+    const int n = (i >> 5) / heads;
+    const float tx = (float)(n % W), ty = (float)(n / W);
+    // theta = t_x * f_x + t_y * f_y in fp32, two rounded products then a rounded sum (einsum + add,
+    // rope_2d_mhsa.py:136-142) -- keep them un-fused so the angle matches the reference bit for bit
+    const float ax = __fmul_rn(tx, freqs[h * 32 + j]);
+    const float ay = __fmul_rn(ty, freqs[(heads + h) * 32 + j]);
+    out[i] = cosf(__fadd_rn(ax, ay));
+}
+
+// dfreqs[a,h,j] += sum_n t_a[n] * (-sin theta) * sum_b (gq + gk)[b,n,h,j]
+// one workgroup per (n, head): 32 columns x 8 batch slices
+__global__ __launch_bounds__(256) void rope_freqs_bwd_kernel(const float* __restrict__ freqs, const float* __restrict__ gcos, int B, int heads, int H, int W,
+                                                             float* __restrict__ dfreqs) {
+    __shared__ float red[8][32];
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int NI = H * W;
+    const int64_t half = (int64_t)B * NI * heads * 32;
+    float acc = 0.f;
+    for (int b = sl; b < B; b += 8) {
+        const int64_t off = (((int64_t)b * NI + n) * heads + h) * 32 + j;
+        acc += gcos[off] + gcos[half + off];
+    }
+    red[sl][j] = acc;
+    __syncthreads();
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][j];
+        const float tx = (float)(n % W), ty = (float)(n / W);
+        const float th = __fadd_rn(__fmul_rn(tx, freqs[h * 32 + j]), __fmul_rn(ty, freqs[(heads + h) * 32 + j]));
+        const float dth = -sinf(th) * t;
+        atomicAdd(dfreqs + h * 32 + j, tx * dth);
+        atomicAdd(dfreqs + (heads + h) * 32 + j, ty * dth);
+    }
+}
+
+template <typename K> void set_lds(K kernel, size_t bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int check_attn(int dtype, int B, int N, int E, int heads, const char* who) {
+    LNX_CHECK(dtype == LNX_F32 || dtype == LNX_BF16, "%s: bad dtype %d", who, dtype);
+    LNX_CHECK(B > 0 && N > 0 && heads > 0 && E >= 0 && E <= N, "%s: bad shape B=%d N=%d E=%d heads=%d", who, B, N, E, heads);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lnx_rope_cos_table(const float* freqs, int heads, int H, int W, float* cos_out, void* stream) {
+    LNX_CHECK(freqs && cos_out && heads > 0 && H > 0 && W > 0, "lnx_rope_cos_table: bad arguments");
+    const int total = H * W * heads * 32;
+    hipLaunchKernelGGL(rope_cos_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, freqs, heads, H, W, cos_out);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_rope_freqs_bwd(const float* freqs, const float* gcos, int B, int heads, int H, int W, float* dfreqs, void* stream) {
+    LNX_CHECK(freqs && gcos && dfreqs && B > 0 && heads > 0 && H > 0 && W > 0, "lnx_rope_freqs_bwd: bad arguments");
+    hipLaunchKernelGGL(rope_freqs_bwd_kernel, dim3(H * W * heads), dim3(256), 0, (hipStream_t)stream, freqs, gcos, B, heads, H, W, dfreqs);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
+    LNX_CHECK(a && a->qkv && a->o, "lnx_attn_fwd: null operand");
+    if (check_attn(a->dtype, a->B, a->N, a->E, a->heads, "lnx_attn_fwd")) return 1;
+    LNX_CHECK(a->E == a->N || a->cos_tab, "lnx_attn_fwd: cos table missing");
+    AttnP p{};
+    p.qkv = a->qkv; p.cos_tab = a->cos_tab; p.o = a->o; p.lse = a->lse;
+    p.B = a->B; p.N = a->N; p.E = a->E; p.heads = a->heads;
+    p.qtiles = cdiv(a->N, BT);
+    const int grid = a->B * a->heads * p.qtiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == LNX_BF16) {
+        const size_t lds = AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG;
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, p);
+    } else {
+        const size_t lds = AT<float>::ROW_IMG + AT<float>::TR_IMG;
+        hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(grid), dim3(256), lds, st, p);
+    }
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
+    LNX_CHECK(a && a->qkv && a->o && a->lse && a->d_o && a->dqkv && a->delta, "lnx_attn_bwd: null operand");
+    if (check_attn(a->dtype, a->B, a->N, a->E, a->heads, "lnx_attn_bwd")) return 1;
+    LNX_CHECK(a->E == a->N || (a->cos_tab && a->gcos), "lnx_attn_bwd: cos table / gcos workspace missing");
+    AttnP p{};
+    p.qkv = a->qkv; p.cos_tab = a->cos_tab; p.o = const_cast<void*>(a->o); p.lse = const_cast<float*>(a->lse);
+    p.d_o = a->d_o; p.dqkv = a->dqkv; p.gcos = a->gcos; p.delta = a->delta;
+    p.B = a->B; p.N = a->N; p.E = a->E; p.heads = a->heads;
+    p.qtiles = cdiv(a->N, BT);
+    const int grid = a->B * a->heads * p.qtiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->dtype == LNX_BF16) {
+        typedef bf16_t T;
+        const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
+        const size_t lds_k = 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+    } else {
+        typedef float T;
+        const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
+        const size_t lds_k = 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float);
+        static bool once = false;
+        if (!once) {
+            set_lds(attn_bwd_dkv_kernel<T>, lds_k);
+            once = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+    }
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,344 @@
+// Small HBM-bound data-movement kernels of the mFormerV1 path (gfx950).
+// All are grid-stride, 16-byte vectorised where the layout allows, fp32 math.
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+inline int ew_grid(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------
+// stem im2col: NCHW fp32 image -> [B*Ho*Wo, ldp] patches, k = c*16 + kh*4 + kw
+// one thread per (patch row, channel, kh): reads 4 contiguous floats, writes 4 T
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int Cin, int H, int W, int ldp) {
+    const int Ho = H >> 2, Wo = W >> 2;
+    const int units_per_row = ldp >> 2;  // groups of 4 columns (incl. zero padding)
+    const int64_t total = (int64_t)B * Ho * Wo * units_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % units_per_row);
+        const int64_t row = i / units_per_row;
+        const int wo = (int)(row % Wo);
+        const int64_t t = row / Wo;
+        const int ho = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < Cin * 4) {
+            const int c = u >> 2, kh = u & 3;
+            v = *reinterpret_cast<const float4*>(x + (((int64_t)b * Cin + c) * H + 4 * ho + kh) * W + 4 * wo);
+        }
+        T* o = out + row * ldp + 4 * u;
+        o[0] = from_f<T>(v.x);
+        o[1] = from_f<T>(v.y);
+        o[2] = from_f<T>(v.z);
+        o[3] = from_f<T>(v.w);
+    }
+}
+
+// out[m, c] = rowscale[m / rps] * in[map(m), c]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ in, int64_t ldin, RowMap map, const float* __restrict__ rowscale,
+                                                         int rps, T* __restrict__ out, int64_t ldout, int M, int C) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)M * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / c4n);
+        const int c = (int)(i % c4n) * 4;
+        const float s = rowscale ? rowscale[m / rps] : 1.f;
+        const float4 v = *reinterpret_cast<const float4*>(in + map_row(map, m) * ldin + c);
+        T* o = out + (int64_t)m * ldout + c;
+        o[0] = from_f<T>(v.x * s);
+        o[1] = from_f<T>(v.y * s);
+        o[2] = from_f<T>(v.z * s);
+        o[3] = from_f<T>(v.w * s);
+    }
+}
+
+// dz = s * gamma * g ; dgamma += sum_m s * g * z.  Block = 256 threads as (rows x C/4
+// column groups); per-thread column partials are reduced through LDS, one atomic per column.
+template <typename T>
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ g, const T* __restrict__ z, const float* __restrict__ gamma,
+                                                             const float* __restrict__ rowscale, int rps, T* __restrict__ dz,
+                                                             float* __restrict__ dgamma, int M, int C) {
+    extern __shared__ float red[];  // [rows_per_block][C]
+    const int c4n = C >> 2;
+    const int rows_pb = 256 / c4n > 0 ? 256 / c4n : 1;
+    const int tr = threadIdx.x / c4n, tc = threadIdx.x % c4n;
+    const bool active = tr < rows_pb;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gm = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) gm = *reinterpret_cast<const float4*>(gamma + 4 * tc);
+    if (active) {
+        for (int m = blockIdx.x * rows_pb + tr; m < M; m += gridDim.x * rows_pb) {
+            const float s = rowscale ? rowscale[m / rps] : 1.f;
+            const float4 gv = *reinterpret_cast<const float4*>(g + (int64_t)m * C + 4 * tc);
+            const T* zp = z + (int64_t)m * C + 4 * tc;
+            const float z0 = to_f(zp[0]), z1 = to_f(zp[1]), z2 = to_f(zp[2]), z3 = to_f(zp[3]);
+            T* o = dz + (int64_t)m * C + 4 * tc;
+            o[0] = from_f<T>(s * gm.x * gv.x);
+            o[1] = from_f<T>(s * gm.y * gv.y);
+            o[2] = from_f<T>(s * gm.z * gv.z);
+            o[3] = from_f<T>(s * gm.w * gv.w);
+            acc.x += s * gv.x * z0;
+            acc.y += s * gv.y * z1;
+            acc.z += s * gv.z * z2;
+            acc.w += s * gv.w * z3;
+        }
+        *reinterpret_cast<float4*>(red + tr * C + 4 * tc) = acc;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int r = 0; r < rows_pb; ++r) t += red[r * C + c];
+        atomicAdd(dgamma + c, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_rows_kernel(const float* __restrict__ vec, float* __restrict__ out, int64_t ldout, RowMap map, int M, int C) {
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)M * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / c4n);
+        const int c = (int)(i % c4n) * 4;
+        *reinterpret_cast<float4*>(out + map_row(map, m) * ldout + c) = *reinterpret_cast<const float4*>(vec + c);
+    }
+}
+
+// out[c] += sum_m in[map(m), c]; block handles a strip of rows, threads over columns
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ in, int64_t ldin, RowMap map, float* __restrict__ out, int M, int C,
+                                                          int rows_per_block) {
+    const int m0 = blockIdx.x * rows_per_block;
+    const int m1 = min(M, m0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int m = m0; m < m1; ++m) t += in[map_row(map, m) * ldin + c];
+        atomicAdd(out + c, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void agg2_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ w2,
+                                                       const float* __restrict__ bias1, float* __restrict__ out, int64_t total) {
+    const float w0 = w2[0], w1 = w2[1], bb = bias1[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) out[i] = w0 * a[i] + w1 * b[i] + bb;
+}
+
+__global__ __launch_bounds__(256) void agg2_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ w2, float* __restrict__ da, float* __restrict__ db_, float* __restrict__ dw2,
+                                                       float* __restrict__ dbias1, int64_t total) {
+    __shared__ float red[3][4];
+    const float w0 = w2[0], w1 = w2[1];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = dout[i];
+        da[i] = w0 * d;
+        db_[i] = w1 * d;
+        s0 += d * a[i];
+        s1 += d * b[i];
+        s2 += d;
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+        red[2][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dw2 + 0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(dw2 + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        atomicAdd(dbias1, red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_meta_kernel(const float* __restrict__ meta, int width, int off, int dim, T* __restrict__ out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 16) return;
+    const int b = i >> 4, j = i & 15;
+    out[i] = from_f<T>(j < dim ? meta[(int64_t)b * width + off + j] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------
+// per-step parameter preparation (descriptor table on the device)
+// ---------------------------------------------------------------------------------
+constexpr int PREP_ELEMS = 2048;  // destination elements per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_kernel(const lnx_prep_desc* __restrict__ descs, int ndesc) {
+    // binary search: last descriptor with block_start <= blockIdx.x
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const lnx_prep_desc d = descs[lo];
+    const int lb = blockIdx.x - d.block_start;
+    const int64_t n_main = (int64_t)d.rows * d.ld;
+    const int64_t base = (int64_t)lb * PREP_ELEMS;
+    if (d.mode == LNX_PREP_DW49) {
+        // src [C, 49] -> dst fp32 [49][C];  rows = C, cols = 49, ld = C
+        float* dst = reinterpret_cast<float*>(d.dst);
+        const int64_t n = (int64_t)49 * d.rows;
+        for (int64_t i = base + threadIdx.x; i < base + PREP_ELEMS && i < n; i += 256) {
+            const int tap = (int)(i / d.rows), c = (int)(i % d.rows);
+            dst[i] = d.src[(int64_t)c * 49 + tap];
+        }
+        return;
+    }
+    const int cols_out = d.cols;  // logical K of the operand
+    for (int64_t i = base + threadIdx.x; i < base + PREP_ELEMS; i += 256) {
+        if (i < n_main) {
+            const int r = (int)(i / d.ld), k = (int)(i % d.ld);
+            float v = 0.f;
+            if (k < cols_out) {
+                int sk = k;
+                if (d.mode == LNX_PREP_CONV_PERM) {  // k = p*C + c  <-  src column c*P + p
+                    const int Cc = d.cols / d.P;
+                    const int pp = k / Cc;
+                    sk = (k - pp * Cc) * d.P + pp;
+                }
+                v = d.src[(int64_t)r * d.cols + sk];
+            }
+            reinterpret_cast<T*>(d.dst)[i] = from_f<T>(v);
+        } else if (d.dst_t != nullptr) {
+            const int64_t j = i - n_main;
+            if (j < (int64_t)cols_out * d.ld_t) {
+                const int k = (int)(j / d.ld_t), r = (int)(j % d.ld_t);
+                float v = 0.f;
+                if (r < d.rows) {
+                    int sk = k;
+                    if (d.mode == LNX_PREP_CONV_PERM) {
+                        const int Cc = d.cols / d.P;
+                        const int pp = k / Cc;
+                        sk = (k - pp * Cc) * d.P + pp;
+                    }
+                    v = d.src[(int64_t)r * d.cols + sk];
+                }
+                reinterpret_cast<T*>(d.dst_t)[j] = from_f<T>(v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                         \
+    do {                                               \
+        if ((dtype) == LNX_BF16) {                     \
+            typedef bf16_t T;                          \
+            __VA_ARGS__;                               \
+        } else if ((dtype) == LNX_F32) {               \
+            typedef float T;                           \
+            __VA_ARGS__;                               \
+        } else {                                       \
+            LNX_CHECK(false, "bad dtype %d", (dtype)); \
+        }                                              \
+    } while (0)
+
+extern "C" int lnx_im2col_stem(const float* x, int B, int Cin, int H, int W, void* patches, int dtype, int ldp, void* stream) {
+    LNX_CHECK(x && patches, "lnx_im2col_stem: null operand");
+    LNX_CHECK(H % 4 == 0 && W % 4 == 0 && ldp % 4 == 0 && ldp >= Cin * 16, "lnx_im2col_stem: bad geometry H=%d W=%d ldp=%d", H, W, ldp);
+    const int64_t total = (int64_t)B * (H / 4) * (W / 4) * (ldp / 4);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((im2col_stem_kernel<T>), dim3(ew_grid(total, 256)), dim3(256), 0, st, x, (T*)patches, B, Cin, H, W, ldp));
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float* rowscale, int rows_per_sample, void* out,
+                              int out_dtype, int64_t ldout, int M, int C, void* stream) {
+    LNX_CHECK(in && out && M > 0 && C > 0 && C % 4 == 0 && ldin % 4 == 0, "lnx_scale_cast: bad arguments M=%d C=%d", M, C);
+    if (rowscale) LNX_CHECK(rows_per_sample > 0, "lnx_scale_cast: rowscale needs rows_per_sample");
+    const RowMap map{in_map.group, in_map.pad, in_map.off};
+    hipStream_t st = (hipStream_t)stream;
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    DISPATCH_T(out_dtype, hipLaunchKernelGGL((scale_cast_kernel<T>), dim3(ew_grid((int64_t)M * (C / 4), 256)), dim3(256), 0, st, in, ldin, map, rowscale,
+                                             rps, (T*)out, ldout, M, C));
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* gamma, const float* rowscale, int rows_per_sample, void* dz,
+                                  float* dgamma, int M, int C, void* stream) {
+    LNX_CHECK(g && z && gamma && dz && dgamma, "lnx_layerscale_bwd: null operand");
+    LNX_CHECK(M > 0 && C > 0 && C % 4 == 0 && C <= 2048, "lnx_layerscale_bwd: bad shape M=%d C=%d", M, C);
+    const int c4n = C / 4;
+    const int rows_pb = 256 / c4n > 0 ? 256 / c4n : 1;
+    LNX_CHECK(c4n <= 256, "lnx_layerscale_bwd: C=%d too large", C);
+    int grid = cdiv(M, rows_pb * 8);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    const size_t lds = (size_t)rows_pb * C * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((layerscale_bwd_kernel<T>), dim3(grid), dim3(256), lds, st, g, (const T*)z, gamma, rowscale, rps, (T*)dz, dgamma, M, C));
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_fill_rows(const float* vec, float* out, int64_t ldout, lnx_rowmap map, int M, int C, void* stream) {
+    LNX_CHECK(vec && out && M > 0 && C % 4 == 0, "lnx_fill_rows: bad arguments");
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(ew_grid((int64_t)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, vec, out, ldout,
+                       RowMap{map.group, map.pad, map.off}, M, C);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_colsum_rows(const float* in, int64_t ldin, lnx_rowmap map, float* out, int M, int C, void* stream) {
+    LNX_CHECK(in && out && M > 0 && C > 0, "lnx_colsum_rows: bad arguments");
+    const int rpb = 32;
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, (hipStream_t)stream, in, ldin, RowMap{map.group, map.pad, map.off}, out, M, C, rpb);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_agg2_fwd(const float* a, const float* b, const float* w2, const float* bias1, float* out, int M, int C, void* stream) {
+    LNX_CHECK(a && b && w2 && bias1 && out, "lnx_agg2_fwd: null operand");
+    const int64_t total = (int64_t)M * C;
+    hipLaunchKernelGGL(agg2_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, a, b, w2, bias1, out, total);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_agg2_bwd(const float* dout, const float* a, const float* b, const float* w2, float* da, float* db_, float* dw2, float* dbias1, int M,
+                            int C, void* stream) {
+    LNX_CHECK(dout && a && b && w2 && da && db_ && dw2 && dbias1, "lnx_agg2_bwd: null operand");
+    const int64_t total = (int64_t)M * C;
+    int grid = ew_grid(total, 1024);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(agg2_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dout, a, b, w2, da, db_, dw2, dbias1, total);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_pack_meta(const float* meta, int width, int off, int dim, void* out, int dtype, int B, void* stream) {
+    LNX_CHECK(meta && out && dim > 0 && dim <= 16 && off >= 0 && off + dim <= width, "lnx_pack_meta: bad arguments width=%d off=%d dim=%d", width, off, dim);
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((pack_meta_kernel<T>), dim3(cdiv(B * 16, 256)), dim3(256), 0, st, meta, width, off, dim, (T*)out, B));
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t) {
+    int64_t n = (int64_t)rows * ld;
+    if (has_t) n += (int64_t)cols * ld_t;
+    return (int)((n + PREP_ELEMS - 1) / PREP_ELEMS);
+}
+
+extern "C" int lnx_prep_weights(const lnx_prep_desc* descs_dev, int ndesc, int total_blocks, int dtype, void* stream) {
+    LNX_CHECK(descs_dev && ndesc > 0 && total_blocks > 0, "lnx_prep_weights: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((prep_weights_kernel<T>), dim3(total_blocks), dim3(256), 0, st, descs_dev, ndesc));
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

@@ -323,7 +323,7 @@ struct WgradP {
     int M, N, K;
     int a_mode;
     PatchGeom pg;
-    int k_perm_c;
+    int k_perm_c, k_store;
     int tiles_n, tiles_k, splits, m_per_split;
 };
 
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WgradP p) {
 #pragma unroll
             for (int ki = 0; ki < 4; ++ki) {
                 const int k = k0 + wk * 64 + ki * 16 + s;
-                if (k >= p.K) continue;
+                if (k >= p.k_store) continue;
                 int col = k;
                 if (p.k_perm_c > 0) {
                     const int P = p.K / p.k_perm_c;
@@ -618,6 +618,7 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     p.a_mode = a->a_mode;
     p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
     p.k_perm_c = a->k_perm_c;
+    p.k_store = (a->k_store > 0 && a->k_store < a->K) ? a->k_store : a->K;
     p.tiles_n = cdiv(a->N, TILE);
     p.tiles_k = cdiv(a->K, TILE);
     const int bmc = a->dtype == LNX_BF16 ? 64 : 32;

@@ -1,0 +1,196 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/lnx.h).
+
+These take torch CUDA tensors only to obtain device pointers, sizes and the current HIP
+stream; all arithmetic happens in liblnx_hip.so.  Used by the per-op parity tests and by
+the model glue.  Nothing here has a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import F32, BF16  # noqa: F401
+
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def code_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise L.LnxError(f"unsupported tensor dtype {t.dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return _TORCH_DT[code]
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.LnxError("linnaeus_amd kernels need CUDA(HIP) tensors; there is no CPU fallback")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _map(m) -> L.RowMap:
+    return L.RowMap(*(m or (0, 0, 0)))
+
+
+def gemm_nt(A, W, out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, act=L.ACT_NONE, aux=None, c2=None,
+            gamma=None, rowscale=None, rows_per_sample=0, res=None, c_map=None, a_patch=None, c_patch=None, dtype=None):
+    """out = epilogue(A . W^T); see lnx_gemm_args.  a_patch / c_patch = (Hin, Win, Cin)."""
+    a = L.GemmArgs()
+    a.dtype = dtype if dtype is not None else code_of(W)
+    a.M = M if M is not None else A.shape[0]
+    a.N = N if N is not None else W.shape[0]
+    a.K = K if K is not None else W.shape[1]
+    a.A, a.lda = _p(A), (lda if lda is not None else (A.stride(0) if a_patch is None else 0))
+    a.W, a.ldw = _p(W), (ldw if ldw is not None else W.stride(0))
+    a.C, a.ldc = _p(out), (ldc if ldc is not None else (out.stride(0) if c_patch is None else 0))
+    a.out_f32 = int(out.dtype == torch.float32)
+    if a_patch is not None:
+        a.a_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, *a_patch
+    if c_patch is not None:
+        a.c_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, *c_patch
+    a.c_map = _map(c_map)
+    a.bias = _p(bias)
+    a.c2, a.ldc2 = _p(c2), (c2.stride(0) if c2 is not None else 0)
+    a.act, a.aux, a.ldaux = act, _p(aux), (aux.stride(0) if aux is not None else 0)
+    a.gamma, a.rowscale, a.rows_per_sample = _p(gamma), _p(rowscale), rows_per_sample
+    a.res, a.ldres = _p(res), ((res.stride(0) if c_patch is None else 0) if res is not None else 0)
+    L.check(L.lib().lnx_gemm_nt(C.byref(a), _stream()), "lnx_gemm_nt")
+    return out
+
+
+def gemm_tn(dY, A, dW, *, M=None, N=None, K=None, lda=None, lddw=None, db=None, a_patch=None, k_perm_c=0, k_store=0, splits=0, dtype=None):
+    a = L.WgradArgs()
+    a.dtype = dtype if dtype is not None else code_of(dY)
+    a.M = M if M is not None else dY.shape[0]
+    a.N = N if N is not None else dY.shape[1]
+    a.K = K if K is not None else (A.shape[1] if a_patch is None else 4 * a_patch[2])
+    a.dY, a.lddy = _p(dY), dY.stride(0)
+    a.A, a.lda = _p(A), (lda if lda is not None else (A.stride(0) if a_patch is None else 0))
+    if a_patch is not None:
+        a.a_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, *a_patch
+    a.dW, a.lddw = _p(dW), (lddw if lddw is not None else dW.stride(0))
+    a.k_perm_c, a.db, a.splits, a.k_store = k_perm_c, _p(db), splits, k_store
+    L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+    return dW
+
+
+def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map=None, y_map=None, add=None, mean=None, rstd=None):
+    a = L.LnArgs()
+    a.M = M if M is not None else x.shape[0]
+    a.C = C_ if C_ is not None else x.shape[-1]
+    a.eps = eps
+    a.x, a.x_dtype, a.ldx, a.x_map = _p(x), code_of(x), (ldx if ldx is not None else x.stride(-2)), _map(x_map)
+    a.w, a.b = _p(w), _p(b)
+    a.y, a.y_dtype, a.ldy, a.y_map = _p(y), code_of(y), (ldy if ldy is not None else y.stride(-2)), _map(y_map)
+    a.add, a.ldadd = _p(add), (add.stride(-2) if add is not None else 0)
+    a.mean, a.rstd = _p(mean), _p(rstd)
+    L.check(L.lib().lnx_layernorm_fwd(C.byref(a), _stream()), "lnx_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=None, lddx=None, dy_map=None, x_map=None, gin=None,
+                  ldgin=None, dw=None, db=None, relu_mask=False):
+    a = L.LnBwdArgs()
+    a.M = M if M is not None else dy.shape[0]
+    a.C = C_ if C_ is not None else x.shape[-1]
+    a.dy, a.dy_dtype, a.lddy, a.dy_map = _p(dy), code_of(dy), (lddy if lddy is not None else dy.stride(-2)), _map(dy_map)
+    a.x, a.x_dtype, a.ldx, a.x_map = _p(x), code_of(x), (ldx if ldx is not None else x.stride(-2)), _map(x_map)
+    a.w, a.mean, a.rstd = _p(w), _p(mean), _p(rstd)
+    a.gin, a.ldgin = _p(gin), ((ldgin if ldgin is not None else gin.stride(-2)) if gin is not None else 0)
+    a.dx, a.dx_dtype, a.lddx = _p(dx), code_of(dx), (lddx if lddx is not None else dx.stride(-2))
+    a.dw, a.db, a.relu_mask = _p(dw), _p(db), int(relu_mask)
+    L.check(L.lib().lnx_layernorm_bwd(C.byref(a), _stream()), "lnx_layernorm_bwd")
+    return dx
+
+
+def dwconv7(x, w49, bias, y, *, flip=False, res=None):
+    B, H, W, Cc = x.shape
+    a = L.DwconvArgs()
+    a.B, a.H, a.W, a.C = B, H, W, Cc
+    a.x, a.x_dtype, a.w49, a.bias = _p(x), code_of(x), _p(w49), _p(bias)
+    a.flip, a.res, a.y, a.y_dtype = int(flip), _p(res), _p(y), code_of(y)
+    L.check(L.lib().lnx_dwconv7_fwd(C.byref(a), _stream()), "lnx_dwconv7_fwd")
+    return y
+
+
+def dwconv7_wgrad(x, dy, dw, db):
+    B, H, W, Cc = x.shape
+    a = L.DwconvWgradArgs()
+    a.B, a.H, a.W, a.C = B, H, W, Cc
+    a.x, a.x_dtype, a.dy, a.dy_dtype, a.dw, a.db = _p(x), code_of(x), _p(dy), code_of(dy), _p(dw), _p(db)
+    L.check(L.lib().lnx_dwconv7_wgrad(C.byref(a), _stream()), "lnx_dwconv7_wgrad")
+
+
+def rope_cos_table(freqs, H, W, out=None):
+    heads = freqs.shape[1]
+    if out is None:
+        out = torch.empty(H * W, heads, 32, device=freqs.device, dtype=torch.float32)
+    L.check(L.lib().lnx_rope_cos_table(_p(freqs), heads, H, W, _p(out), _stream()), "lnx_rope_cos_table")
+    return out
+
+
+def rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs):
+    L.check(L.lib().lnx_rope_freqs_bwd(_p(freqs), _p(gcos), B, freqs.shape[1], H, W, _p(dfreqs), _stream()), "lnx_rope_freqs_bwd")
+
+
+def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads):
+    a = L.AttnArgs()
+    a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
+    a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
+    L.check(L.lib().lnx_attn_fwd(C.byref(a), _stream()), "lnx_attn_fwd")
+
+
+def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads):
+    a = L.AttnBwdArgs()
+    a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
+    a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
+    a.d_o, a.dqkv, a.gcos, a.delta = _p(d_o), _p(dqkv), _p(gcos), _p(delta)
+    L.check(L.lib().lnx_attn_bwd(C.byref(a), _stream()), "lnx_attn_bwd")
+
+
+def im2col_stem(x, patches):
+    B, Cin, H, W = x.shape
+    L.check(L.lib().lnx_im2col_stem(_p(x), B, Cin, H, W, _p(patches), code_of(patches), patches.stride(0), _stream()), "lnx_im2col_stem")
+
+
+def scale_cast(inp, out, M, Cc, *, ldin=None, in_map=None, rowscale=None, rows_per_sample=0, ldout=None):
+    L.check(L.lib().lnx_scale_cast(_p(inp), C.c_int64(ldin if ldin is not None else inp.stride(-2)), _map(in_map), _p(rowscale), rows_per_sample,
+                                   _p(out), code_of(out), C.c_int64(ldout if ldout is not None else out.stride(-2)), M, Cc, _stream()), "lnx_scale_cast")
+
+
+def layerscale_bwd(g, z, gamma, rowscale, rows_per_sample, dz, dgamma, M, Cc):
+    L.check(L.lib().lnx_layerscale_bwd(_p(g), _p(z), code_of(z), _p(gamma), _p(rowscale), rows_per_sample, _p(dz), _p(dgamma), M, Cc, _stream()),
+            "lnx_layerscale_bwd")
+
+
+def fill_rows(vec, out, ldout, row_map, M, Cc):
+    L.check(L.lib().lnx_fill_rows(_p(vec), _p(out), C.c_int64(ldout), _map(row_map), M, Cc, _stream()), "lnx_fill_rows")
+
+
+def colsum_rows(inp, ldin, row_map, out, M, Cc):
+    L.check(L.lib().lnx_colsum_rows(_p(inp), C.c_int64(ldin), _map(row_map), _p(out), M, Cc, _stream()), "lnx_colsum_rows")
+
+
+def agg2_fwd(a, b, w2, bias1, out, M, Cc):
+    L.check(L.lib().lnx_agg2_fwd(_p(a), _p(b), _p(w2), _p(bias1), _p(out), M, Cc, _stream()), "lnx_agg2_fwd")
+
+
+def agg2_bwd(dout, a, b, w2, da, db, dw2, dbias1, M, Cc):
+    L.check(L.lib().lnx_agg2_bwd(_p(dout), _p(a), _p(b), _p(w2), _p(da), _p(db), _p(dw2), _p(dbias1), M, Cc, _stream()), "lnx_agg2_bwd")
+
+
+def pack_meta(meta, off, dim, out):
+    L.check(L.lib().lnx_pack_meta(_p(meta), meta.shape[1], off, dim, _p(out), code_of(out), meta.shape[0], _stream()), "lnx_pack_meta")

@@ -1,0 +1,245 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against the CPU oracle's functions /
+plain PyTorch fp32-fp64 on the same seeded inputs.  fp32 mode: tight tolerances; bf16 mode:
+tolerance of the bf16 storage rounding, stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from linnaeus_amd import _lib as L
+from linnaeus_amd import ops
+from oracle import mformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+DT = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("C_", [32, 96, 192, 384, 768, 2048])
+@pytest.mark.parametrize("xd,yd", [(L.F32, L.F32), (L.F32, L.BF16), (L.BF16, L.BF16), (L.BF16, L.F32)])
+def test_layernorm_fwd_bwd(C_, xd, yd):
+    M = 77
+    gen = g(C_ + xd * 3 + yd)
+    x = (torch.randn(M, C_, generator=gen) * 2 + 0.5).cuda().to(DT[xd])
+    w = (1 + 0.2 * torch.randn(C_, generator=gen)).cuda()
+    b = (0.1 * torch.randn(C_, generator=gen)).cuda()
+    y = torch.empty(M, C_, device="cuda", dtype=DT[yd])
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    ops.layernorm_fwd(x, w, b, y, 1e-6, mean=mean, rstd=rstd)
+    xr = x.double().cpu().requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    br = b.double().cpu().requires_grad_(True)
+    ref = O.layer_norm_last(xr, wr, br, 1e-6)
+    tol = 2e-5 if yd == L.F32 else 1.6e-2
+    torch.testing.assert_close(y.double().cpu(), ref.detach(), rtol=tol, atol=tol)
+    # backward
+    dy = torch.randn(M, C_, generator=gen).cuda().to(DT[yd])
+    gin = torch.randn(M, C_, generator=gen).cuda()
+    dx = torch.empty(M, C_, device="cuda")
+    dw = torch.zeros(C_, device="cuda")
+    db = torch.zeros(C_, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx, gin=gin, dw=dw, db=db)
+    ref.backward(dy.double().cpu())
+    torch.testing.assert_close(dx.double().cpu(), xr.grad + gin.double().cpu(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(db.double().cpu(), br.grad, rtol=1e-4, atol=2e-4)
+
+
+def test_layernorm_rowmaps_add_relu():
+    B, HW, E, C_ = 3, 5, 2, 64
+    N = HW + E
+    gen = g(9)
+    tok = torch.randn(B * N, C_, generator=gen).cuda()
+    w = (1 + 0.2 * torch.randn(C_, generator=gen)).cuda()
+    b = (0.1 * torch.randn(C_, generator=gen)).cuda()
+    # read patch rows of a token buffer, write compact
+    y = torch.empty(B * HW, C_, device="cuda")
+    ops.layernorm_fwd(tok, w, b, y, 1e-5, M=B * HW, x_map=(HW, E, E))
+    ref = O.layer_norm_last(tok.view(B, N, C_)[:, E:].reshape(B * HW, C_).cpu(), w.cpu(), b.cpu(), 1e-5)
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+    # CLS rows only, with an added skip tensor, written into row 1 of each sample
+    add = torch.randn(B, C_, generator=gen).cuda()
+    out = torch.zeros(B * N, C_, device="cuda")
+    ops.layernorm_fwd(tok, w, b, out, 1e-5, M=B, x_map=(1, N - 1, 0), y_map=(1, N - 1, 1), add=add)
+    ref = O.layer_norm_last(tok.view(B, N, C_)[:, 0].cpu(), w.cpu(), b.cpu(), 1e-5) + add.cpu()
+    torch.testing.assert_close(out.view(B, N, C_)[:, 1].cpu(), ref, rtol=2e-5, atol=2e-5)
+    assert out.view(B, N, C_)[:, 0].abs().sum().item() == 0
+    # relu-mask backward
+    x = torch.relu(torch.randn(B, C_, generator=gen)).cuda()
+    mean = torch.empty(B, device="cuda")
+    rstd = torch.empty(B, device="cuda")
+    yy = torch.empty(B, C_, device="cuda")
+    ops.layernorm_fwd(x, w, b, yy, 1e-5, mean=mean, rstd=rstd)
+    dy = torch.randn(B, C_, generator=gen).cuda()
+    dx = torch.empty(B, C_, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx, relu_mask=True)
+    pre = torch.randn(B, C_).double()
+    pre = (x.double().cpu() > 0).double() * x.double().cpu() - (x.double().cpu() <= 0).double()  # pre-activation with same mask
+    pre.requires_grad_(True)
+    O.layer_norm_last(torch.relu(pre), w.double().cpu(), b.double().cpu(), 1e-5).backward(dy.double().cpu())
+    torch.testing.assert_close(dx.double().cpu(), pre.grad, rtol=1e-4, atol=1e-4)
+
+
+def _w49(w):  # [C,1,7,7] -> [49][C]
+    return w.reshape(w.shape[0], 49).t().contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,C_", [(2, 6, 5, 32), (1, 16, 16, 64), (2, 28, 28, 96), (1, 56, 56, 32), (3, 9, 23, 64)])
+@pytest.mark.parametrize("xd,yd", [(L.F32, L.F32), (L.F32, L.BF16), (L.BF16, L.F32)])
+def test_dwconv(B, H, W, C_, xd, yd):
+    gen = g(B * H + W + C_)
+    x = torch.randn(B, H, W, C_, generator=gen).cuda().to(DT[xd])
+    w = (torch.randn(C_, 1, 7, 7, generator=gen) / 7).cuda()
+    bias = torch.randn(C_, generator=gen).cuda()
+    y = torch.empty(B, H, W, C_, device="cuda", dtype=DT[yd])
+    ops.dwconv7(x, _w49(w), bias, y)
+    xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    br = bias.double().cpu().requires_grad_(True)
+    ref = O.depthwise_conv7(xr, wr, br)
+    tol = 2e-5 if yd == L.F32 else 1.6e-2
+    torch.testing.assert_close(y.double().cpu(), ref.detach().permute(0, 2, 3, 1), rtol=tol, atol=tol)
+    # data gradient (flip) with residual add, and weight gradient
+    dy = torch.randn(B, H, W, C_, generator=gen).cuda().to(DT[xd])
+    res = torch.randn(B, H, W, C_, generator=gen).cuda()
+    dx = torch.empty(B, H, W, C_, device="cuda")
+    ops.dwconv7(dy, _w49(w), None, dx, flip=True, res=res)
+    ref.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    torch.testing.assert_close(dx.double().cpu(), xr.grad.permute(0, 2, 3, 1) + res.double().cpu(), rtol=1e-4, atol=1e-4)
+    dw = torch.zeros(C_, 1, 7, 7, device="cuda")
+    db = torch.zeros(C_, device="cuda")
+    ops.dwconv7_wgrad(x, dy, dw, db)
+    sc = (B * H * W) ** 0.5
+    torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=1e-4, atol=2e-5 * sc)
+    torch.testing.assert_close(db.double().cpu(), br.grad, rtol=1e-4, atol=2e-5 * sc)
+
+
+def _attn_ref(qkv, freqs, B, N, E, heads, H, W):
+    """Oracle math of RoPE2DAttention between the qkv Linear and the proj Linear."""
+    C_ = heads * 64
+    t = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    cos = O.rope_cos_table(freqs, H, W).to(qkv.dtype)
+    q = torch.cat([q[:, :, :E], O.rope_scale_pairs(q[:, :, E:], cos)], 2) * 0.125
+    k = torch.cat([k[:, :, :E], O.rope_scale_pairs(k[:, :, E:], cos)], 2)
+    a = torch.softmax(q @ k.transpose(-2, -1), -1)
+    return (a @ v).transpose(1, 2).reshape(B * N, C_)
+
+
+@pytest.mark.parametrize("B,heads,H,W,E", [(2, 2, 3, 5, 3), (1, 6, 14, 14, 3), (2, 4, 7, 7, 3), (1, 2, 12, 12, 4), (2, 1, 2, 2, 1), (1, 2, 24, 24, 4)])
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
+    N = H * W + E
+    C_ = heads * 64
+    gen = g(B + heads * 5 + N)
+    qkv = torch.randn(B * N, 3 * C_, generator=gen).cuda().to(DT[dtype])
+    freqs = O.seeded_fill("t.attn.freqs", (2, heads, 32), 7).cuda()
+    cos = ops.rope_cos_table(freqs, H, W)
+    torch.testing.assert_close(cos.cpu(), O.rope_cos_table(freqs.cpu(), H, W), rtol=0, atol=2e-6)
+    o = torch.empty(B * N, C_, device="cuda", dtype=DT[dtype])
+    lse = torch.empty(B, heads, N, device="cuda")
+    ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads)
+    qr = qkv.double().cpu().requires_grad_(True)
+    fr = freqs.double().cpu().requires_grad_(True)
+    ref = _attn_ref(qr, fr, B, N, E, heads, H, W)
+    tol = 3e-5 if dtype == L.F32 else 2e-2
+    torch.testing.assert_close(o.double().cpu(), ref.detach(), rtol=tol, atol=tol)
+    # backward
+    d_o = torch.randn(B * N, C_, generator=gen).cuda().to(DT[dtype])
+    dqkv = torch.full((B * N, 3 * C_), float("nan"), device="cuda", dtype=DT[dtype])
+    gcos = torch.zeros(2, B, H * W, heads, 32, device="cuda")
+    delta = torch.empty(B, heads, N, device="cuda")
+    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads)
+    dfreqs = torch.zeros(2, heads, 32, device="cuda")
+    ops.rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs)
+    ref.backward(d_o.double().cpu())
+    tolb = 1e-4 if dtype == L.F32 else 4e-2
+    torch.testing.assert_close(dqkv.double().cpu(), qr.grad, rtol=tolb, atol=tolb)
+    scale = fr.grad.abs().max().item()
+    torch.testing.assert_close(dfreqs.double().cpu(), fr.grad, rtol=tolb, atol=tolb * max(scale, 1.0))
+
+
+def test_attention_spiked_softmax():
+    """A key that dominates one query row late in the sequence forces the online-softmax
+    rescale path (running max jumps at the last key tile)."""
+    B, heads, H, W, E = 1, 1, 12, 12, 1
+    N = H * W + E
+    qkv = torch.randn(N, 192, generator=g(3)) * 0.3
+    qkv[5, 0:64] = 6.0          # query 5
+    qkv[N - 2, 64:128] = 6.0    # key N-2 aligned with it
+    qkv = qkv.cuda()
+    freqs = torch.zeros(2, 1, 32).cuda()  # cos == 1
+    cos = ops.rope_cos_table(freqs, H, W)
+    o = torch.empty(N, 64, device="cuda")
+    lse = torch.empty(1, 1, N, device="cuda")
+    ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads)
+    ref = _attn_ref(qkv.double().cpu(), freqs.double().cpu(), B, N, E, heads, H, W)
+    torch.testing.assert_close(o.double().cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_small_kernels(dtype):
+    gen = g(21)
+    tdt = DT[dtype]
+    # im2col
+    x = torch.randn(2, 3, 16, 24, generator=gen).cuda()
+    pat = torch.full((2 * 4 * 6, 64), float("nan"), device="cuda", dtype=tdt)
+    ops.im2col_stem(x, pat)
+    ref = torch.nn.functional.unfold(x.cpu(), 4, stride=4).transpose(1, 2).reshape(-1, 48)
+    torch.testing.assert_close(pat[:, :48].float().cpu(), ref.to(tdt).float(), rtol=0, atol=0)
+    assert pat[:, 48:].abs().sum().item() == 0
+    # scale_cast with row map
+    B, HW, E, C_ = 3, 4, 2, 32
+    tok = torch.randn(B * (HW + E), C_, generator=gen).cuda()
+    rs = torch.tensor([0.0, 2.0, 1.0]).cuda()
+    out = torch.empty(B * HW, C_, device="cuda", dtype=tdt)
+    ops.scale_cast(tok, out, B * HW, C_, in_map=(HW, E, E), rowscale=rs, rows_per_sample=HW)
+    ref = (tok.view(B, HW + E, C_)[:, E:] * rs[:, None, None]).reshape(B * HW, C_).to(tdt)
+    torch.testing.assert_close(out.float(), ref.float(), rtol=0, atol=0)
+    # layerscale backward
+    M, C_ = 150, 96
+    gg = torch.randn(M, C_, generator=gen).cuda()
+    z = torch.randn(M, C_, generator=gen).cuda().to(tdt)
+    gam = torch.randn(C_, generator=gen).cuda()
+    rs = torch.tensor([0.0, 1.25, 1.25]).cuda()
+    dz = torch.empty(M, C_, device="cuda", dtype=tdt)
+    dgam = torch.zeros(C_, device="cuda")
+    ops.layerscale_bwd(gg, z, gam, rs, 50, dz, dgam, M, C_)
+    s = rs.repeat_interleave(50)[:, None]
+    torch.testing.assert_close(dz.float(), (s * gam * gg).to(tdt).float(), rtol=1e-2 if dtype else 1e-6, atol=1e-2 if dtype else 1e-6)
+    torch.testing.assert_close(dgam, (s * gg * z.float()).sum(0), rtol=1e-4, atol=1e-4)
+    # fill_rows / colsum_rows
+    vec = torch.randn(C_, generator=gen).cuda()
+    buf = torch.zeros(3 * 7, C_, device="cuda")
+    ops.fill_rows(vec, buf, C_, (1, 6, 0), 3, C_)
+    assert torch.equal(buf.view(3, 7, C_)[:, 0], vec.expand(3, C_)) and buf.view(3, 7, C_)[:, 1:].abs().sum().item() == 0
+    src = torch.randn(3 * 7, C_, generator=gen).cuda()
+    acc = torch.zeros(C_, device="cuda")
+    ops.colsum_rows(src, C_, (1, 6, 2), acc, 3, C_)
+    torch.testing.assert_close(acc, src.view(3, 7, C_)[:, 2].sum(0), rtol=1e-5, atol=1e-5)
+    # aggregate
+    a = torch.randn(5, 64, generator=gen).cuda()
+    b = torch.randn(5, 64, generator=gen).cuda()
+    w2 = torch.tensor([0.7, -0.3]).cuda()
+    b1 = torch.tensor([0.2]).cuda()
+    out = torch.empty(5, 64, device="cuda")
+    ops.agg2_fwd(a, b, w2, b1, out, 5, 64)
+    torch.testing.assert_close(out, 0.7 * a - 0.3 * b + 0.2, rtol=1e-6, atol=1e-6)
+    dout = torch.randn(5, 64, generator=gen).cuda()
+    da = torch.empty_like(a)
+    dbb = torch.empty_like(b)
+    dw2 = torch.zeros(2, device="cuda")
+    db1 = torch.zeros(1, device="cuda")
+    ops.agg2_bwd(dout, a, b, w2, da, dbb, dw2, db1, 5, 64)
+    torch.testing.assert_close(da, 0.7 * dout)
+    torch.testing.assert_close(dbb, -0.3 * dout)
+    torch.testing.assert_close(dw2, torch.stack([(dout * a).sum(), (dout * b).sum()]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db1, dout.sum().reshape(1), rtol=1e-5, atol=1e-5)
+    # pack_meta
+    meta = torch.randn(4, 5, generator=gen).cuda()
+    pm = torch.full((4, 16), float("nan"), device="cuda", dtype=tdt)
+    ops.pack_meta(meta, 2, 3, pm)
+    assert torch.equal(pm[:, :3].float(), meta[:, 2:5].to(tdt).float()) and pm[:, 3:].abs().sum().item() == 0
