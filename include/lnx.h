@@ -270,6 +270,62 @@ int lnx_prep_weights(const lnx_prep_desc* descs_dev, int ndesc, int total_blocks
 /* number of workgroups lnx_prep_weights needs for one tensor */
 int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t);
 
+
+/* ------------------------------------------------------------------------------------
+ * Whole-model plan: mFormerV1 forward and backward as one native call each.
+ * Replaces mFormerV1.forward_features/forward (models/mFormerV1.py:407-541) and its
+ * autograd backward.  The plan owns no memory: the caller passes one workspace of
+ * lnx_plan_workspace_bytes() bytes (activations saved for backward, the T-typed operand
+ * arena, scratch) and binds parameter / gradient pointers in the plan's parameter order
+ * (= the reference's state_dict order, see lnx_plan_param_name).
+ * -----------------------------------------------------------------------------------*/
+#define LNX_MAX_META 8
+#define LNX_MAX_TASKS 16
+typedef struct lnx_mformer_cfg {
+    int dtype;                 /* LNX_F32 (strict parity) or LNX_BF16 */
+    int batch, img_h, img_w, in_chans;
+    int dims[4];               /* CONVNEXT_STAGES.DIMS (dims[2:] are the RoPE dims) */
+    int conv_depths[2];        /* CONVNEXT_STAGES.DEPTHS[0:2] */
+    int rope_depths[2];
+    int rope_heads[2];
+    int mlp_hidden[2];         /* int(dim * MLP_RATIO) */
+    int n_meta;                /* enabled metadata components, 0 = metadata inactive */
+    int meta_dims[LNX_MAX_META];
+    int only_last_cls;
+    int n_tasks;
+    int task_classes[LNX_MAX_TASKS];
+} lnx_mformer_cfg;
+
+typedef struct lnx_plan lnx_plan;
+int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out);
+void lnx_plan_destroy(lnx_plan* p);
+int64_t lnx_plan_workspace_bytes(const lnx_plan* p);
+int lnx_plan_num_params(const lnx_plan* p);
+/* "stem.0.weight", "stages.2.0.attn.freqs", ...; heads are "head.<task index>.weight|bias" */
+const char* lnx_plan_param_name(const lnx_plan* p, int i);
+int64_t lnx_plan_param_numel(const lnx_plan* p, int i);
+int lnx_plan_num_drop_calls(const lnx_plan* p);
+/* logits are written as one fp32 buffer: task t occupies [batch, ld_t] at element offset off_t */
+int64_t lnx_plan_logits_numel(const lnx_plan* p);
+int64_t lnx_plan_logits_offset(const lnx_plan* p, int task);
+int lnx_plan_logits_ld(const lnx_plan* p, int task);
+/* Bind device pointers: params[i] / grads[i] fp32 in plan order (grads may be NULL for an
+ * inference-only plan), workspace of lnx_plan_workspace_bytes().  Synchronises the device once. */
+int lnx_plan_bind(lnx_plan* p, const float* const* params, float* const* grads, void* workspace);
+/* x [B,Cin,H,W] fp32 NCHW, meta [B, sum(meta_dims)] fp32 or NULL, drop_scales [n_drop_calls, B]
+ * fp32 per-sample DropPath multipliers (NULL = eval / no DropPath), drop_mask[i] != 0 selects
+ * which calls use their row.  Outputs: feats [B, dims[3]] fp32, logits (layout above). */
+int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, const float* drop_scales, const unsigned char* drop_mask,
+                     float* feats, float* logits, void* stream);
+/* Backward of the last forward.  dlogits has the logits layout; dfeats [B, dims[3]] is an
+ * optional extra gradient on feats (NULL).  Parameter gradients are ACCUMULATED into the bound
+ * grads.  segment: -1 = everything, or 0..3 = {tail + RoPE stage 4, RoPE stage 3, ConvNeXt
+ * stage 2, ConvNeXt stage 1 + stem}, to be called in that order (lets the caller start the
+ * gradient all-reduce of a finished segment while the next one runs). */
+int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, int segment, void* stream);
+/* first / one-past-last parameter index whose gradient is final after `segment` */
+int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_out, int max_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,20 +211,18 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const lnx_prep_desc* 
             }
             reinterpret_cast<T*>(d.dst)[i] = from_f<T>(v);
         } else if (d.dst_t != nullptr) {
+            // transposed copy: only the [cols_out, rows] block is written (several tensors may share
+            // one row-padded destination, so padding columns are left as the caller zeroed them)
             const int64_t j = i - n_main;
-            if (j < (int64_t)cols_out * d.ld_t) {
-                const int k = (int)(j / d.ld_t), r = (int)(j % d.ld_t);
-                float v = 0.f;
-                if (r < d.rows) {
-                    int sk = k;
-                    if (d.mode == LNX_PREP_CONV_PERM) {
-                        const int Cc = d.cols / d.P;
-                        const int pp = k / Cc;
-                        sk = (k - pp * Cc) * d.P + pp;
-                    }
-                    v = d.src[(int64_t)r * d.cols + sk];
+            if (j < (int64_t)cols_out * d.rows) {
+                const int k = (int)(j / d.rows), r = (int)(j % d.rows);
+                int sk = k;
+                if (d.mode == LNX_PREP_CONV_PERM) {
+                    const int Cc = d.cols / d.P;
+                    const int pp = k / Cc;
+                    sk = (k - pp * Cc) * d.P + pp;
                 }
-                reinterpret_cast<T*>(d.dst_t)[j] = from_f<T>(v);
+                reinterpret_cast<T*>(d.dst_t)[(int64_t)k * d.ld_t + r] = from_f<T>(d.src[(int64_t)r * d.cols + sk]);
             }
         }
     }
@@ -330,8 +328,9 @@ extern "C" int lnx_pack_meta(const float* meta, int width, int off, int dim, voi
 }
 
 extern "C" int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t) {
+    (void)ld_t;
     int64_t n = (int64_t)rows * ld;
-    if (has_t) n += (int64_t)cols * ld_t;
+    if (has_t) n += (int64_t)cols * rows;
     return (int)((n + PREP_ELEMS - 1) / PREP_ELEMS);
 }
 

@@ -595,7 +595,9 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     const int epv = a->dtype == LNX_F32 ? 4 : 8;
     LNX_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "lnx_gemm_tn: empty problem");
     LNX_CHECK(a->dY && a->A && a->dW, "lnx_gemm_tn: null operand");
-    LNX_CHECK(a->N % epv == 0 && a->lddy % epv == 0, "lnx_gemm_tn: N=%d/lddy must be multiples of %d", a->N, epv);
+    // dY rows are read in 16-byte chunks: a chunk that starts below N may run past it, so the row
+    // must be padded (lddy >= roundup(N, epv)); what the padding holds is never stored
+    LNX_CHECK(a->lddy % epv == 0 && a->lddy >= (int64_t)cdiv(a->N, epv) * epv, "lnx_gemm_tn: lddy=%lld must be a multiple of %d and >= roundup(N)", (long long)a->lddy, epv);
     LNX_CHECK(a->K % epv == 0, "lnx_gemm_tn: K=%d must be a multiple of %d", a->K, epv);
     LNX_CHECK((((uintptr_t)a->A) & 15) == 0 && (((uintptr_t)a->dY) & 15) == 0, "lnx_gemm_tn: operands must be 16-byte aligned");
     if (a->a_mode == LNX_ADDR_PATCH2) {

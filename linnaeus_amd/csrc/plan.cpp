@@ -1,0 +1,1208 @@
+// mFormerV1 forward/backward plan: the native runtime of the path.
+//
+// One lnx_plan_forward / lnx_plan_backward call enqueues every kernel of a training step's
+// model work on the caller's HIP stream (no allocation, no host sync, no Python between
+// kernels).  Orchestration follows mFormerV1.forward_features (models/mFormerV1.py:407-529),
+// restated for NHWC / token-major buffers:
+//
+//   activations      T (bf16 | fp32) row-major [rows, channels]; conv stages are NHWC
+//   residual stream  fp32 (what autocast keeps in fp32 in the reference)
+//   parameters/grads fp32, caller-owned; a T-typed operand arena is refreshed every forward
+//   saved-for-backward tensors live in the workspace until the next forward
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lnx.h"
+
+void lnx_set_error(const char* fmt, ...);
+
+#define RUN(expr)                  \
+    do {                           \
+        const int rc_ = (expr);    \
+        if (rc_ != 0) return rc_;  \
+    } while (0)
+#define FAIL(...)                   \
+    do {                            \
+        lnx_set_error(__VA_ARGS__); \
+        return 1;                   \
+    } while (0)
+#define HIPRUN(expr)                                                         \
+    do {                                                                     \
+        const hipError_t e_ = (expr);                                        \
+        if (e_ != hipSuccess) FAIL("%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct OpW {          // a GEMM weight in the T-typed operand arena
+    int param = -1;   // source parameter
+    int N = 0, K = 0; // logical [N, K]
+    int ld = 0;       // leading dimension of the [N, ld] copy (K zero-padded)
+    int ld_t = 0;     // leading dimension of the transposed [K, ld_t] copy (0: none)
+    int mode = LNX_PREP_CAST, P = 0;
+    bool f32 = false;  // operand kept in fp32 even in bf16 mode (the tiny M = batch meta-head GEMMs)
+    int64_t off = 0, off_t = 0;
+};
+
+struct ConvBlk {
+    int gamma, dww, dwb, lnw, lnb, b1, b2;
+    OpW w1, w2;
+    int64_t w49;  // fp32 [49][C] in the arena
+    // saved
+    int64_t xin, y, ln, mean, rstd, hpre, act, z;
+};
+struct RopeBlk {
+    int n1w, n1b, n2w, n2b, freqs, qkvb, projb, fc1b, fc2b;
+    OpW qkv, proj, fc1, fc2;
+    int64_t xin, n1, mean1, rstd1, qkvbuf, cos, o, lse, xmid, n2, mean2, rstd2, hpre, act;
+};
+struct MetaHead {
+    int b0, lnw0, lnb0, nf1w, nf1b, nf2w, nf2b, b1, b2;
+    OpW w0, w1, w2;
+    int dim, off;
+    int64_t t0, h0, x, m0, r0, h1, n1, m1, r1, h2, m2, r2;
+};
+struct Down {
+    int lnw, lnb, cb;
+    OpW w;
+    int64_t ln, mean, rstd;
+};
+
+}  // namespace
+
+struct lnx_plan {
+    lnx_mformer_cfg c;
+    int esz;  // sizeof(T)
+    int E;    // extra tokens
+    int H[4], W[4], HW[4];
+    int N2, N3;
+    std::vector<std::string> names;
+    std::vector<int64_t> numel;
+    std::vector<const float*> P;
+    std::vector<float*> G;
+    bool bound = false, has_grads = false, fwd_done = false;
+    unsigned char* ws = nullptr;
+    int64_t ws_bytes = 0;
+
+    // parameters
+    int stem_b, stem_lnw, stem_lnb, cls[2], norm_w[2], norm_b[2], fin_w, fin_b, agg_w, agg_b, cl_b1, cl_b2, cl_lnw, cl_lnb;
+    OpW stem_w, cl_w1, cl_w2;
+    std::vector<int> head_b;
+    std::vector<OpW> head_w;
+    std::vector<int> logit_ld;
+    std::vector<int64_t> logit_off;
+    int64_t logits_numel = 0;
+    Down down[3];
+    std::vector<ConvBlk> conv[2];
+    std::vector<RopeBlk> rope[2];
+    std::vector<MetaHead> meta[2];
+    std::vector<OpW*> all_w;
+    std::vector<int> drop_conv[2], drop_attn[2], drop_mlp[2];
+    int n_drop = 0;
+
+    // workspace offsets
+    int64_t o_descs = 0, n_descs = 0, prep_blocks = 0;
+    int64_t n_descs_t = 0, n_descs_f = 0, prep_blocks_f = 0;  // T-typed table first, fp32-typed table after it
+    int64_t o_patches, o_stem_pre, o_stem_mean, o_stem_rstd;
+    int64_t o_stage_out[4];   // fp32 output of each stage (input of the next downsample / norm)
+    int64_t o_tok[2];         // fp32 token buffers entering RoPE stages
+    int64_t o_t1, o_t1_mean, o_t1_rstd;           // norm_1 output (T) + stats
+    int64_t o_cl_hpre, o_cl_act, o_cl_u, o_cl_mean, o_cl_rstd, o_c1n;
+    int64_t o_c2n, o_n2_mean, o_n2_rstd, o_agg, o_fin_mean, o_fin_rstd, o_feats, o_featsT;
+    int64_t o_g[4];           // fp32 gradient streams per stage
+    int64_t o_sA, o_sC, o_sD; // T scratch: [M,4C] / [M,C] / [M,C]
+    int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
+    const float* last_drop = nullptr;
+    const unsigned char* last_mask = nullptr;
+    std::vector<unsigned char> mask_host;
+    const float* last_meta = nullptr;
+
+    template <typename U> U* at(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
+    const float* drop_ptr(int call) const {
+        if (last_drop == nullptr || call < 0 || !mask_host[call]) return nullptr;
+        return last_drop + (int64_t)call * c.batch;
+    }
+};
+
+namespace {
+
+int find_param(const lnx_plan* p, const std::string& n) {
+    for (size_t i = 0; i < p->names.size(); ++i)
+        if (p->names[i] == n) return (int)i;
+    return -1;
+}
+
+void add_param(lnx_plan* p, const std::string& n, int64_t numel) {
+    p->names.push_back(n);
+    p->numel.push_back(numel);
+}
+
+// parameter inventory in the reference's state_dict order (mFormerV1.py:145-343; checked
+// against the reference by tests/golden/gen/make_golden.py through oracle.param_shapes)
+void build_inventory(lnx_plan* p) {
+    const lnx_mformer_cfg& c = p->c;
+    const int* D = c.dims;
+    char b[128];
+    add_param(p, "cls_token_1", D[2]);
+    add_param(p, "cls_token_2", D[3]);
+    add_param(p, "stem.0.weight", (int64_t)D[0] * c.in_chans * 16);
+    add_param(p, "stem.0.bias", D[0]);
+    add_param(p, "stem.1.weight", D[0]);
+    add_param(p, "stem.1.bias", D[0]);
+    for (int i = 0; i < 3; ++i) {
+        snprintf(b, sizeof b, "downsample_layers.%d.", i);
+        const std::string pre(b);
+        add_param(p, pre + "norm.weight", D[i]);
+        add_param(p, pre + "norm.bias", D[i]);
+        add_param(p, pre + "conv.weight", (int64_t)D[i + 1] * D[i] * 4);
+        add_param(p, pre + "conv.bias", D[i + 1]);
+    }
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < c.conv_depths[s]; ++i) {
+            snprintf(b, sizeof b, "stages.%d.%d.", s, i);
+            const std::string pre(b);
+            const int64_t C = D[s];
+            add_param(p, pre + "gamma", C);
+            add_param(p, pre + "dwconv.weight", C * 49);
+            add_param(p, pre + "dwconv.bias", C);
+            add_param(p, pre + "norm.weight", C);
+            add_param(p, pre + "norm.bias", C);
+            add_param(p, pre + "pwconv1.weight", 4 * C * C);
+            add_param(p, pre + "pwconv1.bias", 4 * C);
+            add_param(p, pre + "pwconv2.weight", 4 * C * C);
+            add_param(p, pre + "pwconv2.bias", C);
+        }
+    for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < c.rope_depths[s]; ++i) {
+            snprintf(b, sizeof b, "stages.%d.%d.", s + 2, i);
+            const std::string pre(b);
+            const int64_t C = D[2 + s], hid = c.mlp_hidden[s];
+            add_param(p, pre + "norm1.weight", C);
+            add_param(p, pre + "norm1.bias", C);
+            add_param(p, pre + "norm2.weight", C);
+            add_param(p, pre + "norm2.bias", C);
+            add_param(p, pre + "attn.freqs", 2 * c.rope_heads[s] * 32);
+            add_param(p, pre + "attn.qkv.weight", 3 * C * C);
+            add_param(p, pre + "attn.qkv.bias", 3 * C);
+            add_param(p, pre + "attn.proj.weight", C * C);
+            add_param(p, pre + "attn.proj.bias", C);
+            add_param(p, pre + "mlp.fc1.weight", hid * C);
+            add_param(p, pre + "mlp.fc1.bias", hid);
+            add_param(p, pre + "mlp.fc2.weight", C * hid);
+            add_param(p, pre + "mlp.fc2.bias", C);
+        }
+    add_param(p, "norm_1.weight", D[2]);
+    add_param(p, "norm_1.bias", D[2]);
+    add_param(p, "norm_2.weight", D[3]);
+    add_param(p, "norm_2.bias", D[3]);
+    for (int m = 0; m < c.n_meta; ++m)
+        for (int s = 0; s < 2; ++s) {
+            snprintf(b, sizeof b, "meta.%d.head_%d.", m, s + 1);
+            const std::string pre(b);
+            const int64_t C = D[2 + s];
+            add_param(p, pre + "0.weight", C * c.meta_dims[m]);
+            add_param(p, pre + "0.bias", C);
+            add_param(p, pre + "2.weight", C);
+            add_param(p, pre + "2.bias", C);
+            add_param(p, pre + "3.norm_fn1.weight", C);
+            add_param(p, pre + "3.norm_fn1.bias", C);
+            add_param(p, pre + "3.norm_fn2.weight", C);
+            add_param(p, pre + "3.norm_fn2.bias", C);
+            add_param(p, pre + "3.w1.weight", C * C);
+            add_param(p, pre + "3.w1.bias", C);
+            add_param(p, pre + "3.w2.weight", C * C);
+            add_param(p, pre + "3.w2.bias", C);
+        }
+    if (!c.only_last_cls) {
+        add_param(p, "cl_1_fc.0.fc1.weight", (int64_t)D[2] * D[2]);
+        add_param(p, "cl_1_fc.0.fc1.bias", D[2]);
+        add_param(p, "cl_1_fc.0.fc2.weight", (int64_t)D[3] * D[2]);
+        add_param(p, "cl_1_fc.0.fc2.bias", D[3]);
+        add_param(p, "cl_1_fc.1.weight", D[3]);
+        add_param(p, "cl_1_fc.1.bias", D[3]);
+        add_param(p, "aggregate.weight", 2);
+        add_param(p, "aggregate.bias", 1);
+    }
+    add_param(p, "final_norm.weight", D[3]);
+    add_param(p, "final_norm.bias", D[3]);
+    for (int t = 0; t < c.n_tasks; ++t) {
+        snprintf(b, sizeof b, "head.%d.", t);
+        add_param(p, std::string(b) + "weight", (int64_t)c.task_classes[t] * D[3]);
+        add_param(p, std::string(b) + "bias", c.task_classes[t]);
+    }
+}
+
+struct Carver {
+    int64_t cur = 0;
+    int64_t take(int64_t bytes) {
+        const int64_t o = cur;
+        cur += align_up(bytes > 0 ? bytes : 16, 256);
+        return o;
+    }
+};
+
+OpW make_w(lnx_plan* p, const std::string& name, int N, int K, bool want_t, int mode = LNX_PREP_CAST, int P = 0, bool f32 = false) {
+    OpW w;
+    w.param = find_param(p, name);
+    w.N = N;
+    w.K = K;
+    w.f32 = f32 || p->esz == 4;
+    const int epv = w.f32 ? 4 : 8;
+    w.ld = (int)align_up(K, epv);
+    if (K < 16) w.ld = 16;  // tiny-K first meta Linear: pad to one 16-element chunk row
+    w.ld_t = want_t ? (int)align_up(N, epv) : 0;
+    w.mode = mode;
+    w.P = P;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
+    if (!cfg || !out) FAIL("lnx_plan_create: null argument");
+    const lnx_mformer_cfg& c = *cfg;
+    if (c.dtype != LNX_F32 && c.dtype != LNX_BF16) FAIL("lnx_plan_create: bad dtype %d", c.dtype);
+    if (c.batch <= 0 || c.img_h <= 0 || c.img_w <= 0 || c.in_chans <= 0 || c.in_chans > 4) FAIL("lnx_plan_create: bad input geometry");
+    if (c.img_h % 32 != 0 || c.img_w % 32 != 0) FAIL("lnx_plan_create: image size %dx%d must be divisible by 32 (4*2*2*2 patchify)", c.img_h, c.img_w);
+    for (int i = 0; i < 4; ++i)
+        if (c.dims[i] <= 0 || c.dims[i] % 32 != 0 || c.dims[i] > 2048) FAIL("lnx_plan_create: dims[%d]=%d must be a multiple of 32 in (0, 2048]", i, c.dims[i]);
+    for (int s = 0; s < 2; ++s) {
+        if (c.conv_depths[s] < 0 || c.rope_depths[s] <= 0) FAIL("lnx_plan_create: bad depths");
+        if (c.rope_heads[s] <= 0 || c.dims[2 + s] != c.rope_heads[s] * 64) FAIL("lnx_plan_create: head_dim must be 64 (dim %d, heads %d)", c.dims[2 + s], c.rope_heads[s]);
+        if (c.mlp_hidden[s] <= 0 || c.mlp_hidden[s] % 16 != 0) FAIL("lnx_plan_create: mlp_hidden must be a multiple of 16");
+    }
+    if (c.n_meta < 0 || c.n_meta > LNX_MAX_META || c.n_tasks < 0 || c.n_tasks > LNX_MAX_TASKS) FAIL("lnx_plan_create: too many meta components / tasks");
+    for (int m = 0; m < c.n_meta; ++m)
+        if (c.meta_dims[m] <= 0 || c.meta_dims[m] > 16) FAIL("lnx_plan_create: meta dim %d must be in 1..16", c.meta_dims[m]);
+
+    lnx_plan* p = new lnx_plan();
+    p->c = c;
+    p->esz = c.dtype == LNX_BF16 ? 2 : 4;
+    p->E = 1 + c.n_meta;
+    p->H[0] = c.img_h / 4;
+    p->W[0] = c.img_w / 4;
+    for (int i = 1; i < 4; ++i) {
+        p->H[i] = p->H[i - 1] / 2;
+        p->W[i] = p->W[i - 1] / 2;
+    }
+    for (int i = 0; i < 4; ++i) p->HW[i] = p->H[i] * p->W[i];
+    p->N2 = p->HW[2] + p->E;
+    p->N3 = p->HW[3] + p->E;
+    build_inventory(p);
+    const int* D = c.dims;
+    const int B = c.batch;
+    const int esz = p->esz;
+    char b[128];
+
+    // ---- parameter handles and operand-arena entries ----
+    p->cls[0] = find_param(p, "cls_token_1");
+    p->cls[1] = find_param(p, "cls_token_2");
+    p->stem_w = make_w(p, "stem.0.weight", D[0], c.in_chans * 16, false);
+    p->stem_w.ld = 64;
+    p->stem_b = find_param(p, "stem.0.bias");
+    p->stem_lnw = find_param(p, "stem.1.weight");
+    p->stem_lnb = find_param(p, "stem.1.bias");
+    for (int i = 0; i < 3; ++i) {
+        snprintf(b, sizeof b, "downsample_layers.%d.", i);
+        const std::string pre(b);
+        p->down[i].lnw = find_param(p, pre + "norm.weight");
+        p->down[i].lnb = find_param(p, pre + "norm.bias");
+        p->down[i].cb = find_param(p, pre + "conv.bias");
+        p->down[i].w = make_w(p, pre + "conv.weight", D[i + 1], 4 * D[i], true, LNX_PREP_CONV_PERM, 4);
+    }
+    int call = 0;
+    for (int s = 0; s < 2; ++s) {
+        p->conv[s].resize(c.conv_depths[s]);
+        for (int i = 0; i < c.conv_depths[s]; ++i) {
+            snprintf(b, sizeof b, "stages.%d.%d.", s, i);
+            const std::string pre(b);
+            ConvBlk& k = p->conv[s][i];
+            const int C = D[s];
+            k.gamma = find_param(p, pre + "gamma");
+            k.dww = find_param(p, pre + "dwconv.weight");
+            k.dwb = find_param(p, pre + "dwconv.bias");
+            k.lnw = find_param(p, pre + "norm.weight");
+            k.lnb = find_param(p, pre + "norm.bias");
+            k.b1 = find_param(p, pre + "pwconv1.bias");
+            k.b2 = find_param(p, pre + "pwconv2.bias");
+            k.w1 = make_w(p, pre + "pwconv1.weight", 4 * C, C, true);
+            k.w2 = make_w(p, pre + "pwconv2.weight", C, 4 * C, true);
+            p->drop_conv[s].push_back(call++);
+        }
+    }
+    for (int s = 0; s < 2; ++s) {
+        p->rope[s].resize(c.rope_depths[s]);
+        for (int i = 0; i < c.rope_depths[s]; ++i) {
+            snprintf(b, sizeof b, "stages.%d.%d.", s + 2, i);
+            const std::string pre(b);
+            RopeBlk& k = p->rope[s][i];
+            const int C = D[2 + s], hid = c.mlp_hidden[s];
+            k.n1w = find_param(p, pre + "norm1.weight");
+            k.n1b = find_param(p, pre + "norm1.bias");
+            k.n2w = find_param(p, pre + "norm2.weight");
+            k.n2b = find_param(p, pre + "norm2.bias");
+            k.freqs = find_param(p, pre + "attn.freqs");
+            k.qkvb = find_param(p, pre + "attn.qkv.bias");
+            k.projb = find_param(p, pre + "attn.proj.bias");
+            k.fc1b = find_param(p, pre + "mlp.fc1.bias");
+            k.fc2b = find_param(p, pre + "mlp.fc2.bias");
+            k.qkv = make_w(p, pre + "attn.qkv.weight", 3 * C, C, true);
+            k.proj = make_w(p, pre + "attn.proj.weight", C, C, true);
+            k.fc1 = make_w(p, pre + "mlp.fc1.weight", hid, C, true);
+            k.fc2 = make_w(p, pre + "mlp.fc2.weight", C, hid, true);
+            p->drop_attn[s].push_back(call++);
+            p->drop_mlp[s].push_back(call++);
+        }
+    }
+    p->n_drop = call;
+    for (int s = 0; s < 2; ++s) {
+        snprintf(b, sizeof b, "norm_%d.", s + 1);
+        p->norm_w[s] = find_param(p, std::string(b) + "weight");
+        p->norm_b[s] = find_param(p, std::string(b) + "bias");
+        p->meta[s].resize(c.n_meta);
+        int off = 0;
+        for (int m = 0; m < c.n_meta; ++m) {
+            snprintf(b, sizeof b, "meta.%d.head_%d.", m, s + 1);
+            const std::string pre(b);
+            MetaHead& k = p->meta[s][m];
+            const int C = D[2 + s];
+            k.dim = c.meta_dims[m];
+            k.off = off;
+            off += k.dim;
+            k.w0 = make_w(p, pre + "0.weight", C, k.dim, false, LNX_PREP_CAST, 0, true);
+            k.b0 = find_param(p, pre + "0.bias");
+            k.lnw0 = find_param(p, pre + "2.weight");
+            k.lnb0 = find_param(p, pre + "2.bias");
+            k.nf1w = find_param(p, pre + "3.norm_fn1.weight");
+            k.nf1b = find_param(p, pre + "3.norm_fn1.bias");
+            k.nf2w = find_param(p, pre + "3.norm_fn2.weight");
+            k.nf2b = find_param(p, pre + "3.norm_fn2.bias");
+            k.w1 = make_w(p, pre + "3.w1.weight", C, C, true, LNX_PREP_CAST, 0, true);
+            k.b1 = find_param(p, pre + "3.w1.bias");
+            k.w2 = make_w(p, pre + "3.w2.weight", C, C, true, LNX_PREP_CAST, 0, true);
+            k.b2 = find_param(p, pre + "3.w2.bias");
+        }
+    }
+    if (!c.only_last_cls) {
+        p->cl_w1 = make_w(p, "cl_1_fc.0.fc1.weight", D[2], D[2], true);
+        p->cl_w2 = make_w(p, "cl_1_fc.0.fc2.weight", D[3], D[2], true);
+        p->cl_b1 = find_param(p, "cl_1_fc.0.fc1.bias");
+        p->cl_b2 = find_param(p, "cl_1_fc.0.fc2.bias");
+        p->cl_lnw = find_param(p, "cl_1_fc.1.weight");
+        p->cl_lnb = find_param(p, "cl_1_fc.1.bias");
+        p->agg_w = find_param(p, "aggregate.weight");
+        p->agg_b = find_param(p, "aggregate.bias");
+    }
+    p->fin_w = find_param(p, "final_norm.weight");
+    p->fin_b = find_param(p, "final_norm.bias");
+    p->head_w.resize(c.n_tasks);
+    p->head_b.resize(c.n_tasks);
+    p->logit_ld.resize(c.n_tasks);
+    p->logit_off.resize(c.n_tasks);
+    for (int t = 0; t < c.n_tasks; ++t) {
+        snprintf(b, sizeof b, "head.%d.", t);
+        p->head_w[t] = make_w(p, std::string(b) + "weight", c.task_classes[t], D[3], true);
+        p->head_b[t] = find_param(p, std::string(b) + "bias");
+        p->logit_ld[t] = (int)align_up(c.task_classes[t], 8);
+        p->head_w[t].ld_t = p->logit_ld[t];  // the data-gradient GEMM contracts over the padded logits row
+        p->logit_off[t] = p->logits_numel;
+        p->logits_numel += (int64_t)B * p->logit_ld[t];
+    }
+
+    // collect every arena weight
+    auto reg = [&](OpW& w) { p->all_w.push_back(&w); };
+    reg(p->stem_w);
+    for (int i = 0; i < 3; ++i) reg(p->down[i].w);
+    for (int s = 0; s < 2; ++s)
+        for (auto& k : p->conv[s]) {
+            reg(k.w1);
+            reg(k.w2);
+        }
+    for (int s = 0; s < 2; ++s)
+        for (auto& k : p->rope[s]) {
+            reg(k.qkv);
+            reg(k.proj);
+            reg(k.fc1);
+            reg(k.fc2);
+        }
+    for (int s = 0; s < 2; ++s)
+        for (auto& k : p->meta[s]) {
+            reg(k.w0);
+            reg(k.w1);
+            reg(k.w2);
+        }
+    if (!c.only_last_cls) {
+        reg(p->cl_w1);
+        reg(p->cl_w2);
+    }
+    for (auto& w : p->head_w) reg(w);
+
+    // ---- workspace layout ----
+    Carver cv;
+    int ndw = 0;
+    for (int s = 0; s < 2; ++s) ndw += c.conv_depths[s];
+    p->n_descs = (int64_t)p->all_w.size() + ndw;
+    p->o_descs = cv.take(p->n_descs * sizeof(lnx_prep_desc));
+    for (OpW* w : p->all_w) {
+        const int wes = w->f32 ? 4 : 2;
+        w->off = cv.take((int64_t)w->N * w->ld * wes);
+        if (w->ld_t) w->off_t = cv.take((int64_t)w->K * w->ld_t * wes);
+    }
+    for (int s = 0; s < 2; ++s)
+        for (auto& k : p->conv[s]) k.w49 = cv.take((int64_t)49 * D[s] * 4);
+    const int64_t arena_end = cv.cur;
+    (void)arena_end;
+
+    const int64_t M0 = (int64_t)B * p->HW[0];
+    p->o_patches = cv.take(M0 * 64 * esz);
+    p->o_stem_pre = cv.take(M0 * D[0] * esz);
+    p->o_stem_mean = cv.take(M0 * 4);
+    p->o_stem_rstd = cv.take(M0 * 4);
+    int64_t maxMC = 0, maxM4C = 0;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t M = (int64_t)B * p->HW[s], C = D[s];
+        if (M * C > maxMC) maxMC = M * C;
+        if (M * 4 * C > maxM4C) maxM4C = M * 4 * C;
+        for (auto& k : p->conv[s]) {
+            k.xin = cv.take(M * C * 4);
+            k.y = cv.take(M * C * esz);
+            k.ln = cv.take(M * C * esz);
+            k.mean = cv.take(M * 4);
+            k.rstd = cv.take(M * 4);
+            k.hpre = cv.take(M * 4 * C * esz);
+            k.act = cv.take(M * 4 * C * esz);
+            k.z = cv.take(M * C * esz);
+        }
+        p->o_stage_out[s] = cv.take(M * C * 4);
+        p->down[s].ln = cv.take(M * C * esz);
+        p->down[s].mean = cv.take(M * 4);
+        p->down[s].rstd = cv.take(M * 4);
+        p->o_g[s] = cv.take(M * C * 4);
+    }
+    for (int s = 0; s < 2; ++s) {
+        const int N = s == 0 ? p->N2 : p->N3;
+        const int64_t M = (int64_t)B * N, C = D[2 + s], hid = c.mlp_hidden[s];
+        const int heads = c.rope_heads[s];
+        if (M * C > maxMC) maxMC = M * C;
+        const int64_t wide = hid > 3 * C ? hid : 3 * C;
+        if (M * wide > maxM4C) maxM4C = M * wide;
+        p->o_tok[s] = cv.take(M * C * 4);
+        for (size_t i = 0; i < p->rope[s].size(); ++i) {
+            RopeBlk& k = p->rope[s][i];
+            if (i == 0) k.xin = p->o_tok[s];  // later blocks: output buffer of the previous block (set below)
+            k.n1 = cv.take(M * C * esz);
+            k.mean1 = cv.take(M * 4);
+            k.rstd1 = cv.take(M * 4);
+            k.qkvbuf = cv.take(M * 3 * C * esz);
+            k.cos = cv.take((int64_t)p->HW[2 + s] * heads * 32 * 4);
+            k.o = cv.take(M * C * esz);
+            k.lse = cv.take((int64_t)B * heads * N * 4);
+            k.xmid = cv.take(M * C * 4);
+            k.n2 = cv.take(M * C * esz);
+            k.mean2 = cv.take(M * 4);
+            k.rstd2 = cv.take(M * 4);
+            k.hpre = cv.take(M * hid * esz);
+            k.act = cv.take(M * hid * esz);
+            const int64_t outb = cv.take(M * C * 4);
+            if (i + 1 < p->rope[s].size()) p->rope[s][i + 1].xin = outb;
+            else p->o_stage_out[2 + s] = outb;
+        }
+        p->o_g[2 + s] = cv.take(M * C * 4);
+        for (auto& k : p->meta[s]) {
+            // meta heads run in fp32 storage in both modes (M = batch rows: negligible cost)
+            k.t0 = cv.take((int64_t)B * 16 * 4);
+            k.h0 = cv.take((int64_t)B * C * 4);
+            k.x = cv.take((int64_t)B * C * 4);
+            k.m0 = cv.take(B * 4);
+            k.r0 = cv.take(B * 4);
+            k.h1 = cv.take((int64_t)B * C * 4);
+            k.n1 = cv.take((int64_t)B * C * 4);
+            k.m1 = cv.take(B * 4);
+            k.r1 = cv.take(B * 4);
+            k.h2 = cv.take((int64_t)B * C * 4);
+            k.m2 = cv.take(B * 4);
+            k.r2 = cv.take(B * 4);
+        }
+    }
+    {
+        const int64_t M2 = (int64_t)B * p->N2;
+        p->o_t1 = cv.take(M2 * D[2] * esz);
+        p->o_t1_mean = cv.take(M2 * 4);
+        p->o_t1_rstd = cv.take(M2 * 4);
+        p->o_dt1 = cv.take(M2 * D[2] * esz);
+        p->down[2].ln = cv.take((int64_t)B * p->HW[2] * D[2] * esz);
+        p->down[2].mean = cv.take((int64_t)B * p->HW[2] * 4);
+        p->down[2].rstd = cv.take((int64_t)B * p->HW[2] * 4);
+        p->o_cl_hpre = cv.take((int64_t)B * D[2] * esz);
+        p->o_cl_act = cv.take((int64_t)B * D[2] * esz);
+        p->o_cl_u = cv.take((int64_t)B * D[3] * 4);
+        p->o_cl_mean = cv.take(B * 4);
+        p->o_cl_rstd = cv.take(B * 4);
+        p->o_c1n = cv.take((int64_t)B * D[3] * 4);
+        p->o_c2n = cv.take((int64_t)B * D[3] * 4);
+        p->o_n2_mean = cv.take(B * 4);
+        p->o_n2_rstd = cv.take(B * 4);
+        p->o_agg = cv.take((int64_t)B * D[3] * 4);
+        p->o_fin_mean = cv.take(B * 4);
+        p->o_fin_rstd = cv.take(B * 4);
+        p->o_feats = cv.take((int64_t)B * D[3] * 4);
+        p->o_featsT = cv.take((int64_t)B * D[3] * esz);
+        for (int i = 0; i < 6; ++i) p->o_tail[i] = cv.take((int64_t)B * D[3] * 4);
+        for (int i = 0; i < 4; ++i) p->o_mtmp[i] = cv.take((int64_t)B * (D[3] > D[2] ? D[3] : D[2]) * 4);
+        int maxld = 8;
+        for (int t = 0; t < c.n_tasks; ++t)
+            if (p->logit_ld[t] > maxld) maxld = p->logit_ld[t];
+        p->o_dlT = cv.take((int64_t)B * maxld * esz);
+    }
+    p->o_sA = cv.take(maxM4C * esz);
+    p->o_sC = cv.take(maxMC * esz);
+    p->o_sD = cv.take(maxMC * esz);
+    {
+        int64_t gmax = 0, dmax = 0;
+        for (int s = 0; s < 2; ++s) {
+            const int N = s == 0 ? p->N2 : p->N3;
+            const int64_t gsz = (int64_t)2 * B * p->HW[2 + s] * c.rope_heads[s] * 32 * 4;
+            const int64_t dsz = (int64_t)B * c.rope_heads[s] * N * 4;
+            if (gsz > gmax) gmax = gsz;
+            if (dsz > dmax) dmax = dsz;
+        }
+        p->o_gcos = cv.take(gmax);
+        p->o_delta = cv.take(dmax);
+    }
+    p->ws_bytes = cv.cur;
+    *out = p;
+    return 0;
+}
+
+extern "C" void lnx_plan_destroy(lnx_plan* p) { delete p; }
+extern "C" int64_t lnx_plan_workspace_bytes(const lnx_plan* p) { return p ? p->ws_bytes : 0; }
+extern "C" int lnx_plan_num_params(const lnx_plan* p) { return p ? (int)p->names.size() : 0; }
+extern "C" const char* lnx_plan_param_name(const lnx_plan* p, int i) {
+    return (p && i >= 0 && i < (int)p->names.size()) ? p->names[i].c_str() : nullptr;
+}
+extern "C" int64_t lnx_plan_param_numel(const lnx_plan* p, int i) { return (p && i >= 0 && i < (int)p->numel.size()) ? p->numel[i] : -1; }
+extern "C" int lnx_plan_num_drop_calls(const lnx_plan* p) { return p ? p->n_drop : 0; }
+extern "C" int64_t lnx_plan_logits_numel(const lnx_plan* p) { return p ? p->logits_numel : 0; }
+extern "C" int64_t lnx_plan_logits_offset(const lnx_plan* p, int t) { return (p && t >= 0 && t < p->c.n_tasks) ? p->logit_off[t] : -1; }
+extern "C" int lnx_plan_logits_ld(const lnx_plan* p, int t) { return (p && t >= 0 && t < p->c.n_tasks) ? p->logit_ld[t] : -1; }
+
+extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* const* grads, void* workspace) {
+    if (!p || !params || !workspace) FAIL("lnx_plan_bind: null argument");
+    const int n = (int)p->names.size();
+    p->P.assign(params, params + n);
+    for (int i = 0; i < n; ++i)
+        if (p->P[i] == nullptr || (((uintptr_t)p->P[i]) & 3) != 0) FAIL("lnx_plan_bind: parameter %s is null or misaligned", p->names[i].c_str());
+    p->has_grads = grads != nullptr;
+    if (grads) {
+        p->G.assign(grads, grads + n);
+        for (int i = 0; i < n; ++i)
+            if (p->G[i] == nullptr) FAIL("lnx_plan_bind: gradient of %s is null", p->names[i].c_str());
+    } else {
+        p->G.assign(n, nullptr);
+    }
+    p->ws = reinterpret_cast<unsigned char*>(workspace);
+    if ((((uintptr_t)p->ws) & 255) != 0) FAIL("lnx_plan_bind: workspace must be 256-byte aligned");
+    // operand arena starts zeroed: K / N padding stays zero across refreshes
+    int64_t arena_end = 0;
+    for (OpW* w : p->all_w) {
+        const int wes = w->f32 ? 4 : 2;
+        const int64_t e1 = w->off + (int64_t)w->N * w->ld * wes;
+        const int64_t e2 = w->ld_t ? w->off_t + (int64_t)w->K * w->ld_t * wes : 0;
+        if (e1 > arena_end) arena_end = e1;
+        if (e2 > arena_end) arena_end = e2;
+    }
+    HIPRUN(hipMemset(p->ws, 0, (size_t)arena_end));
+    // descriptor tables: [T-typed weights + depthwise taps][fp32-typed weights]
+    std::vector<lnx_prep_desc> d;
+    int blk = 0;
+    auto push_w = [&](OpW* w) {
+        lnx_prep_desc e;
+        memset(&e, 0, sizeof e);
+        e.src = p->P[w->param];
+        e.dst = p->ws + w->off;
+        e.dst_t = w->ld_t ? p->ws + w->off_t : nullptr;
+        e.rows = w->N;
+        e.cols = w->K;
+        e.ld = w->ld;
+        e.ld_t = w->ld_t;
+        e.P = w->P;
+        e.mode = w->mode;
+        e.block_start = blk;
+        blk += lnx_prep_blocks(e.rows, e.ld, e.cols, e.ld_t, e.dst_t != nullptr);
+        d.push_back(e);
+    };
+    const bool split = p->esz == 2;  // in fp32 mode everything goes through one fp32 table
+    for (OpW* w : p->all_w)
+        if (!split || !w->f32) push_w(w);
+    for (int s = 0; s < 2; ++s)
+        for (auto& k : p->conv[s]) {
+            lnx_prep_desc e;
+            memset(&e, 0, sizeof e);
+            e.src = p->P[k.dww];
+            e.dst = p->ws + k.w49;
+            e.rows = p->c.dims[s];
+            e.cols = 49;
+            e.ld = 49;
+            e.mode = LNX_PREP_DW49;
+            e.block_start = blk;
+            blk += lnx_prep_blocks(e.rows, e.ld, e.cols, 0, 0);
+            d.push_back(e);
+        }
+    p->n_descs_t = (int64_t)d.size();
+    p->prep_blocks = blk;
+    blk = 0;
+    if (split)
+        for (OpW* w : p->all_w)
+            if (w->f32) push_w(w);
+    p->n_descs_f = (int64_t)d.size() - p->n_descs_t;
+    p->prep_blocks_f = blk;
+    HIPRUN(hipMemcpy(p->ws + p->o_descs, d.data(), d.size() * sizeof(lnx_prep_desc), hipMemcpyHostToDevice));
+    HIPRUN(hipDeviceSynchronize());
+    p->bound = true;
+    p->fwd_done = false;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------
+namespace {
+
+struct Ctx {
+    lnx_plan* p;
+    void* st;
+    int dt;
+    template <typename U> U* at(int64_t off) const { return p->at<U>(off); }
+    const void* wptr(const OpW& w) const { return p->ws + w.off; }
+    const void* wtptr(const OpW& w) const { return p->ws + w.off_t; }
+};
+
+lnx_gemm_args gemm_base(const Ctx& c, int M, int N, int K, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, bool out_f32) {
+    lnx_gemm_args a;
+    memset(&a, 0, sizeof a);
+    a.dtype = c.dt;
+    a.M = M;
+    a.N = N;
+    a.K = K;
+    a.A = A;
+    a.lda = lda;
+    a.W = W;
+    a.ldw = ldw;
+    a.C = C;
+    a.ldc = ldc;
+    a.out_f32 = out_f32 ? 1 : 0;
+    return a;
+}
+
+int ln_fwd(const Ctx& c, int M, int C, float eps, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi, int bi, void* y, int ydt, int64_t ldy,
+           lnx_rowmap ym, const void* add, int64_t ldadd, float* mean, float* rstd) {
+    lnx_ln_args a;
+    memset(&a, 0, sizeof a);
+    a.M = M; a.C = C; a.eps = eps;
+    a.x = x; a.x_dtype = xdt; a.ldx = ldx; a.x_map = xm;
+    a.w = c.p->P[wi]; a.b = c.p->P[bi];
+    a.y = y; a.y_dtype = ydt; a.ldy = ldy; a.y_map = ym;
+    a.add = add; a.ldadd = ldadd; a.mean = mean; a.rstd = rstd;
+    return lnx_layernorm_fwd(&a, c.st);
+}
+
+int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, lnx_rowmap dym, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi,
+           int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu) {
+    lnx_ln_bwd_args a;
+    memset(&a, 0, sizeof a);
+    a.M = M; a.C = C;
+    a.dy = dy; a.dy_dtype = dydt; a.lddy = lddy; a.dy_map = dym;
+    a.x = x; a.x_dtype = xdt; a.ldx = ldx; a.x_map = xm;
+    a.w = c.p->P[wi]; a.mean = mean; a.rstd = rstd;
+    a.gin = gin; a.ldgin = lddx;
+    a.dx = dx; a.dx_dtype = dxdt; a.lddx = lddx;
+    a.dw = c.p->G[wi]; a.db = c.p->G[bi];
+    a.relu_mask = relu ? 1 : 0;
+    return lnx_layernorm_bwd(&a, c.st);
+}
+
+int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, int wparam, int bparam, int64_t lddw, int k_store = 0) {
+    lnx_wgrad_args a;
+    memset(&a, 0, sizeof a);
+    a.dtype = c.dt;
+    a.M = M; a.N = N; a.K = K;
+    a.dY = dY; a.lddy = lddy;
+    a.A = A; a.lda = lda;
+    a.dW = c.p->G[wparam]; a.lddw = lddw;
+    a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
+    a.k_store = k_store;
+    return lnx_gemm_tn(&a, c.st);
+}
+
+const lnx_rowmap IDM = {0, 0, 0};
+
+// ------------------------------ forward pieces ------------------------------
+int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
+    lnx_plan* p = c.p;
+    ConvBlk& k = p->conv[s][i];
+    const int B = p->c.batch, H = p->H[s], W = p->W[s], C = p->c.dims[s];
+    const int M = B * H * W;
+    (void)xin;
+    lnx_dwconv_args d;
+    memset(&d, 0, sizeof d);
+    d.B = B; d.H = H; d.W = W; d.C = C;
+    d.x = c.at<float>(k.xin); d.x_dtype = LNX_F32;
+    d.w49 = c.at<float>(k.w49); d.bias = p->P[k.dwb];
+    d.y = c.at<void>(k.y); d.y_dtype = c.dt;
+    RUN(lnx_dwconv7_fwd(&d, c.st));
+    RUN(ln_fwd(c, M, C, 1e-6f, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<void>(k.ln), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean), c.at<float>(k.rstd)));
+    lnx_gemm_args g = gemm_base(c, M, 4 * C, C, c.at<void>(k.ln), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.act), 4 * C, false);
+    g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
+    RUN(lnx_gemm_nt(&g, c.st));
+    g = gemm_base(c, M, C, 4 * C, c.at<void>(k.act), 4 * C, c.wptr(k.w2), k.w2.ld, xout, C, true);
+    g.bias = p->P[k.b2]; g.c2 = c.at<void>(k.z); g.ldc2 = C;
+    g.gamma = p->P[k.gamma]; g.rowscale = p->drop_ptr(p->drop_conv[s][i]); g.rows_per_sample = H * W;
+    g.res = c.at<float>(k.xin); g.ldres = C;
+    RUN(lnx_gemm_nt(&g, c.st));
+    return 0;
+}
+
+int downsample_fwd(const Ctx& c, int i, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, float* out, int64_t ldout, lnx_rowmap om) {
+    lnx_plan* p = c.p;
+    Down& d = p->down[i];
+    const int B = p->c.batch, Hin = p->H[i], Win = p->W[i], Cin = p->c.dims[i], Cout = p->c.dims[i + 1];
+    const int Min = B * Hin * Win, Mout = Min / 4;
+    RUN(ln_fwd(c, Min, Cin, 1e-6f, x, xdt, ldx, xm, d.lnw, d.lnb, c.at<void>(d.ln), c.dt, Cin, IDM, nullptr, 0, c.at<float>(d.mean), c.at<float>(d.rstd)));
+    lnx_gemm_args g = gemm_base(c, Mout, Cout, 4 * Cin, c.at<void>(d.ln), 0, c.wptr(d.w), d.w.ld, out, ldout, true);
+    g.a_mode = LNX_ADDR_PATCH2; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
+    g.bias = p->P[d.cb]; g.c_map = om;
+    RUN(lnx_gemm_nt(&g, c.st));
+    return 0;
+}
+
+int meta_head_fwd(const Ctx& cc, int s, int m, const float* meta, int meta_width, float* tok, int N) {
+    const Ctx c{cc.p, cc.st, LNX_F32};  // fp32 storage for the M = batch meta-head chain
+    lnx_plan* p = c.p;
+    MetaHead& k = p->meta[s][m];
+    const int B = p->c.batch, C = p->c.dims[2 + s];
+    RUN(lnx_pack_meta(meta, meta_width, k.off, k.dim, c.at<void>(k.t0), c.dt, B, c.st));
+    lnx_gemm_args g = gemm_base(c, B, C, 16, c.at<void>(k.t0), 16, c.wptr(k.w0), k.w0.ld, c.at<void>(k.h0), C, false);
+    g.bias = p->P[k.b0]; g.act = LNX_ACT_RELU;
+    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h0), c.dt, C, IDM, k.lnw0, k.lnb0, c.at<void>(k.x), c.dt, C, IDM, nullptr, 0, c.at<float>(k.m0), c.at<float>(k.r0)));
+    g = gemm_base(c, B, C, C, c.at<void>(k.x), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.h1), C, false);
+    g.bias = p->P[k.b1]; g.act = LNX_ACT_RELU;
+    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h1), c.dt, C, IDM, k.nf1w, k.nf1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.m1), c.at<float>(k.r1)));
+    g = gemm_base(c, B, C, C, c.at<void>(k.n1), C, c.wptr(k.w2), k.w2.ld, c.at<void>(k.h2), C, false);
+    g.bias = p->P[k.b2]; g.act = LNX_ACT_RELU;
+    RUN(lnx_gemm_nt(&g, c.st));
+    const lnx_rowmap om = {1, N - 1, 1 + m};
+    RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h2), c.dt, C, IDM, k.nf2w, k.nf2b, tok, LNX_F32, C, om, c.at<void>(k.x), C, c.at<float>(k.m2), c.at<float>(k.r2)));
+    return 0;
+}
+
+int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
+    lnx_plan* p = c.p;
+    RopeBlk& k = p->rope[s][i];
+    const int B = p->c.batch, C = p->c.dims[2 + s], heads = p->c.rope_heads[s], hid = p->c.mlp_hidden[s];
+    const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
+    const float* xin = c.at<float>(k.xin);
+    RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1)));
+    lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
+    g.bias = p->P[k.qkvb];
+    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), c.st));
+    lnx_attn_args a;
+    memset(&a, 0, sizeof a);
+    a.dtype = c.dt; a.B = B; a.N = N; a.E = E; a.heads = heads;
+    a.qkv = c.at<void>(k.qkvbuf); a.cos_tab = c.at<float>(k.cos); a.o = c.at<void>(k.o); a.lse = c.at<float>(k.lse);
+    RUN(lnx_attn_fwd(&a, c.st));
+    g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<float>(k.xmid), C, true);
+    g.bias = p->P[k.projb]; g.rowscale = p->drop_ptr(p->drop_attn[s][i]); g.rows_per_sample = N; g.res = xin; g.ldres = C;
+    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2)));
+    g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
+    g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
+    RUN(lnx_gemm_nt(&g, c.st));
+    g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, xout, C, true);
+    g.bias = p->P[k.fc2b]; g.rowscale = p->drop_ptr(p->drop_mlp[s][i]); g.rows_per_sample = N; g.res = c.at<float>(k.xmid); g.ldres = C;
+    RUN(lnx_gemm_nt(&g, c.st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, const float* drop_scales, const unsigned char* drop_mask, float* feats,
+                                float* logits, void* stream) {
+    if (!p || !p->bound) FAIL("lnx_plan_forward: plan is not bound");
+    if (!x) FAIL("lnx_plan_forward: null input");
+    const lnx_mformer_cfg& cf = p->c;
+    if (cf.n_meta > 0 && !meta) FAIL("lnx_plan_forward: metadata components are configured but meta is NULL");
+    if (cf.n_tasks > 0 && !logits) FAIL("lnx_plan_forward: logits buffer is NULL");
+    Ctx c{p, stream, cf.dtype};
+    const int B = cf.batch;
+    const int* D = cf.dims;
+    p->last_drop = drop_scales;
+    p->mask_host.assign(p->n_drop, 0);
+    if (drop_scales && drop_mask)
+        for (int i = 0; i < p->n_drop; ++i) p->mask_host[i] = drop_mask[i];
+    p->last_meta = meta;
+
+    // 0. refresh the T-typed operand arena from the fp32 master parameters
+    RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs), (int)p->n_descs_t, (int)p->prep_blocks, cf.dtype, stream));
+    if (p->n_descs_f > 0)
+        RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs) + p->n_descs_t, (int)p->n_descs_f, (int)p->prep_blocks_f, LNX_F32, stream));
+
+    // 1. stem: 4x4/4 patchify conv as im2col + GEMM, then channels-first LN (mFormerV1.py:145-148)
+    const int M0 = B * p->HW[0];
+    RUN(lnx_im2col_stem(x, B, cf.in_chans, cf.img_h, cf.img_w, c.at<void>(p->o_patches), cf.dtype, 64, stream));
+    {
+        lnx_gemm_args g = gemm_base(c, M0, D[0], 64, c.at<void>(p->o_patches), 64, c.wptr(p->stem_w), 64, c.at<void>(p->o_stem_pre), D[0], false);
+        g.bias = p->P[p->stem_b];
+        RUN(lnx_gemm_nt(&g, stream));
+    }
+    float* first = cf.conv_depths[0] > 0 ? c.at<float>(p->conv[0][0].xin) : c.at<float>(p->o_stage_out[0]);
+    RUN(ln_fwd(c, M0, D[0], 1e-6f, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, first, LNX_F32, D[0], IDM, nullptr, 0,
+               c.at<float>(p->o_stem_mean), c.at<float>(p->o_stem_rstd)));
+
+    // 2. ConvNeXt stages + downsamplers (mFormerV1.py:427-443)
+    for (int s = 0; s < 2; ++s) {
+        const int nb = cf.conv_depths[s];
+        for (int i = 0; i < nb; ++i) {
+            float* xout = i + 1 < nb ? c.at<float>(p->conv[s][i + 1].xin) : c.at<float>(p->o_stage_out[s]);
+            RUN(conv_block_fwd(c, s, i, nullptr, xout));
+        }
+        if (s == 0) {
+            float* nxt = cf.conv_depths[1] > 0 ? c.at<float>(p->conv[1][0].xin) : c.at<float>(p->o_stage_out[1]);
+            RUN(downsample_fwd(c, 0, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, nxt, D[1], IDM));
+        } else {
+            const lnx_rowmap tm = {p->HW[2], p->E, p->E};
+            RUN(downsample_fwd(c, 1, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_tok[0]), D[2], tm));
+        }
+    }
+
+    // 3. RoPE stages (mFormerV1.py:445-510)
+    for (int s = 0; s < 2; ++s) {
+        const int N = s == 0 ? p->N2 : p->N3, C = D[2 + s];
+        float* tok = c.at<float>(p->o_tok[s]);
+        const lnx_rowmap clsmap = {1, N - 1, 0};
+        RUN(lnx_fill_rows(p->P[p->cls[s]], tok, C, clsmap, B, C, stream));
+        int mw = 0;
+        for (int m = 0; m < cf.n_meta; ++m) mw += cf.meta_dims[m];
+        for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(c, s, m, meta, mw, tok, N));
+        const int nb = cf.rope_depths[s];
+        for (int i = 0; i < nb; ++i) {
+            float* xout = i + 1 < nb ? c.at<float>(p->rope[s][i + 1].xin) : c.at<float>(p->o_stage_out[2 + s]);
+            RUN(rope_block_fwd(c, s, i, xout));
+        }
+        if (s == 0) {
+            const int M2 = B * p->N2;
+            // norm_1 over all tokens (mFormerV1.py:470); T output feeds cl_1_fc and downsample 3
+            RUN(ln_fwd(c, M2, C, 1e-5f, c.at<float>(p->o_stage_out[2]), LNX_F32, C, IDM, p->norm_w[0], p->norm_b[0], c.at<void>(p->o_t1), cf.dtype, C, IDM,
+                       nullptr, 0, c.at<float>(p->o_t1_mean), c.at<float>(p->o_t1_rstd)));
+            if (!cf.only_last_cls) {
+                // cl_1_fc = Mlp(D2, D2, D3) + LayerNorm on the CLS row (mFormerV1.py:316-321,474-476)
+                lnx_gemm_args g = gemm_base(c, B, D[2], D[2], c.at<void>(p->o_t1), (int64_t)p->N2 * D[2], c.wptr(p->cl_w1), p->cl_w1.ld, c.at<void>(p->o_cl_act),
+                                            D[2], false);
+                g.bias = p->P[p->cl_b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(p->o_cl_hpre); g.ldc2 = D[2];
+                RUN(lnx_gemm_nt(&g, stream));
+                g = gemm_base(c, B, D[3], D[2], c.at<void>(p->o_cl_act), D[2], c.wptr(p->cl_w2), p->cl_w2.ld, c.at<float>(p->o_cl_u), D[3], true);
+                g.bias = p->P[p->cl_b2];
+                RUN(lnx_gemm_nt(&g, stream));
+                RUN(ln_fwd(c, B, D[3], 1e-5f, c.at<float>(p->o_cl_u), LNX_F32, D[3], IDM, p->cl_lnw, p->cl_lnb, c.at<float>(p->o_c1n), LNX_F32, D[3], IDM, nullptr,
+                           0, c.at<float>(p->o_cl_mean), c.at<float>(p->o_cl_rstd)));
+            }
+            // patch tokens -> downsample 3 -> stage-4 tokens (mFormerV1.py:479-483)
+            const lnx_rowmap pm = {p->HW[2], p->E, p->E};
+            const lnx_rowmap tm = {p->HW[3], p->E, p->E};
+            RUN(downsample_fwd(c, 2, c.at<void>(p->o_t1), cf.dtype, C, pm, c.at<float>(p->o_tok[1]), D[3], tm));
+        }
+    }
+
+    // 4. tail: norm_2 on the CLS row, aggregate, final_norm, heads (mFormerV1.py:509-541)
+    {
+        const int C = D[3];
+        const lnx_rowmap clsrow = {1, p->N3 - 1, 0};
+        RUN(ln_fwd(c, B, C, 1e-5f, c.at<float>(p->o_stage_out[3]), LNX_F32, C, clsrow, p->norm_w[1], p->norm_b[1], c.at<float>(p->o_c2n), LNX_F32, C, IDM, nullptr,
+                   0, c.at<float>(p->o_n2_mean), c.at<float>(p->o_n2_rstd)));
+        const float* fin_in = c.at<float>(p->o_c2n);
+        if (!cf.only_last_cls) {
+            RUN(lnx_agg2_fwd(c.at<float>(p->o_c1n), c.at<float>(p->o_c2n), p->P[p->agg_w], p->P[p->agg_b], c.at<float>(p->o_agg), B, C, stream));
+            fin_in = c.at<float>(p->o_agg);
+        }
+        RUN(ln_fwd(c, B, C, 1e-5f, fin_in, LNX_F32, C, IDM, p->fin_w, p->fin_b, c.at<float>(p->o_feats), LNX_F32, C, IDM, nullptr, 0, c.at<float>(p->o_fin_mean),
+                   c.at<float>(p->o_fin_rstd)));
+        if (feats) HIPRUN(hipMemcpyAsync(feats, c.at<float>(p->o_feats), (size_t)B * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (cf.n_tasks > 0) {
+            RUN(lnx_scale_cast(c.at<float>(p->o_feats), C, IDM, nullptr, 0, c.at<void>(p->o_featsT), cf.dtype, C, B, C, stream));
+            for (int t = 0; t < cf.n_tasks; ++t) {
+                lnx_gemm_args g = gemm_base(c, B, cf.task_classes[t], C, c.at<void>(p->o_featsT), C, c.wptr(p->head_w[t]), p->head_w[t].ld,
+                                            logits + p->logit_off[t], p->logit_ld[t], true);
+                g.bias = p->P[p->head_b[t]];
+                RUN(lnx_gemm_nt(&g, stream));
+            }
+        }
+    }
+    p->fwd_done = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+namespace {
+
+int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
+    lnx_plan* p = c.p;
+    RopeBlk& k = p->rope[s][i];
+    const int B = p->c.batch, C = p->c.dims[2 + s], heads = p->c.rope_heads[s], hid = p->c.mlp_hidden[s];
+    const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
+    void* sA = c.at<void>(p->o_sA);
+    void* sC = c.at<void>(p->o_sC);
+    void* sD = c.at<void>(p->o_sD);
+    // ---- MLP branch ----
+    RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
+    RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
+    lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
+    a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = hid;
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C));
+    a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false));
+    // ---- attention branch ----
+    RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_attn[s][i]), N, sC, c.dt, C, M, C, c.st));
+    RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C));
+    a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
+    RUN(lnx_gemm_nt(&a, c.st));
+    lnx_attn_bwd_args ab;
+    memset(&ab, 0, sizeof ab);
+    ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
+    ab.qkv = c.at<void>(k.qkvbuf); ab.cos_tab = c.at<float>(k.cos); ab.o = c.at<void>(k.o); ab.lse = c.at<float>(k.lse);
+    ab.d_o = sD; ab.dqkv = sA; ab.gcos = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
+    RUN(lnx_attn_bwd(&ab, c.st));
+    RUN(lnx_rope_freqs_bwd(p->P[k.freqs], c.at<float>(p->o_gcos), B, heads, p->H[2 + s], p->W[2 + s], p->G[k.freqs], c.st));
+    RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C));
+    a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false));
+    return 0;
+}
+
+int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
+    lnx_plan* p = c.p;
+    ConvBlk& k = p->conv[s][i];
+    const int B = p->c.batch, H = p->H[s], W = p->W[s], C = p->c.dims[s];
+    const int M = B * H * W;
+    void* sA = c.at<void>(p->o_sA);
+    void* sC = c.at<void>(p->o_sC);
+    void* sD = c.at<void>(p->o_sD);
+    RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
+    RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
+    lnx_gemm_args a = gemm_base(c, M, 4 * C, C, sC, C, c.wtptr(k.w2), k.w2.ld_t, sA, 4 * C, false);
+    a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
+    a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<float>(k.mean), c.at<float>(k.rstd), nullptr, sC, c.dt, C, false));
+    lnx_dwconv_wgrad_args w;
+    memset(&w, 0, sizeof w);
+    w.B = B; w.H = H; w.W = W; w.C = C;
+    w.x = c.at<float>(k.xin); w.x_dtype = LNX_F32; w.dy = sC; w.dy_dtype = c.dt;
+    w.dw = p->G[k.dww]; w.db = p->G[k.dwb];
+    RUN(lnx_dwconv7_wgrad(&w, c.st));
+    lnx_dwconv_args d;
+    memset(&d, 0, sizeof d);
+    d.B = B; d.H = H; d.W = W; d.C = C;
+    d.x = sC; d.x_dtype = c.dt; d.w49 = c.at<float>(k.w49); d.bias = nullptr; d.flip = 1; d.res = g; d.y = g; d.y_dtype = LNX_F32;
+    RUN(lnx_dwconv7_fwd(&d, c.st));
+    return 0;
+}
+
+// gradient of downsample i: gout (fp32, rows via gmap) -> gradient wrt the LN input
+int downsample_bwd(const Ctx& c, int i, const float* gout, int64_t ldg, lnx_rowmap gmap, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, void* dx, int dxdt,
+                   int64_t lddx) {
+    lnx_plan* p = c.p;
+    Down& d = p->down[i];
+    const int B = p->c.batch, Hin = p->H[i], Win = p->W[i], Cin = p->c.dims[i], Cout = p->c.dims[i + 1];
+    const int Min = B * Hin * Win, Mout = Min / 4;
+    void* sA = c.at<void>(p->o_sA);
+    void* sC = c.at<void>(p->o_sC);
+    RUN(lnx_scale_cast(gout, ldg, gmap, nullptr, 0, sC, c.dt, Cout, Mout, Cout, c.st));
+    lnx_wgrad_args w;
+    memset(&w, 0, sizeof w);
+    w.dtype = c.dt; w.M = Mout; w.N = Cout; w.K = 4 * Cin;
+    w.dY = sC; w.lddy = Cout; w.A = c.at<void>(d.ln); w.a_mode = LNX_ADDR_PATCH2; w.Hin = Hin; w.Win = Win; w.Cin = Cin;
+    w.dW = p->G[d.w.param]; w.lddw = 4 * Cin; w.k_perm_c = Cin; w.db = p->G[d.cb];
+    RUN(lnx_gemm_tn(&w, c.st));
+    lnx_gemm_args a = gemm_base(c, Mout, 4 * Cin, Cout, sC, Cout, c.wtptr(d.w), d.w.ld_t, sA, 0, false);
+    a.c_mode = LNX_ADDR_PATCH2; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, Min, Cin, sA, c.dt, Cin, IDM, x, xdt, ldx, xm, d.lnw, d.lnb, c.at<float>(d.mean), c.at<float>(d.rstd), nullptr, dx, dxdt, lddx, false));
+    return 0;
+}
+
+int meta_head_bwd(const Ctx& cc, int s, int m, const float* g, int N) {
+    const Ctx c{cc.p, cc.st, LNX_F32};
+    lnx_plan* p = c.p;
+    MetaHead& k = p->meta[s][m];
+    const int B = p->c.batch, C = p->c.dims[2 + s];
+    float* dtok = c.at<float>(p->o_mtmp[0]);   // [B, C] fp32
+    void* t1 = c.at<void>(p->o_mtmp[1]);
+    void* t2 = c.at<void>(p->o_mtmp[2]);
+    float* dxf = c.at<float>(p->o_mtmp[3]);
+    const lnx_rowmap rm = {1, N - 1, 1 + m};
+    RUN(lnx_scale_cast(g, C, rm, nullptr, 0, dtok, LNX_F32, C, B, C, c.st));
+    RUN(ln_bwd(c, B, C, dtok, LNX_F32, C, IDM, c.at<void>(k.h2), c.dt, C, IDM, k.nf2w, k.nf2b, c.at<float>(k.m2), c.at<float>(k.r2), nullptr, t1, c.dt, C, true));
+    RUN(wgrad(c, B, C, C, t1, C, c.at<void>(k.n1), C, k.w2.param, k.b2, C));
+    lnx_gemm_args a = gemm_base(c, B, C, C, t1, C, c.wtptr(k.w2), k.w2.ld_t, t2, C, false);
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, B, C, t2, c.dt, C, IDM, c.at<void>(k.h1), c.dt, C, IDM, k.nf1w, k.nf1b, c.at<float>(k.m1), c.at<float>(k.r1), nullptr, t1, c.dt, C, true));
+    RUN(wgrad(c, B, C, C, t1, C, c.at<void>(k.x), C, k.w1.param, k.b1, C));
+    a = gemm_base(c, B, C, C, t1, C, c.wtptr(k.w1), k.w1.ld_t, dxf, C, true);
+    a.res = dtok; a.ldres = C;  // skip connection of ResNormLayer
+    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(ln_bwd(c, B, C, dxf, LNX_F32, C, IDM, c.at<void>(k.h0), c.dt, C, IDM, k.lnw0, k.lnb0, c.at<float>(k.m0), c.at<float>(k.r0), nullptr, t1, c.dt, C, true));
+    RUN(wgrad(c, B, C, 16, t1, C, c.at<void>(k.t0), 16, k.w0.param, k.b0, k.dim, k.dim));
+    return 0;
+}
+
+int tokens_bwd(const Ctx& c, int s, const float* g) {
+    lnx_plan* p = c.p;
+    const int B = p->c.batch, C = p->c.dims[2 + s], N = s == 0 ? p->N2 : p->N3;
+    const lnx_rowmap clsmap = {1, N - 1, 0};
+    RUN(lnx_colsum_rows(g, C, clsmap, p->G[p->cls[s]], B, C, c.st));
+    for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(c, s, m, g, N));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, int segment, void* stream) {
+    if (!p || !p->bound || !p->has_grads) FAIL("lnx_plan_backward: plan is not bound with gradient buffers");
+    if (!p->fwd_done) FAIL("lnx_plan_backward: no forward to differentiate");
+    if (segment < -1 || segment > 3) FAIL("lnx_plan_backward: bad segment %d", segment);
+    const lnx_mformer_cfg& cf = p->c;
+    Ctx c{p, stream, cf.dtype};
+    hipStream_t st = (hipStream_t)stream;
+    const int B = cf.batch;
+    const int* D = cf.dims;
+    const bool all = segment < 0;
+
+    if (all || segment == 0) {
+        const int C = D[3];
+        float* dfe = c.at<float>(p->o_tail[0]);  // d feats [B, C]
+        bool have = false;
+        if (dfeats) {
+            HIPRUN(hipMemcpyAsync(dfe, dfeats, (size_t)B * C * 4, hipMemcpyDeviceToDevice, st));
+            have = true;
+        }
+        if (cf.n_tasks > 0) {
+            if (!dlogits) FAIL("lnx_plan_backward: dlogits is NULL");
+            for (int t = 0; t < cf.n_tasks; ++t) {
+                const int ld = p->logit_ld[t], nc = cf.task_classes[t];
+                void* dl = c.at<void>(p->o_dlT);
+                RUN(lnx_scale_cast(dlogits + p->logit_off[t], ld, IDM, nullptr, 0, dl, cf.dtype, ld, B, ld, stream));
+                RUN(wgrad(c, B, nc, C, dl, ld, c.at<void>(p->o_featsT), C, p->head_w[t].param, p->head_b[t], C));
+                lnx_gemm_args a = gemm_base(c, B, C, ld, dl, ld, c.wtptr(p->head_w[t]), p->head_w[t].ld_t, dfe, C, true);
+                if (have) {
+                    a.res = dfe;
+                    a.ldres = C;
+                }
+                RUN(lnx_gemm_nt(&a, stream));
+                have = true;
+            }
+        }
+        if (!have) FAIL("lnx_plan_backward: neither dlogits nor dfeats given");
+        // final_norm
+        const float* fin_in = cf.only_last_cls ? c.at<float>(p->o_c2n) : c.at<float>(p->o_agg);
+        float* dfin = c.at<float>(p->o_tail[1]);
+        RUN(ln_bwd(c, B, C, dfe, LNX_F32, C, IDM, fin_in, LNX_F32, C, IDM, p->fin_w, p->fin_b, c.at<float>(p->o_fin_mean), c.at<float>(p->o_fin_rstd), nullptr, dfin,
+                   LNX_F32, C, false));
+        float* dc2n = dfin;
+        float* dc1n = nullptr;
+        if (!cf.only_last_cls) {
+            dc1n = c.at<float>(p->o_tail[2]);
+            dc2n = c.at<float>(p->o_tail[3]);
+            RUN(lnx_agg2_bwd(dfin, c.at<float>(p->o_c1n), c.at<float>(p->o_c2n), p->P[p->agg_w], dc1n, dc2n, p->G[p->agg_w], p->G[p->agg_b], B, C, stream));
+        }
+        // norm_2 acts on the CLS row only: every other row of the stage-4 output has zero gradient
+        float* g3 = c.at<float>(p->o_g[3]);
+        HIPRUN(hipMemsetAsync(g3, 0, (size_t)B * p->N3 * C * 4, st));
+        const lnx_rowmap clsrow = {1, p->N3 - 1, 0};
+        RUN(ln_bwd(c, B, C, dc2n, LNX_F32, C, IDM, c.at<float>(p->o_stage_out[3]), LNX_F32, C, clsrow, p->norm_w[1], p->norm_b[1], c.at<float>(p->o_n2_mean),
+                   c.at<float>(p->o_n2_rstd), nullptr, g3, LNX_F32, C, false));
+        for (int i = cf.rope_depths[1] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 1, i, g3));
+        RUN(tokens_bwd(c, 1, g3));
+        // downsample 3 backward into d(norm_1 output); meta/CLS rows of dt1 start at zero
+        const int C2 = D[2];
+        void* dt1 = c.at<void>(p->o_dt1);
+        HIPRUN(hipMemsetAsync(dt1, 0, (size_t)B * p->N2 * C2 * p->esz, st));
+        const lnx_rowmap gm = {p->HW[3], p->E, p->E};
+        const lnx_rowmap pm = {p->HW[2], p->E, p->E};
+        RUN(downsample_bwd(c, 2, g3, C, gm, c.at<void>(p->o_t1), cf.dtype, C2, pm, dt1, cf.dtype, C2));
+        if (!cf.only_last_cls) {
+            void* du = c.at<void>(p->o_tail[4]);
+            void* dca = c.at<void>(p->o_tail[5]);
+            RUN(ln_bwd(c, B, C, dc1n, LNX_F32, C, IDM, c.at<float>(p->o_cl_u), LNX_F32, C, IDM, p->cl_lnw, p->cl_lnb, c.at<float>(p->o_cl_mean), c.at<float>(p->o_cl_rstd),
+                       nullptr, du, cf.dtype, C, false));
+            RUN(wgrad(c, B, C, C2, du, C, c.at<void>(p->o_cl_act), C2, p->cl_w2.param, p->cl_b2, C2));
+            lnx_gemm_args a = gemm_base(c, B, C2, C, du, C, c.wtptr(p->cl_w2), p->cl_w2.ld_t, dca, C2, false);
+            a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(p->o_cl_hpre); a.ldaux = C2;
+            RUN(lnx_gemm_nt(&a, stream));
+            RUN(wgrad(c, B, C2, C2, dca, C2, c.at<void>(p->o_t1), (int64_t)p->N2 * C2, p->cl_w1.param, p->cl_b1, C2));
+            a = gemm_base(c, B, C2, C2, dca, C2, c.wtptr(p->cl_w1), p->cl_w1.ld_t, dt1, C2, false);
+            a.c_map = lnx_rowmap{1, p->N2 - 1, 0};
+            RUN(lnx_gemm_nt(&a, stream));
+        }
+        float* g2 = c.at<float>(p->o_g[2]);
+        RUN(ln_bwd(c, B * p->N2, C2, dt1, cf.dtype, C2, IDM, c.at<float>(p->o_stage_out[2]), LNX_F32, C2, IDM, p->norm_w[0], p->norm_b[0], c.at<float>(p->o_t1_mean),
+                   c.at<float>(p->o_t1_rstd), nullptr, g2, LNX_F32, C2, false));
+    }
+    if (all || segment == 1) {
+        float* g2 = c.at<float>(p->o_g[2]);
+        for (int i = cf.rope_depths[0] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 0, i, g2));
+        RUN(tokens_bwd(c, 0, g2));
+        const lnx_rowmap gm = {p->HW[2], p->E, p->E};
+        RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
+    }
+    if (all || segment == 2) {
+        float* g1 = c.at<float>(p->o_g[1]);
+        for (int i = cf.conv_depths[1] - 1; i >= 0; --i) RUN(conv_block_bwd(c, 1, i, g1));
+        RUN(downsample_bwd(c, 0, g1, D[1], IDM, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, c.at<float>(p->o_g[0]), LNX_F32, D[0]));
+    }
+    if (all || segment == 3) {
+        float* g0 = c.at<float>(p->o_g[0]);
+        for (int i = cf.conv_depths[0] - 1; i >= 0; --i) RUN(conv_block_bwd(c, 0, i, g0));
+        const int M0 = B * p->HW[0];
+        void* sC = c.at<void>(p->o_sC);
+        RUN(ln_bwd(c, M0, D[0], g0, LNX_F32, D[0], IDM, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, c.at<float>(p->o_stem_mean),
+                   c.at<float>(p->o_stem_rstd), nullptr, sC, cf.dtype, D[0], false));
+        const int kst = cf.in_chans * 16;
+        RUN(wgrad(c, M0, D[0], 64, sC, D[0], c.at<void>(p->o_patches), 64, p->stem_w.param, p->stem_b, kst, kst));
+    }
+    return 0;
+}
+
+extern "C" int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_out, int max_out) {
+    if (!p || segment < 0 || segment > 3) return -1;
+    // a parameter's gradient is final after the segment that owns it
+    int n = 0;
+    auto seg_of = [&](const std::string& nm) -> int {
+        if (nm.rfind("stages.3.", 0) == 0 || nm.rfind("head.", 0) == 0 || nm.rfind("norm_", 0) == 0 || nm.rfind("cl_1_fc", 0) == 0 ||
+            nm.rfind("aggregate", 0) == 0 || nm.rfind("final_norm", 0) == 0 || nm == "cls_token_2" || nm.rfind("downsample_layers.2", 0) == 0)
+            return 0;
+        if (nm.rfind("meta.", 0) == 0) return nm.find("head_2") != std::string::npos ? 0 : 1;
+        if (nm.rfind("stages.2.", 0) == 0 || nm == "cls_token_1" || nm.rfind("downsample_layers.1", 0) == 0) return 1;
+        if (nm.rfind("stages.1.", 0) == 0 || nm.rfind("downsample_layers.0", 0) == 0) return 2;
+        return 3;
+    };
+    for (size_t i = 0; i < p->names.size(); ++i)
+        if (seg_of(p->names[i]) == segment) {
+            if (idx_out && n < max_out) idx_out[n] = (int)i;
+            ++n;
+        }
+    return n;
+}

@@ -1,0 +1,526 @@
+"""mFormerV1 on the HIP plan: the host-side mirror of the reference's model interface.
+
+Same constructor, `forward(x, meta=None, force_checkpointing=None) -> {task: logits}`,
+`forward_features`, `.head` ModuleDict, `parameter_groups_metadata`,
+`pretrained_ckpt_handling_metadata` and *identical state_dict names and shapes* as
+linnaeus/models/mFormerV1.py:31-541 -- so checkpoints, optimizer parameter filters and
+GradNorm code written against the reference keep working -- but no torch.nn forward is
+ever executed: the sub-modules below only hold parameters.  forward()/backward() are one
+native call each into liblnx_hip.so (lnx_plan_forward / lnx_plan_backward).
+
+There is no CPU path: calling the model with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .heads import configure_classification_heads
+from .registry import register_model
+
+_DTYPES = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "float32": L.F32}
+
+
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int), ("batch", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int), ("in_chans", C.c_int),
+        ("dims", C.c_int * 4), ("conv_depths", C.c_int * 2), ("rope_depths", C.c_int * 2), ("rope_heads", C.c_int * 2),
+        ("mlp_hidden", C.c_int * 2), ("n_meta", C.c_int), ("meta_dims", C.c_int * 8), ("only_last_cls", C.c_int),
+        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16),
+    ]
+
+
+def _trunc_normal_(t: torch.Tensor, std: float = 0.02) -> torch.Tensor:
+    # reference: models/utils/initialization.py:11-36 (a=-2, b=2 absolute bounds)
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+# ---- parameter holders (never called; names/shapes = the reference's state_dict) -------
+class _LNCF(nn.Module):  # LayerNormChannelsFirst, blocks/convnext.py:21-30
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Down(nn.Module):  # ConvNeXtDownsampleLayer, blocks/convnext.py:104-110
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.norm = _LNCF(cin)
+        self.conv = nn.Conv2d(cin, cout, kernel_size=2, stride=2)
+
+
+class _ConvBlk(nn.Module):  # ConvNeXtBlock, blocks/convnext.py:54-71
+    def __init__(self, dim: int, ls_init: float, drop_path: float):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, kernel_size=7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        if ls_init <= 0:
+            raise NotImplementedError("LAYER_SCALE_INIT_VALUE <= 0 (no LayerScale) is not supported by the HIP path")
+        self.gamma = nn.Parameter(ls_init * torch.ones(dim))
+        self.drop_prob = float(drop_path)
+
+
+class _Attn(nn.Module):  # RoPE2DAttention, blocks/rope_2d_mhsa.py:292-303
+    def __init__(self, dim: int, heads: int, theta: float):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        d = dim // heads
+        # learnable mixed frequencies: per head a random direction (rope_2d_mhsa.py:76-111)
+        inv = 1.0 / (theta ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+        fx, fy = [], []
+        for _ in range(heads):
+            ang = torch.rand(1) * 2 * math.pi
+            fx.append(inv * torch.cos(ang))
+            fy.append(inv * torch.sin(ang))
+        self.freqs = nn.Parameter(torch.stack([torch.stack(fx, 0), torch.stack(fy, 0)], 0).float())
+
+
+class _Mlp(nn.Module):  # blocks/mlp.py:35-39
+    def __init__(self, cin: int, hidden: int, cout: int):
+        super().__init__()
+        self.fc1 = nn.Linear(cin, hidden)
+        self.fc2 = nn.Linear(hidden, cout)
+
+
+class _RopeBlk(nn.Module):  # RoPE2DMHSABlock, blocks/rope_2d_mhsa.py:546-574
+    def __init__(self, dim: int, heads: int, mlp_ratio: float, theta: float, drop_path: float):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn = _Attn(dim, heads, theta)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), dim)
+        self.drop_prob = float(drop_path)
+
+
+class _ResNorm(nn.Module):  # ResNormLayer, normalization/res_norm_layer.py:14-21
+    def __init__(self, dim: int):
+        super().__init__()
+        self.norm_fn1 = nn.LayerNorm(dim)
+        self.norm_fn2 = nn.LayerNorm(dim)
+        self.w1 = nn.Linear(dim, dim)
+        self.w2 = nn.Linear(dim, dim)
+
+
+class _Holder(nn.Sequential):
+    """nn.Sequential used purely as an indexed container (keeps '0.', '2.', '3.' names)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the computation runs in the native HIP plan")
+
+
+class _PlanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, meta, drop, *params):
+        feats, logits = model._plan_forward(x, meta, drop)
+        ctx.model = model
+        ctx.st = model._active
+        ctx.fwd_id = ctx.st["fwd_id"]
+        return feats, logits
+
+    @staticmethod
+    def backward(ctx, dfeats, dlogits):
+        if ctx.st["fwd_id"] != ctx.fwd_id:
+            raise L.LnxError("backward() of a forward whose saved activations were overwritten by a later forward of the same "
+                             "(batch, image-size) plan; run backward before the next forward")
+        grads = ctx.model._plan_backward(ctx.st, dfeats, dlogits)
+        return (None, None, None, None, *grads)
+
+
+@register_model("mFormerV1")
+class mFormerV1(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        M = config.MODEL
+        # BaseModel._init_common_parameters (models/base_model.py:64-96)
+        self.drop_rate = M.DROP_RATE
+        self.drop_path_rate = M.DROP_PATH_RATE
+        self.attn_drop_rate = M.get("ATTN_DROP_RATE", 0.0)
+        self.label_smoothing = M.LABEL_SMOOTHING
+        self.only_last_cls = M.ONLY_LAST_CLS
+        if self.drop_rate != 0.0 or self.attn_drop_rate != 0.0:
+            raise NotImplementedError("DROP_RATE / ATTN_DROP_RATE > 0 are not implemented in the HIP path (all shipped configs use 0.0)")
+
+        img = M.IMG_SIZE
+        self.img_size = (img, img) if isinstance(img, int) else tuple(img)
+        in_chans = M.IN_CHANS
+        if not hasattr(M, "CONVNEXT_STAGES") and "CONVNEXT_STAGES" not in M:
+            raise ValueError("mFormerV1 requires MODEL.CONVNEXT_STAGES config")
+        cs = M.CONVNEXT_STAGES
+        depths, dims = list(cs.DEPTHS), list(cs.DIMS)
+        self.convnext_ls_init = cs.get("LAYER_SCALE_INIT_VALUE", 1e-6)
+        if len(depths) != 4 or len(dims) != 4:
+            raise ValueError("CONVNEXT_STAGES depths and dims must be lists of length 4.")
+        if "ROPE_STAGES" not in M:
+            raise ValueError("mFormerV1 requires MODEL.ROPE_STAGES config")
+        rs = M.ROPE_STAGES
+        rdepths, rdims, rheads, rratio = list(rs.DEPTHS), list(rs.DIMS), list(rs.NUM_HEADS), list(rs.MLP_RATIO)
+        self.rope_theta = rs.get("ROPE_THETA", 10000.0)
+        self.rope_mixed = rs.get("ROPE_MIXED", True)
+        if len(rdepths) != 2 or len(rdims) != 2 or len(rheads) != 2 or len(rratio) != 2:
+            raise ValueError("ROPE_STAGES depths, dims, num_heads, mlp_ratio must be lists of length 2.")
+        if not self.rope_mixed:
+            raise NotImplementedError("ROPE_MIXED=False (axial) is broken in the reference (SURVEY F8) and unused by every config")
+        if rdims[0] != dims[2]:
+            raise ValueError(f"ConvNeXt dim[2] ({dims[2]}) must match RoPE dim[0] ({rdims[0]})")
+        if rdims[1] != dims[3]:
+            raise ValueError(f"ConvNeXt dim[3] ({dims[3]}) must match RoPE dim[1] ({rdims[1]})")
+        for d_, h_ in zip(rdims, rheads):
+            if d_ % h_ != 0 or d_ // h_ != 64:
+                raise NotImplementedError(f"HIP attention kernels are built for head_dim 64 (got dim {d_}, heads {h_})")
+        self.use_flash_attn = M.get("USE_FLASH_ATTN", False)  # accepted and ignored: attention is always the fused HIP kernel
+
+        # metadata components in IDX order (mFormerV1.py:94-130)
+        self.use_meta = False
+        self.meta_components: Dict[str, Dict[str, int]] = {}
+        self.meta_dims: List[int] = []
+        meta_cfg = config.DATA.get("META", None) if hasattr(config, "DATA") else None
+        if meta_cfg is not None and meta_cfg.get("ACTIVE", False) and "COMPONENTS" in meta_cfg:
+            self.use_meta = True
+            items = []
+            for name, cc in meta_cfg.COMPONENTS.items():
+                if cc.get("ENABLED", False) and cc.get("IDX", -1) >= 0:
+                    items.append((cc.get("IDX"), name, cc))
+            items.sort(key=lambda t: t[0])
+            off = 0
+            for _, name, cc in items:
+                self.meta_dims.append(cc.DIM)
+                self.meta_components[name] = {"dim": cc.DIM, "offset": off}
+                off += cc.DIM
+        self.extra_token_num = 1 + len(self.meta_dims)
+
+        total = sum(depths[:2]) + sum(rdepths)
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, total)]
+
+        self.stem = _Holder(nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4), _LNCF(dims[0]))
+        self.downsample_layers = nn.ModuleList([_Down(dims[i], dims[i + 1]) for i in range(3)])
+        self.stages = nn.ModuleList()
+        k = 0
+        for s in range(2):
+            self.stages.append(nn.ModuleList([_ConvBlk(dims[s], self.convnext_ls_init, dpr[k + i]) for i in range(depths[s])]))
+            k += depths[s]
+        for s in range(2):
+            self.stages.append(nn.ModuleList([_RopeBlk(rdims[s], rheads[s], rratio[s], self.rope_theta, dpr[k + i]) for i in range(rdepths[s])]))
+            k += rdepths[s]
+        self.norm_1 = nn.LayerNorm(rdims[0])
+        self.norm_2 = nn.LayerNorm(rdims[1])
+        self.cls_token_1 = nn.Parameter(torch.zeros(1, 1, rdims[0]))
+        self.cls_token_2 = nn.Parameter(torch.zeros(1, 1, rdims[1]))
+        _trunc_normal_(self.cls_token_1, std=0.02)
+        _trunc_normal_(self.cls_token_2, std=0.02)
+        for name, info in self.meta_components.items():
+            for s in range(2):
+                setattr(self, f"meta_{name.lower()}_head_{s + 1}",
+                        _Holder(nn.Linear(info["dim"], rdims[s]), nn.ReLU(inplace=True), nn.LayerNorm(rdims[s]), _ResNorm(rdims[s])))
+        if not self.only_last_cls:
+            self.cl_1_fc = _Holder(_Mlp(rdims[0], rdims[0], rdims[1]), nn.LayerNorm(rdims[1]))
+            self.aggregate = nn.Conv1d(in_channels=2, out_channels=1, kernel_size=1)
+        else:
+            self.cl_1_fc = None
+            self.aggregate = None
+        self.final_norm = nn.LayerNorm(rdims[1])
+
+        self.task_keys = list(config.DATA.TASK_KEYS_H5)
+        self.head = configure_classification_heads(
+            heads_config=M.CLASSIFICATION.HEADS, in_features=rdims[1], num_classes_dict=kwargs.get("num_classes"),
+            task_keys=self.task_keys, taxonomy_tree=kwargs.get("taxonomy_tree"))
+        self.apply(self._init_weights)
+
+        self._dims, self._depths, self._rdepths, self._rheads = dims, depths, rdepths, rheads
+        self._hidden = [int(rdims[s] * rratio[s]) for s in range(2)]
+        self._in_chans = in_chans
+        self._dtype_code = _DTYPES[str(kwargs.get("compute_dtype", os.environ.get("LNX_DTYPE", M.get("LNX_DTYPE", "bf16")))).lower()]
+        self.grad_mode = "autograd"  # or "direct": gradients are written straight into .grad views of one flat arena
+        self._plans: Dict[Any, Dict[str, Any]] = {}
+        self._active = None
+        self._inject_drop = None      # tests: list of per-call [B] multipliers (None entries = no drop)
+        self._segment_hook = None     # DataParallel: called after each backward segment is enqueued
+        self._grad_arena = None
+        self._grad_views: Optional[List[torch.Tensor]] = None
+        self._arena_layout = None
+        self.use_checkpoint = False   # probed by the reference's train loop; activations are always kept (no recompute path)
+
+    # reference: mFormerV1._init_weights (mFormerV1.py:351-359)
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            _trunc_normal_(m.weight, std=0.02)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    # identical contract data to mFormerV1.py:361-405
+    @property
+    def parameter_groups_metadata(self) -> Dict[str, Any]:
+        return {
+            "stages": {
+                "convnext_stages": ["stem.", "stages.0.", "stages.1.", "downsample_layers.0", "downsample_layers.1"],
+                "rope_stages": ["stages.2.", "stages.3.", "downsample_layers.2", "downsample_layers.3"],
+                "rope_freqs": ["freqs"],
+            },
+            "heads": {"classification_heads": ["head."], "meta_heads": ["meta_"]},
+            "embeddings": ["cls_token"],
+            "norm_layers": ["norm", ".bn", "LayerNorm"],
+            "aggregation": ["cl_1_fc.", "aggregate.", "final_norm."],
+        }
+
+    @property
+    def pretrained_ckpt_handling_metadata(self) -> Dict[str, Any]:
+        return {
+            "drop_buffers": [],
+            "drop_params": ["head.", "meta_", "pos_embed", "norm.", "downsample_layers."],
+            "interpolate_rel_pos_bias": False,
+            "supports_module_prefix": True,
+            "strict": False,
+        }
+
+    # ------------------------------------------------------------------ plan plumbing
+    def set_compute_dtype(self, name: str) -> None:
+        """'bf16' (production: bf16 operands, fp32 accumulate/residual) or 'fp32' (strict parity)."""
+        self._dtype_code = _DTYPES[name.lower()]
+        self._plans.clear()
+        self._active = None
+
+    @property
+    def compute_dtype(self) -> str:
+        return "bf16" if self._dtype_code == L.BF16 else "fp32"
+
+    def _task_list(self) -> List[str]:
+        return list(self.head.keys())
+
+    def _param_for(self, plan_name: str) -> torch.Tensor:
+        if plan_name.startswith("meta."):
+            _, m, rest = plan_name.split(".", 2)
+            comp = list(self.meta_components.keys())[int(m)]
+            stage, tail = rest.split(".", 1)  # head_1 / head_2
+            return self.get_parameter(f"meta_{comp.lower()}_{stage}.{tail}")
+        if plan_name.startswith("head."):
+            _, t, kind = plan_name.split(".")
+            lin = self.head[self._task_list()[int(t)]].effective_linear
+            if kind == "bias" and lin.bias is None:
+                raise NotImplementedError("heads without bias are not supported by the HIP plan")
+            return lin.weight if kind == "weight" else lin.bias
+        return self.get_parameter(plan_name)
+
+    def _get_plan(self, B: int, H: int, W: int) -> Dict[str, Any]:
+        key = (B, H, W, self._dtype_code)
+        st = self._plans.get(key)
+        lib = L.lib()
+        if st is None:
+            cfg = _Cfg()
+            cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
+            cfg.dims[:] = self._dims
+            cfg.conv_depths[:] = self._depths[:2]
+            cfg.rope_depths[:] = self._rdepths
+            cfg.rope_heads[:] = self._rheads
+            cfg.mlp_hidden[:] = self._hidden
+            cfg.n_meta = len(self.meta_dims)
+            for i, d in enumerate(self.meta_dims):
+                cfg.meta_dims[i] = d
+            cfg.only_last_cls = int(bool(self.only_last_cls))
+            tasks = self._task_list()
+            cfg.n_tasks = len(tasks)
+            for i, t in enumerate(tasks):
+                cfg.task_classes[i] = self.head[t].effective_linear.out_features
+            handle = C.c_void_p()
+            L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
+            lib.lnx_plan_workspace_bytes.restype = C.c_int64
+            lib.lnx_plan_param_name.restype = C.c_char_p
+            lib.lnx_plan_param_numel.restype = C.c_int64
+            lib.lnx_plan_logits_numel.restype = C.c_int64
+            lib.lnx_plan_logits_offset.restype = C.c_int64
+            n = lib.lnx_plan_num_params(handle)
+            names = [lib.lnx_plan_param_name(handle, i).decode() for i in range(n)]
+            params = [self._param_for(nm) for nm in names]
+            for nm, p_, i in zip(names, params, range(n)):
+                if p_.numel() != lib.lnx_plan_param_numel(handle, i):
+                    raise L.LnxError(f"parameter {nm}: module has {p_.numel()} elements, plan expects {lib.lnx_plan_param_numel(handle, i)}")
+            dev = params[0].device
+            wsb = lib.lnx_plan_workspace_bytes(handle)
+            ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+            seg_of = [3] * n
+            buf = (C.c_int * n)()
+            for seg in range(4):
+                cnt = lib.lnx_plan_segment_params(handle, seg, buf, n)
+                for j in range(cnt):
+                    seg_of[buf[j]] = seg
+            st = dict(handle=handle, names=names, params=params, ws=ws, ptrs=None, n=n, seg_of=seg_of,
+                      ndrop=lib.lnx_plan_num_drop_calls(handle), logits_numel=lib.lnx_plan_logits_numel(handle),
+                      logit_off=[lib.lnx_plan_logits_offset(handle, i) for i in range(len(tasks))],
+                      logit_ld=[lib.lnx_plan_logits_ld(handle, i) for i in range(len(tasks))], tasks=tasks, B=B, fwd_id=0)
+            self._plans[key] = st
+        self._ensure_bound(st)
+        return st
+
+    def _ensure_grad_arena(self, st) -> None:
+        """One flat fp32 gradient arena, ordered by backward segment (so each segment is one
+        contiguous all-reduce bucket); every parameter gets a view into it."""
+        params = st["params"]
+        ident = tuple(id(p) for p in params)
+        dev = params[0].device
+        if self._grad_arena is not None and self._arena_layout == (ident, dev):
+            return
+        order = sorted(range(st["n"]), key=lambda i: (st["seg_of"][i], i))
+        offs, cur, seg_bounds = {}, 0, {}
+        for i in order:
+            seg = st["seg_of"][i]
+            seg_bounds.setdefault(seg, [cur, cur])
+            offs[i] = cur
+            cur += (params[i].numel() + 3) // 4 * 4  # 16-byte aligned slices
+            seg_bounds[seg][1] = cur
+        self._grad_arena = torch.zeros(cur, dtype=torch.float32, device=dev)
+        self._grad_views = [self._grad_arena[offs[i]: offs[i] + params[i].numel()].view(params[i].shape) for i in range(st["n"])]
+        self._segment_bounds = {s: tuple(b) for s, b in seg_bounds.items()}
+        self._arena_layout = (ident, dev)
+        for s2 in self._plans.values():
+            s2["ptrs"] = None
+
+    def _ensure_bound(self, st) -> None:
+        params = st["params"]
+        if not params[0].is_cuda:
+            raise L.LnxError("mFormerV1 (linnaeus_amd) runs on the MI355X HIP kernels only: call model.cuda() first; there is no CPU fallback")
+        for p_ in params:
+            if p_.dtype != torch.float32 or not p_.is_contiguous():
+                raise L.LnxError("parameters must be contiguous fp32 (master weights); the bf16 operand copies are made by the plan")
+        self._ensure_grad_arena(st)
+        ptrs = tuple(p_.data_ptr() for p_ in params)
+        if st["ptrs"] == ptrs:
+            return
+        n = st["n"]
+        parr = (C.c_void_p * n)(*ptrs)
+        garr = (C.c_void_p * n)(*[v.data_ptr() for v in self._grad_views])
+        wsp = (st["ws"].data_ptr() + 255) // 256 * 256
+        L.check(L.lib().lnx_plan_bind(st["handle"], parr, garr, C.c_void_p(wsp)), "lnx_plan_bind")
+        st["ptrs"] = ptrs
+
+    def _draw_drop_scales(self, st, B: int, dev) -> Optional[torch.Tensor]:
+        """Per-call, per-sample DropPath multipliers floor(keep + U)/keep (blocks/drop_path.py:29-33);
+        ConvNeXt blocks draw once, RoPE blocks twice (attn and mlp branches)."""
+        probs: List[float] = []
+        for s in range(2):
+            probs += [blk.drop_prob for blk in self.stages[s]]
+        for s in range(2, 4):
+            for blk in self.stages[s]:
+                probs += [blk.drop_prob, blk.drop_prob]
+        assert len(probs) == st["ndrop"]
+        if self._inject_drop is not None:
+            inj = list(self._inject_drop)
+            assert len(inj) == len(probs)
+            mask = bytes(int(v is not None) for v in inj)
+            if not any(mask):
+                return None
+            rows = [v.to(dev, torch.float32) if v is not None else torch.ones(B, device=dev) for v in inj]
+            st["drop_mask"] = mask
+            return torch.stack(rows, 0).contiguous()
+        if not self.training or all(p == 0.0 for p in probs):
+            return None
+        keep = torch.tensor([1.0 - p for p in probs], device=dev).unsqueeze(1)
+        scales = torch.floor(keep + torch.rand(len(probs), B, device=dev)) / keep
+        st["drop_mask"] = bytes(int(p > 0.0) for p in probs)
+        return scales.contiguous()
+
+    def _plan_forward(self, x, meta, drop):
+        st = self._active
+        B = x.shape[0]
+        feats = torch.empty(B, self._dims[3], device=x.device, dtype=torch.float32)
+        logits = torch.zeros(max(st["logits_numel"], 1), device=x.device, dtype=torch.float32)
+        mask = st.get("drop_mask") if drop is not None else None
+        L.check(L.lib().lnx_plan_forward(
+            st["handle"], C.c_void_p(x.data_ptr()), C.c_void_p(meta.data_ptr()) if meta is not None else None,
+            C.c_void_p(drop.data_ptr()) if drop is not None else None, mask, C.c_void_p(feats.data_ptr()),
+            C.c_void_p(logits.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lnx_plan_forward")
+        st["saved_inputs"] = (x, meta, drop)  # keep alive until backward
+        st["fwd_id"] = st.get("fwd_id", 0) + 1
+        return feats, logits
+
+    def _plan_backward(self, st, dfeats, dlogits):
+        direct = self.grad_mode == "direct"
+        params = st["params"]
+        fresh = (not direct) or any(p_.grad is None for p_ in params)
+        if fresh:
+            self._grad_arena.zero_()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dl = dlogits.contiguous() if dlogits is not None else None
+        df = dfeats.contiguous() if dfeats is not None else None
+        if st["logits_numel"] == 0:
+            dl = None
+        lib = L.lib()
+        if self._segment_hook is None:
+            L.check(lib.lnx_plan_backward(st["handle"], C.c_void_p(dl.data_ptr()) if dl is not None else None,
+                                          C.c_void_p(df.data_ptr()) if df is not None else None, -1, stream), "lnx_plan_backward")
+        else:
+            for seg in range(4):
+                L.check(lib.lnx_plan_backward(st["handle"], C.c_void_p(dl.data_ptr()) if dl is not None else None,
+                                              C.c_void_p(df.data_ptr()) if df is not None else None, seg, stream), "lnx_plan_backward")
+                self._segment_hook(seg)
+        if direct:
+            for p_, v in zip(params, self._grad_views):
+                if p_.grad is None:
+                    p_.grad = v
+                elif p_.grad.data_ptr() != v.data_ptr():
+                    p_.grad.add_(v)
+            return [None] * len(params)
+        # autograd mode: hand out copies, so .grad never aliases the arena the next backward zeroes
+        return [v.clone() for v in self._grad_views]
+
+    # ------------------------------------------------------------------ public forward
+    def _run(self, x: torch.Tensor, meta: Optional[torch.Tensor]):
+        if not x.is_cuda:
+            raise L.LnxError("mFormerV1 (linnaeus_amd) has no CPU path: inputs must be on the GPU")
+        if x.dim() != 4 or x.shape[1] != self._in_chans:
+            raise ValueError(f"expected input [B, {self._in_chans}, H, W], got {tuple(x.shape)}")
+        x = x.float().contiguous()
+        B, _, H, W = x.shape
+        if self.use_meta and self.meta_dims:
+            if meta is None:
+                # the reference asserts N == H*W + extra_token_num inside attention (rope_2d_mhsa.py:427-429)
+                raise AssertionError("metadata components are configured but meta is None")
+            if meta.shape[-1] != sum(self.meta_dims):
+                raise ValueError(f"meta must be [B, {sum(self.meta_dims)}] (components in IDX order), got {tuple(meta.shape)}")
+            meta = meta.float().contiguous()
+        else:
+            meta = None
+        st = self._get_plan(B, H, W)
+        self._active = st
+        drop = self._draw_drop_scales(st, B, x.device)
+        if torch.is_grad_enabled() and any(p_.requires_grad for p_ in st["params"]):
+            feats, logits = _PlanFn.apply(self, x, meta, drop, *st["params"])
+        else:
+            feats, logits = self._plan_forward(x, meta, drop)
+        return st, feats, logits
+
+    def forward_features(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> torch.Tensor:
+        """[B, D3] features after final_norm (mFormerV1.py:407-529).  `force_checkpointing` is accepted
+        for interface parity; the plan keeps activations in its workspace instead of recomputing."""
+        return self._run(x, meta)[1]
+
+    def forward(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        st, feats, logits = self._run(x, meta)
+        B = x.shape[0]
+        out = {}
+        for i, t in enumerate(st["tasks"]):
+            ld = st["logit_ld"][i]
+            nc = self.head[t].effective_linear.out_features
+            out[t] = logits[st["logit_off"][i]: st["logit_off"][i] + B * ld].view(B, ld)[:, :nc]
+        self._last_feats = feats
+        return out
+
+    def __del__(self):
+        try:
+            lib = L.lib()
+            for st in self._plans.values():
+                lib.lnx_plan_destroy(st["handle"])
+        except Exception:
+            pass

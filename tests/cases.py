@@ -34,3 +34,64 @@ def load_case(name, golden_dir):
             k = f"drop_scale_{i}"
             drops.append(torch.from_numpy(z[k]) if k in z.files else None)
     return spec, z, sd, x, meta, drops
+
+
+def make_config(spec, img, head_type="Linear", drop_path_rate=None):
+    """linnaeus_amd config for a Spec (mirrors apply_spec() of the golden generator)."""
+    from linnaeus_amd import default_config
+
+    cfg = default_config()
+    cfg.MODEL.IMG_SIZE = img
+    cfg.MODEL.CONVNEXT_STAGES.DIMS = list(spec.conv_dims)
+    cfg.MODEL.CONVNEXT_STAGES.DEPTHS = [spec.conv_depths[0], spec.conv_depths[1], 9, 3]
+    cfg.MODEL.ROPE_STAGES.DIMS = list(spec.rope_dims)
+    cfg.MODEL.ROPE_STAGES.DEPTHS = list(spec.rope_depths)
+    cfg.MODEL.ROPE_STAGES.NUM_HEADS = list(spec.rope_heads)
+    cfg.MODEL.ROPE_STAGES.MLP_RATIO = list(spec.mlp_ratio)
+    cfg.MODEL.ONLY_LAST_CLS = spec.only_last_cls
+    cfg.MODEL.DROP_PATH_RATE = spec.drop_path_rate if drop_path_rate is None else drop_path_rate
+    names = [n for n, _ in spec.meta]
+    cfg.DATA.META.ACTIVE = bool(names)
+    for comp in ("TEMPORAL", "SPATIAL", "ELEVATION"):
+        cfg.DATA.META.COMPONENTS[comp].ENABLED = comp in names
+    tasks = [t for t, _ in spec.heads]
+    cfg.DATA.TASK_KEYS_H5 = tasks
+    if head_type == "Linear":
+        cfg.MODEL.CLASSIFICATION.HEADS = {t: {"TYPE": "Linear"} for t in tasks}
+    else:
+        cfg.MODEL.CLASSIFICATION.HEADS = {t: {"TYPE": head_type, "ROUTING_STRATEGY": "soft", "TEMPERATURE": 1.0, "USE_BIAS": True} for t in tasks}
+    return cfg
+
+
+class TinyTree:
+    """Stand-in with the one method the heads use (TaxonomyTree.build_hierarchy_matrices,
+    utils/taxonomy/taxonomy_tree.py:384-405): matrices keyed "{parent}_{child}"."""
+
+    def __init__(self, hierarchy_map, task_keys, num_classes):
+        self.hierarchy_map, self.task_keys, self.num_classes = hierarchy_map, task_keys, num_classes
+
+    def build_hierarchy_matrices(self):
+        import torch
+
+        out = {}
+        for i in range(len(self.task_keys) - 1):
+            child, parent = self.task_keys[i], self.task_keys[i + 1]
+            m = torch.zeros(self.num_classes[parent], self.num_classes[child])
+            for c, p_ in self.hierarchy_map.get(child, {}).items():
+                m[p_, c] = 1.0
+            out[f"{parent}_{child}"] = m
+        return out
+
+
+def model_state_dict_from_oracle(model, sd):
+    """Map the oracle's Linear-layout state dict onto whatever head layout the model has."""
+    out = {}
+    for k, v in model.state_dict().items():
+        parts = k.split(".")
+        if parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers":
+            out[k] = sd[f"head.{parts[3]}.fc.{parts[4]}"]
+        elif "hmatrix" in k:
+            out[k] = v
+        else:
+            out[k] = sd[k]
+    return out

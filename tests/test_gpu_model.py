@@ -1,0 +1,161 @@
+"""End-to-end parity of the HIP mFormerV1 (through build_model() and the C-ABI plan) against
+the golden fixtures produced by the reference, and against the CPU oracle's gradients.
+
+Tolerances (stated per BASELINE.md section 4):
+  fp32 mode : logits rtol 1e-4 / atol 5e-5 vs the reference, class-index argmax EXACT
+  bf16 mode : max-abs logit error reported and bounded; argmax exact wherever the
+              reference's top-1/top-2 margin exceeds 4x the observed error
+"""
+import numpy as np
+import pytest
+import torch
+
+from linnaeus_amd import build_model
+from oracle import mformer_oracle as O
+from tests.cases import CASES, TinyTree, load_case, make_config, model_state_dict_from_oracle
+
+pytestmark = pytest.mark.gpu
+IMG = {"tiny_a": 64, "tiny_b": 96, "tiny_c": 64, "tiny_dp": 64, "sm": 224}
+
+
+def build(name, spec, sd, dtype):
+    kw = {"num_classes": {t: c for t, c in spec.heads}}
+    head_type = "Linear"
+    if name == "tiny_c":
+        head_type = "ConditionalClassifier"
+        kw["taxonomy_tree"] = TinyTree({"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}},
+                                       [t for t, _ in spec.heads], {t: c for t, c in spec.heads})
+    model = build_model(make_config(spec, IMG[name], head_type), **kw)
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    return model
+
+
+def run(model, x, meta, drops, train):
+    model.train(train)
+    model._inject_drop = drops
+    return model(x.cuda(), meta.cuda() if meta is not None else None)
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_dp", "sm"])
+def test_forward_fp32_matches_reference(name, golden_dir):
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    model = build(name, spec, sd, "fp32")
+    with torch.no_grad():
+        out = run(model, x, meta, drops, train=drops is not None)
+        feats = model._last_feats
+    np.testing.assert_allclose(feats.cpu().numpy(), z["feats"], rtol=1e-4, atol=5e-5)
+    for task, _ in spec.heads:
+        ref = z["logits_" + task]
+        got = out[task].cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=5e-5, err_msg=task)
+        assert (got.argmax(-1) == ref.argmax(-1)).all(), f"argmax differs for {task}"
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_dp", "sm"])
+def test_forward_bf16_close_to_reference(name, golden_dir):
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    model = build(name, spec, sd, "bf16")
+    with torch.no_grad():
+        out = run(model, x, meta, drops, train=drops is not None)
+    worst = 0.0
+    for task, _ in spec.heads:
+        ref = z["logits_" + task]
+        got = out[task].float().cpu().numpy()
+        err = np.abs(got - ref).max()
+        worst = max(worst, err)
+        scale = np.abs(ref).max()
+        assert err <= 0.04 * max(scale, 1.0), f"{task}: bf16 max-abs error {err:.4f} vs logit scale {scale:.3f}"
+        srt = np.sort(ref, -1)
+        margin = srt[:, -1] - srt[:, -2]
+        safe = margin > 4 * err
+        assert (got.argmax(-1)[safe] == ref.argmax(-1)[safe]).all()
+    print(f"[{name}] bf16 max-abs logit error vs reference fp32: {worst:.5f}")
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c", "tiny_dp"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_backward_matches_oracle(name, dtype, golden_dir):
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    model = build(name, spec, sd, dtype)
+    out = run(model, x, meta, drops, train=True)
+    loss = O.probe_loss({k: v for k, v in out.items()})
+    if dtype == "fp32":
+        assert abs(loss.item() - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    # oracle gradients on the CPU
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    O.probe_loss(O.forward(osd, spec, x, meta, drops)).backward()
+    names = [str(n) for n in z["grad_names"]]
+    got = {}
+    for k, p_ in model.named_parameters():
+        parts = k.split(".")
+        ck = f"head.{parts[3]}.fc.{parts[4]}" if (parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers") else k
+        got[ck] = p_.grad
+    assert sorted(got) == names
+    # fp32: tight per-parameter bound.  bf16: operands/activations are rounded to 8 mantissa bits, so
+    # per-parameter relative error is bounded loosely (25 %: the batch-2 meta-head chains flip ReLU masks) and the whole gradient tightly (5 %).
+    rel_tol = 2e-3 if dtype == "fp32" else 0.25
+    bad = []
+    tot_err = tot_ref = 0.0
+    for i, k in enumerate(names):
+        g = got[k].float().cpu()
+        ref = osd[k].grad
+        denom = ref.norm().item()
+        err = (g - ref).norm().item()
+        tot_err += err * err
+        tot_ref += denom * denom
+        if dtype == "fp32":  # the fixture pins the oracle; check the GPU against the reference's own numbers too
+            assert abs(g.double().norm().item() - z["grad_norms"][i]) <= 5e-3 * max(z["grad_norms"][i], 1e-3), k
+        if err > rel_tol * max(denom, 1e-3 * (1 if dtype == "fp32" else 10)):
+            bad.append((k, err, denom))
+    assert not bad, bad[:8]
+    glob = (tot_err / tot_ref) ** 0.5
+    print(f"[{name}/{dtype}] global relative gradient error vs oracle: {glob:.2e}")
+    assert glob <= (1e-3 if dtype == "fp32" else 5e-2)
+
+
+def test_sm_backward_grad_norms_fp32(golden_dir):
+    spec, z, sd, x, meta, drops = load_case("sm", golden_dir)
+    model = build("sm", spec, sd, "fp32")
+    out = run(model, x, meta, None, train=True)
+    O.probe_loss(out).backward()
+    names = [str(n) for n in z["grad_names"]]
+    got = dict(model.named_parameters())
+    for i, k in enumerate(names):
+        n = got[k].grad.double().norm().item()
+        assert abs(n - z["grad_norms"][i]) <= 5e-3 * max(z["grad_norms"][i], 1e-3), (k, n, z["grad_norms"][i])
+        np.testing.assert_allclose(got[k].grad.reshape(-1)[:8].cpu().numpy(), z["gradslice_" + k], rtol=2e-2, atol=2e-5, err_msg=k)
+
+
+def test_state_dict_contract_and_errors():
+    spec = CASES["tiny_a"]
+    model = build_model(make_config(spec, 64), num_classes={t: c for t, c in spec.heads})
+    shapes = O.param_shapes(spec)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+    with pytest.raises(Exception, match="no CPU path|GPU"):
+        model(torch.zeros(1, 3, 64, 64), torch.zeros(1, 5))
+    model = model.cuda()
+    with pytest.raises(AssertionError):
+        model(torch.zeros(1, 3, 64, 64, device="cuda"), None)  # meta configured but missing
+
+
+def test_direct_grad_mode_accumulates():
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 1)
+    model = build("tiny_a", spec, sd, "fp32")
+    model.grad_mode = "direct"
+    x, meta = O.seeded_inputs(spec, 2, 64, 5)
+    model.train()
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()
+    g1 = {k: p_.grad.clone() for k, p_ in model.named_parameters()}
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()  # accumulate (no zero_grad)
+    for k, p_ in model.named_parameters():
+        torch.testing.assert_close(p_.grad, 2 * g1[k], rtol=1e-4, atol=1e-6)
+    model.zero_grad(set_to_none=True)
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()
+    for k, p_ in model.named_parameters():
+        torch.testing.assert_close(p_.grad, g1[k], rtol=1e-4, atol=1e-6)
