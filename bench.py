@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one mFormerV1_sm training step (forward + loss + backward
+[+ gradient all-reduce] + AdamW) on synthetic 3x224x224 batches, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` is the whole-job images/sec with inputs resident in HBM.
+Beside it: `roofline` for the dominant kernel class (the MFMA forward/data-gradient GEMM),
+measured live with HIP events on the launch stream in extra, untimed steps; and
+`cpu_baseline`, the CPU oracle (oracle/, a port of the reference's arithmetic) timed on this
+host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+TASKS = (("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20))
+FLOP_PER_IMG = 25.79e9          # fwd+bwd FLOPs per image, mFormerV1_sm @224
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T0 = time.perf_counter()
+
+
+def host_cores():
+    """CPU threads this process may actually use: min(affinity, cgroup quota), capped by LNX_CPU_CORES
+    (default 16, the GPU box's per-GPU CPU share) -- os.cpu_count() reports the whole host."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LNX_CPU_CORES", "16"))))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--arch", default="sm")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--profile-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def make_model(args):
+    from linnaeus_amd import arch_config, build_model
+
+    cfg = arch_config(args.arch, args.img)
+    cfg.DATA.TASK_KEYS_H5 = [t for t, _ in TASKS]
+    cfg.MODEL.CLASSIFICATION.HEADS = {t: {"TYPE": "Linear"} for t, _ in TASKS}
+    cfg.TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS = False
+    model = build_model(cfg, num_classes={t: c for t, c in TASKS})
+    return cfg, model
+
+
+def cpu_baseline(args, cfg):
+    """Time the CPU oracle (fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import mformer_oracle as O
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    spec = O.Spec(heads=TASKS, drop_path_rate=0.0)
+    sd = {k: v.requires_grad_(True) for k, v in O.seeded_state_dict(O.param_shapes(spec), 1).items()}
+    g = torch.Generator().manual_seed(42)
+    B = args.cpu_batch
+    x = torch.rand(B, 3, args.img, args.img, generator=g)
+    meta = torch.rand(B, 5, generator=g)
+    tg = {t: torch.randint(1, c, (B,), generator=g) for t, c in TASKS}
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        out = O.forward(sd, spec, x, meta)
+        loss = sum(F.cross_entropy(out[t], tg[t]) for t, _ in TASKS)
+        loss.backward()
+
+    step()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 fwd+loss+bwd, batch {B}, 1 warm-up + {n} timed steps, {args.img}x{args.img}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(42 + rank)
+    cfg, model = make_model(args)
+    model = model.to(dev)
+    model.set_compute_dtype(args.dtype)
+    model.train()
+    net = model
+    if world > 1:
+        from linnaeus_amd.ddp import DataParallel
+
+        net = DataParallel(model)
+    else:
+        model.grad_mode = "direct"
+    opt = None if args.no_optim else torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    x = torch.rand(B, 3, args.img, args.img, device=dev, generator=g)
+    meta = torch.rand(B, 5, device=dev, generator=g)
+    tg = {t: torch.randint(1, c, (B,), device=dev, generator=g) for t, c in TASKS}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = net(x, meta)
+        loss = out[TASKS[0][0]].new_zeros(())
+        for t, _ in TASKS:
+            loss = loss + F.cross_entropy(out[t], tg[t])
+        loss.backward()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    log(f"model on {dev}, batch {B}/GPU; warm-up {args.warmup} steps")
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    log("warm-up done; timing")
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    last_loss = float(loss.item())
+    log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
+    ips = world * B * args.steps / dt
+
+    # ---- live per-kernel-class timing (untimed extra steps, rank 0 only) ----
+    roofline, kernels = None, {}
+    if rank == 0 and args.profile_steps > 0:
+        from linnaeus_amd import _lib as L
+
+        lib = L.lib()
+        st = model._active
+        NC = 6
+        L.check(lib.lnx_plan_profile_begin(st["handle"]), "profile_begin")
+        hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
+        for _ in range(args.profile_steps):
+            model.zero_grad(set_to_none=True)
+            out = model(x, meta)
+            sum(F.cross_entropy(out[t], tg[t]) for t, _ in TASKS).backward()
+        model._segment_hook = hook
+        ms = (C.c_double * NC)()
+        work = (C.c_double * NC)()
+        cnt = (C.c_int * NC)()
+        L.check(lib.lnx_plan_profile_end(st["handle"], ms, work, cnt), "profile_end")
+        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad"]
+        for i, nm in enumerate(names):
+            if cnt[i] == 0:
+                continue
+            per = {"ms_per_step": round(ms[i] / args.profile_steps, 4), "launches_per_step": cnt[i] // args.profile_steps,
+                   "avg_launch_us": round(ms[i] * 1e3 / cnt[i], 2)}
+            if i < 4:
+                per["tflops"] = round(work[i] / (ms[i] * 1e-3) / 1e12, 2)
+            else:
+                per["gbs"] = round(work[i] / (ms[i] * 1e-3) / 1e9, 1)
+            kernels[nm] = per
+        a = work[0] / (ms[0] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_kernel<{args.dtype}> (forward + data-gradient GEMMs, fused epilogues)",
+                    "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
+                    "traffic": None, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
+                    "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
+                    "flops_per_step": work[0] / args.profile_steps}
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        log("kernel profile done; timing the CPU oracle")
+        cpu = cpu_baseline(args, cfg)
+        log("cpu baseline done")
+    line = {
+        "metric": "images/sec (train fwd+bwd) mFormerV1_sm 3x224x224",
+        "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"mFormerV1_{args.arch} train step (forward + 4-task CE loss + backward"
+                               f"{' + RCCL gradient all-reduce' if world > 1 else ''}{'' if args.no_optim else ' + fused AdamW'}), "
+                               f"{args.dtype} operands / fp32 accumulate+residual, batch {B}/GPU, 3x{args.img}x{args.img} synthetic, "
+                               "DropPath 0.2, gradient checkpointing off",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "tasks": dict(TASKS)},
+        "step_mfma_roofline_frac": round(ips / world * FLOP_PER_IMG / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "loss": round(last_loss, 4),
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+    }
+    print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

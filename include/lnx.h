@@ -323,7 +323,15 @@ int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, const float
  * stage 2, ConvNeXt stage 1 + stem}, to be called in that order (lets the caller start the
  * gradient all-reduce of a finished segment while the next one runs). */
 int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, int segment, void* stream);
-/* first / one-past-last parameter index whose gradient is final after `segment` */
+/* Live per-kernel-class timing with HIP events on the launch stream (used by bench.py for the
+ * roofline line; adds event records around the timed launches, so never leave it on in a timed
+ * region).  Classes: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd (both kernels),
+ * 4 depthwise conv fwd / data-grad, 5 depthwise conv weight-grad.  work = FLOPs for 0-3,
+ * algorithmic HBM bytes for 4-5. */
+#define LNX_PROFILE_CLASSES 6
+int lnx_plan_profile_begin(lnx_plan* p);
+int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
+/* indices of the parameters whose gradient is final after `segment`; returns their count */
 int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_out, int max_out);
 
 #ifdef __cplusplus

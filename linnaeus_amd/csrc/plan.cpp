@@ -121,6 +121,12 @@ struct lnx_plan {
     const unsigned char* last_mask = nullptr;
     std::vector<unsigned char> mask_host;
     const float* last_meta = nullptr;
+    // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
+    bool profile = false;
+    struct Span { hipEvent_t e0, e1; int cls; double work; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
 
     template <typename U> U* at(int64_t off) const { return reinterpret_cast<U*>(ws + off); }
     const float* drop_ptr(int call) const {
@@ -682,6 +688,41 @@ struct Ctx {
     const void* wtptr(const OpW& w) const { return p->ws + w.off_t; }
 };
 
+// kernel classes for the profile: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd, 4 dwconv (fwd/dgrad), 5 dwconv wgrad
+hipEvent_t take_event(lnx_plan* p) {
+    if (p->ev_used == p->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        p->ev_pool.push_back(e);
+    }
+    return p->ev_pool[p->ev_used++];
+}
+struct Timed {
+    lnx_plan* p;
+    hipStream_t st;
+    bool on;
+    lnx_plan::Span sp;
+    Timed(const Ctx& c, int cls, double work) : p(c.p), st((hipStream_t)c.st), on(c.p->profile) {
+        if (on) {
+            sp.cls = cls;
+            sp.work = work;
+            sp.e0 = take_event(p);
+            sp.e1 = take_event(p);
+            (void)hipEventRecord(sp.e0, st);
+        }
+    }
+    ~Timed() {
+        if (on) {
+            (void)hipEventRecord(sp.e1, st);
+            p->spans.push_back(sp);
+        }
+    }
+};
+int gemm_nt_t(const Ctx& c, const lnx_gemm_args* a) {
+    Timed t(c, 0, 2.0 * a->M * a->N * a->K);
+    return lnx_gemm_nt(a, c.st);
+}
+
 lnx_gemm_args gemm_base(const Ctx& c, int M, int N, int K, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, bool out_f32) {
     lnx_gemm_args a;
     memset(&a, 0, sizeof a);
@@ -736,10 +777,13 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
     a.dW = c.p->G[wparam]; a.lddw = lddw;
     a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
     a.k_store = k_store;
+    Timed t(c, 1, 2.0 * M * N * K);
     return lnx_gemm_tn(&a, c.st);
 }
 
 const lnx_rowmap IDM = {0, 0, 0};
+
+
 
 // ------------------------------ forward pieces ------------------------------
 int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
@@ -754,16 +798,19 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
     d.x = c.at<float>(k.xin); d.x_dtype = LNX_F32;
     d.w49 = c.at<float>(k.w49); d.bias = p->P[k.dwb];
     d.y = c.at<void>(k.y); d.y_dtype = c.dt;
-    RUN(lnx_dwconv7_fwd(&d, c.st));
+    {
+        Timed t(c, 4, (double)M * C * (4 + p->esz));  // bytes: read fp32 x, write T y
+        RUN(lnx_dwconv7_fwd(&d, c.st));
+    }
     RUN(ln_fwd(c, M, C, 1e-6f, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<void>(k.ln), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean), c.at<float>(k.rstd)));
     lnx_gemm_args g = gemm_base(c, M, 4 * C, C, c.at<void>(k.ln), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.act), 4 * C, false);
     g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     g = gemm_base(c, M, C, 4 * C, c.at<void>(k.act), 4 * C, c.wptr(k.w2), k.w2.ld, xout, C, true);
     g.bias = p->P[k.b2]; g.c2 = c.at<void>(k.z); g.ldc2 = C;
     g.gamma = p->P[k.gamma]; g.rowscale = p->drop_ptr(p->drop_conv[s][i]); g.rows_per_sample = H * W;
     g.res = c.at<float>(k.xin); g.ldres = C;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     return 0;
 }
 
@@ -776,7 +823,7 @@ int downsample_fwd(const Ctx& c, int i, const void* x, int xdt, int64_t ldx, lnx
     lnx_gemm_args g = gemm_base(c, Mout, Cout, 4 * Cin, c.at<void>(d.ln), 0, c.wptr(d.w), d.w.ld, out, ldout, true);
     g.a_mode = LNX_ADDR_PATCH2; g.Hin = Hin; g.Win = Win; g.Cin = Cin;
     g.bias = p->P[d.cb]; g.c_map = om;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     return 0;
 }
 
@@ -788,15 +835,15 @@ int meta_head_fwd(const Ctx& cc, int s, int m, const float* meta, int meta_width
     RUN(lnx_pack_meta(meta, meta_width, k.off, k.dim, c.at<void>(k.t0), c.dt, B, c.st));
     lnx_gemm_args g = gemm_base(c, B, C, 16, c.at<void>(k.t0), 16, c.wptr(k.w0), k.w0.ld, c.at<void>(k.h0), C, false);
     g.bias = p->P[k.b0]; g.act = LNX_ACT_RELU;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h0), c.dt, C, IDM, k.lnw0, k.lnb0, c.at<void>(k.x), c.dt, C, IDM, nullptr, 0, c.at<float>(k.m0), c.at<float>(k.r0)));
     g = gemm_base(c, B, C, C, c.at<void>(k.x), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.h1), C, false);
     g.bias = p->P[k.b1]; g.act = LNX_ACT_RELU;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h1), c.dt, C, IDM, k.nf1w, k.nf1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.m1), c.at<float>(k.r1)));
     g = gemm_base(c, B, C, C, c.at<void>(k.n1), C, c.wptr(k.w2), k.w2.ld, c.at<void>(k.h2), C, false);
     g.bias = p->P[k.b2]; g.act = LNX_ACT_RELU;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     const lnx_rowmap om = {1, N - 1, 1 + m};
     RUN(ln_fwd(c, B, C, 1e-5f, c.at<void>(k.h2), c.dt, C, IDM, k.nf2w, k.nf2b, tok, LNX_F32, C, om, c.at<void>(k.x), C, c.at<float>(k.m2), c.at<float>(k.r2)));
     return 0;
@@ -811,23 +858,26 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1)));
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), c.st));
     lnx_attn_args a;
     memset(&a, 0, sizeof a);
     a.dtype = c.dt; a.B = B; a.N = N; a.E = E; a.heads = heads;
     a.qkv = c.at<void>(k.qkvbuf); a.cos_tab = c.at<float>(k.cos); a.o = c.at<void>(k.o); a.lse = c.at<float>(k.lse);
-    RUN(lnx_attn_fwd(&a, c.st));
+    {
+        Timed t(c, 2, 4.0 * B * heads * (double)N * N * 64);
+        RUN(lnx_attn_fwd(&a, c.st));
+    }
     g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<float>(k.xmid), C, true);
     g.bias = p->P[k.projb]; g.rowscale = p->drop_ptr(p->drop_attn[s][i]); g.rows_per_sample = N; g.res = xin; g.ldres = C;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2)));
     g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
     g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, xout, C, true);
     g.bias = p->P[k.fc2b]; g.rowscale = p->drop_ptr(p->drop_mlp[s][i]); g.rows_per_sample = N; g.res = c.at<float>(k.xmid); g.ldres = C;
-    RUN(lnx_gemm_nt(&g, c.st));
+    RUN(gemm_nt_t(c, &g));
     return 0;
 }
 
@@ -860,7 +910,7 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
     {
         lnx_gemm_args g = gemm_base(c, M0, D[0], 64, c.at<void>(p->o_patches), 64, c.wptr(p->stem_w), 64, c.at<void>(p->o_stem_pre), D[0], false);
         g.bias = p->P[p->stem_b];
-        RUN(lnx_gemm_nt(&g, stream));
+        RUN(gemm_nt_t(c, &g));
     }
     float* first = cf.conv_depths[0] > 0 ? c.at<float>(p->conv[0][0].xin) : c.at<float>(p->o_stage_out[0]);
     RUN(ln_fwd(c, M0, D[0], 1e-6f, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, first, LNX_F32, D[0], IDM, nullptr, 0,
@@ -906,10 +956,10 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
                 lnx_gemm_args g = gemm_base(c, B, D[2], D[2], c.at<void>(p->o_t1), (int64_t)p->N2 * D[2], c.wptr(p->cl_w1), p->cl_w1.ld, c.at<void>(p->o_cl_act),
                                             D[2], false);
                 g.bias = p->P[p->cl_b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(p->o_cl_hpre); g.ldc2 = D[2];
-                RUN(lnx_gemm_nt(&g, stream));
+                RUN(gemm_nt_t(c, &g));
                 g = gemm_base(c, B, D[3], D[2], c.at<void>(p->o_cl_act), D[2], c.wptr(p->cl_w2), p->cl_w2.ld, c.at<float>(p->o_cl_u), D[3], true);
                 g.bias = p->P[p->cl_b2];
-                RUN(lnx_gemm_nt(&g, stream));
+                RUN(gemm_nt_t(c, &g));
                 RUN(ln_fwd(c, B, D[3], 1e-5f, c.at<float>(p->o_cl_u), LNX_F32, D[3], IDM, p->cl_lnw, p->cl_lnb, c.at<float>(p->o_c1n), LNX_F32, D[3], IDM, nullptr,
                            0, c.at<float>(p->o_cl_mean), c.at<float>(p->o_cl_rstd)));
             }
@@ -940,7 +990,7 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
                 lnx_gemm_args g = gemm_base(c, B, cf.task_classes[t], C, c.at<void>(p->o_featsT), C, c.wptr(p->head_w[t]), p->head_w[t].ld,
                                             logits + p->logit_off[t], p->logit_ld[t], true);
                 g.bias = p->P[p->head_b[t]];
-                RUN(lnx_gemm_nt(&g, stream));
+                RUN(gemm_nt_t(c, &g));
             }
         }
     }
@@ -966,26 +1016,29 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
     RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = hid;
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C));
     a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false));
     // ---- attention branch ----
     RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_attn[s][i]), N, sC, c.dt, C, M, C, c.st));
     RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     lnx_attn_bwd_args ab;
     memset(&ab, 0, sizeof ab);
     ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
     ab.qkv = c.at<void>(k.qkvbuf); ab.cos_tab = c.at<float>(k.cos); ab.o = c.at<void>(k.o); ab.lse = c.at<float>(k.lse);
     ab.d_o = sD; ab.dqkv = sA; ab.gcos = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
-    RUN(lnx_attn_bwd(&ab, c.st));
+    {
+        Timed t(c, 3, 14.0 * B * heads * (double)N * N * 64);
+        RUN(lnx_attn_bwd(&ab, c.st));
+    }
     RUN(lnx_rope_freqs_bwd(p->P[k.freqs], c.at<float>(p->o_gcos), B, heads, p->H[2 + s], p->W[2 + s], p->G[k.freqs], c.st));
     RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C));
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false));
     return 0;
 }
@@ -1002,22 +1055,28 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
     RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
     lnx_gemm_args a = gemm_base(c, M, 4 * C, C, sC, C, c.wtptr(k.w2), k.w2.ld_t, sA, 4 * C, false);
     a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
     a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<float>(k.mean), c.at<float>(k.rstd), nullptr, sC, c.dt, C, false));
     lnx_dwconv_wgrad_args w;
     memset(&w, 0, sizeof w);
     w.B = B; w.H = H; w.W = W; w.C = C;
     w.x = c.at<float>(k.xin); w.x_dtype = LNX_F32; w.dy = sC; w.dy_dtype = c.dt;
     w.dw = p->G[k.dww]; w.db = p->G[k.dwb];
-    RUN(lnx_dwconv7_wgrad(&w, c.st));
+    {
+        Timed t(c, 5, (double)M * C * (4 + p->esz));
+        RUN(lnx_dwconv7_wgrad(&w, c.st));
+    }
     lnx_dwconv_args d;
     memset(&d, 0, sizeof d);
     d.B = B; d.H = H; d.W = W; d.C = C;
     d.x = sC; d.x_dtype = c.dt; d.w49 = c.at<float>(k.w49); d.bias = nullptr; d.flip = 1; d.res = g; d.y = g; d.y_dtype = LNX_F32;
-    RUN(lnx_dwconv7_fwd(&d, c.st));
+    {
+        Timed t(c, 4, (double)M * C * (8 + p->esz));  // bytes: read T dy + fp32 g, write fp32 g
+        RUN(lnx_dwconv7_fwd(&d, c.st));
+    }
     return 0;
 }
 
@@ -1036,10 +1095,13 @@ int downsample_bwd(const Ctx& c, int i, const float* gout, int64_t ldg, lnx_rowm
     w.dtype = c.dt; w.M = Mout; w.N = Cout; w.K = 4 * Cin;
     w.dY = sC; w.lddy = Cout; w.A = c.at<void>(d.ln); w.a_mode = LNX_ADDR_PATCH2; w.Hin = Hin; w.Win = Win; w.Cin = Cin;
     w.dW = p->G[d.w.param]; w.lddw = 4 * Cin; w.k_perm_c = Cin; w.db = p->G[d.cb];
-    RUN(lnx_gemm_tn(&w, c.st));
+    {
+        Timed t(c, 1, 2.0 * Mout * Cout * 4 * Cin);
+        RUN(lnx_gemm_tn(&w, c.st));
+    }
     lnx_gemm_args a = gemm_base(c, Mout, 4 * Cin, Cout, sC, Cout, c.wtptr(d.w), d.w.ld_t, sA, 0, false);
     a.c_mode = LNX_ADDR_PATCH2; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, Min, Cin, sA, c.dt, Cin, IDM, x, xdt, ldx, xm, d.lnw, d.lnb, c.at<float>(d.mean), c.at<float>(d.rstd), nullptr, dx, dxdt, lddx, false));
     return 0;
 }
@@ -1058,12 +1120,12 @@ int meta_head_bwd(const Ctx& cc, int s, int m, const float* g, int N) {
     RUN(ln_bwd(c, B, C, dtok, LNX_F32, C, IDM, c.at<void>(k.h2), c.dt, C, IDM, k.nf2w, k.nf2b, c.at<float>(k.m2), c.at<float>(k.r2), nullptr, t1, c.dt, C, true));
     RUN(wgrad(c, B, C, C, t1, C, c.at<void>(k.n1), C, k.w2.param, k.b2, C));
     lnx_gemm_args a = gemm_base(c, B, C, C, t1, C, c.wtptr(k.w2), k.w2.ld_t, t2, C, false);
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, B, C, t2, c.dt, C, IDM, c.at<void>(k.h1), c.dt, C, IDM, k.nf1w, k.nf1b, c.at<float>(k.m1), c.at<float>(k.r1), nullptr, t1, c.dt, C, true));
     RUN(wgrad(c, B, C, C, t1, C, c.at<void>(k.x), C, k.w1.param, k.b1, C));
     a = gemm_base(c, B, C, C, t1, C, c.wtptr(k.w1), k.w1.ld_t, dxf, C, true);
     a.res = dtok; a.ldres = C;  // skip connection of ResNormLayer
-    RUN(lnx_gemm_nt(&a, c.st));
+    RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, B, C, dxf, LNX_F32, C, IDM, c.at<void>(k.h0), c.dt, C, IDM, k.lnw0, k.lnb0, c.at<float>(k.m0), c.at<float>(k.r0), nullptr, t1, c.dt, C, true));
     RUN(wgrad(c, B, C, 16, t1, C, c.at<void>(k.t0), 16, k.w0.param, k.b0, k.dim, k.dim));
     return 0;
@@ -1111,7 +1173,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
                     a.res = dfe;
                     a.ldres = C;
                 }
-                RUN(lnx_gemm_nt(&a, stream));
+                RUN(gemm_nt_t(c, &a));
                 have = true;
             }
         }
@@ -1151,11 +1213,11 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
             RUN(wgrad(c, B, C, C2, du, C, c.at<void>(p->o_cl_act), C2, p->cl_w2.param, p->cl_b2, C2));
             lnx_gemm_args a = gemm_base(c, B, C2, C, du, C, c.wtptr(p->cl_w2), p->cl_w2.ld_t, dca, C2, false);
             a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(p->o_cl_hpre); a.ldaux = C2;
-            RUN(lnx_gemm_nt(&a, stream));
+            RUN(gemm_nt_t(c, &a));
             RUN(wgrad(c, B, C2, C2, dca, C2, c.at<void>(p->o_t1), (int64_t)p->N2 * C2, p->cl_w1.param, p->cl_b1, C2));
             a = gemm_base(c, B, C2, C2, dca, C2, c.wtptr(p->cl_w1), p->cl_w1.ld_t, dt1, C2, false);
             a.c_map = lnx_rowmap{1, p->N2 - 1, 0};
-            RUN(lnx_gemm_nt(&a, stream));
+            RUN(gemm_nt_t(c, &a));
         }
         float* g2 = c.at<float>(p->o_g[2]);
         RUN(ln_bwd(c, B * p->N2, C2, dt1, cf.dtype, C2, IDM, c.at<float>(p->o_stage_out[2]), LNX_F32, C2, IDM, p->norm_w[0], p->norm_b[0], c.at<float>(p->o_t1_mean),
@@ -1205,4 +1267,36 @@ extern "C" int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_
             ++n;
         }
     return n;
+}
+
+extern "C" int lnx_plan_profile_begin(lnx_plan* p) {
+    if (!p) FAIL("lnx_plan_profile_begin: null plan");
+    p->profile = true;
+    p->spans.clear();
+    p->ev_used = 0;
+    return 0;
+}
+
+// Ends profiling; synchronises the device and returns, per kernel class, the summed launch
+// time (ms), the summed algorithmic work (FLOPs, or bytes for the HBM-bound classes) and the
+// number of launches.  Arrays must hold LNX_PROFILE_CLASSES entries.
+extern "C" int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches) {
+    if (!p || !ms || !work || !launches) FAIL("lnx_plan_profile_end: null argument");
+    p->profile = false;
+    HIPRUN(hipDeviceSynchronize());
+    for (int i = 0; i < LNX_PROFILE_CLASSES; ++i) {
+        ms[i] = 0;
+        work[i] = 0;
+        launches[i] = 0;
+    }
+    for (const auto& sp : p->spans) {
+        float t = 0.f;
+        HIPRUN(hipEventElapsedTime(&t, sp.e0, sp.e1));
+        ms[sp.cls] += t;
+        work[sp.cls] += sp.work;
+        launches[sp.cls] += 1;
+    }
+    p->spans.clear();
+    p->ev_used = 0;
+    return 0;
 }
