@@ -1,0 +1,79 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/lnx.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from linnaeus_amd import _lib as L
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(REPO, "include", "lnx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lnx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_lists_agree():
+    assert declared_symbols() == sorted(L.EXPORTS)
+
+
+def test_library_loads_and_exports_everything():
+    lib = L.lib()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.lnx_version() >= 100
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes the C compiler produces for the argument structs (LP64): catches field drift
+    assert C.sizeof(L.RowMap) == 12
+    assert C.sizeof(L.GemmArgs) % 8 == 0 and C.sizeof(L.WgradArgs) % 8 == 0
+    assert C.sizeof(L.PrepDesc) == 56
+
+
+def test_argument_validation_without_gpu():
+    lib = L.lib()
+    a = L.GemmArgs()
+    a.dtype = 7
+    assert lib.lnx_gemm_nt(C.byref(a), None) != 0
+    assert b"dtype" in lib.lnx_last_error()
+    a.dtype, a.M, a.N, a.K = L.BF16, 4, 4, 3  # K not a multiple of 8
+    assert lib.lnx_gemm_nt(C.byref(a), None) != 0
+    assert b"multiple" in lib.lnx_last_error()
+
+
+def test_plan_create_validates_and_enumerates_parameters():
+    from linnaeus_amd.model import _Cfg
+
+    lib = L.lib()
+    lib.lnx_plan_param_name.restype = C.c_char_p
+    lib.lnx_plan_param_numel.restype = C.c_int64
+    lib.lnx_plan_workspace_bytes.restype = C.c_int64
+    cfg = _Cfg()
+    cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = L.BF16, 2, 224, 224, 3
+    cfg.dims[:] = [96, 192, 384, 768]
+    cfg.conv_depths[:] = [3, 3]
+    cfg.rope_depths[:] = [5, 2]
+    cfg.rope_heads[:] = [6, 12]
+    cfg.mlp_hidden[:] = [1536, 3072]
+    cfg.n_meta = 2
+    cfg.meta_dims[0], cfg.meta_dims[1] = 2, 3
+    cfg.n_tasks = 0
+    h = C.c_void_p()
+    assert lib.lnx_plan_create(C.byref(cfg), C.byref(h)) == 0, lib.lnx_last_error()
+    n = lib.lnx_plan_num_params(h)
+    assert n == 225  # 225 state_dict tensors for sm without heads
+    total = sum(lib.lnx_plan_param_numel(h, i) for i in range(n))
+    assert total == 29_189_091
+    assert lib.lnx_plan_num_drop_calls(h) == 6 + 2 * 7
+    assert lib.lnx_plan_workspace_bytes(h) > 0
+    lib.lnx_plan_destroy(h)
+    cfg.rope_heads[0] = 5  # head_dim != 64
+    assert lib.lnx_plan_create(C.byref(cfg), C.byref(h)) != 0
+    assert b"head_dim" in lib.lnx_last_error()
+    cfg.rope_heads[0] = 6
+    cfg.img_h = 230
+    assert lib.lnx_plan_create(C.byref(cfg), C.byref(h)) != 0
