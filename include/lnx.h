@@ -150,6 +150,8 @@ typedef struct lnx_ln_bwd_args {
     float* dw;          /* [C] += (fp32 atomics) or NULL */
     float* db;
     int relu_mask;      /* 1: x is a ReLU output feeding this LN; dx *= (x > 0) */
+    float* ws;          /* optional scratch for the dw/db column partials (avoids contended atomics) */
+    int64_t ws_floats;  /* its capacity in floats; 2048*2*C is the most that is used */
 } lnx_ln_bwd_args;
 int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
 

@@ -115,6 +115,7 @@ class LnBwdArgs(C.Structure):
         ("gin", C.c_void_p), ("ldgin", C.c_int64),
         ("dx", C.c_void_p), ("dx_dtype", C.c_int), ("lddx", C.c_int64),
         ("dw", C.c_void_p), ("db", C.c_void_p), ("relu_mask", C.c_int),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

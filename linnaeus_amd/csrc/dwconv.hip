@@ -3,13 +3,16 @@
 // blocks/convnext.py:56-58.
 //
 // HBM-bound op: algorithmic traffic is one read of x and one write of y per element
-// (49 MACs per element).  To get there the input tile with its 3-pixel halo is staged once
-// in LDS (channel-innermost, so a wave reads 32 consecutive channels = conflict-free
-// ds_read_b32) and every thread produces a 16-pixel output row segment from registers:
-// 22 LDS reads + 7 weight loads per 112 FMAs.
+// (49 MACs per element).  A workgroup walks a sequence of 8x16-pixel x 32-channel tiles; the
+// tile's input with its 3-pixel halo is staged in LDS (channel-innermost: a wave reads 32
+// consecutive channels = conflict-free ds_read_b32) and each thread produces a 16-pixel output
+// row segment from registers (22 + 7 LDS reads per 112 FMAs, ky loop kept rolled so only one
+// input row is live).  The NEXT tile's halo is fetched global->registers before the current
+// tile's FMAs and written to LDS after them, so HBM/L2 latency hides under the arithmetic
+// (issue-early / write-late staging) instead of serialising load -> compute -> store.
 //
 // Tile: 8 rows x 16 cols x 32 channels of output per 256-thread workgroup
-// (thread = (channel lane 0..31, row 0..7)); LDS 14 x 22 x 32 fp32 = 38.5 KiB.
+// (thread = (channel lane 0..31, row 0..7)); LDS 14 x 22 x 32 fp32 = 38.5 KiB + 6 KiB taps.
 #include "common.hpp"
 #include "../../include/lnx.h"
 
@@ -17,6 +20,9 @@ namespace {
 
 constexpr int TH = 8, TW = 16, CB = 32;
 constexpr int IH = TH + 6, IW = TW + 6;
+constexpr int NV = IH * IW * (CB / 4);         // float4 slots of a halo tile
+constexpr int NPRE = (NV + 255) / 256;         // per-thread prefetch registers
+constexpr int NDY = TH * TW * (CB / 4) / 256;  // float4 slots per thread of an output-shaped tile
 
 struct DwP {
     const void* x;
@@ -27,81 +33,126 @@ struct DwP {
     int B, H, W, C;
     int flip;
     int tiles_h, tiles_w, cblocks;
+    int tiles_per_wg;  // consecutive tiles (same channel block) one workgroup walks
 };
 
+template <typename TX> struct Raw4;  // 4 consecutive channels as loaded
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef uint2 type; };
+
+__device__ __forceinline__ float4 widen(const float4& v) { return v; }
+__device__ __forceinline__ float4 widen(const uint2& r) {
+    const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void zero_raw(float4& v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero_raw(uint2& v) { v = make_uint2(0u, 0u); }
+
+// tile index -> (b, th, tw); tiles of one channel block are numbered ((b*tiles_h + th)*tiles_w + tw)
+struct TilePos {
+    int b, h0, w0;
+};
+__device__ __forceinline__ TilePos tile_pos(int t, int tiles_h, int tiles_w) {
+    TilePos q;
+    const int tw = t % tiles_w;
+    const int t2 = t / tiles_w;
+    q.b = t2 / tiles_h;
+    q.h0 = (t2 % tiles_h) * TH;
+    q.w0 = tw * TW;
+    return q;
+}
+
 template <typename TX>
-__device__ __forceinline__ void load_halo_tile(float* __restrict__ tile, const TX* __restrict__ x, int b, int h0, int w0, int c0, int H, int W, int C) {
-    // tile[(ih*IW + iw)*CB + c] ; 4-channel vectors, consecutive threads -> consecutive channels
-    constexpr int NV = IH * IW * (CB / 4);
-    for (int i = threadIdx.x; i < NV; i += 256) {
-        const int cv = i % (CB / 4);
-        const int pix = i / (CB / 4);
-        const int iw = pix % IW, ih = pix / IW;
-        const int h = h0 + ih - 3, w = w0 + iw - 3;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h >= 0 && h < H && w >= 0 && w < W) {
-            const TX* p = x + (((int64_t)b * H + h) * W + w) * C + c0 + 4 * cv;
-            if constexpr (sizeof(TX) == 4) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                const uint2 r = *reinterpret_cast<const uint2*>(p);
-                const bf16_t* hh = reinterpret_cast<const bf16_t*>(&r);
-                v = make_float4((float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]);
-            }
+__device__ __forceinline__ void halo_issue(typename Raw4<TX>::type (&pre)[NPRE], const TX* __restrict__ x, const TilePos& q, int c0, int H, int W, int C) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        zero_raw(pre[k]);
+        if (i < NV) {
+            const int cv = i % (CB / 4);
+            const int pix = i / (CB / 4);
+            const int iw = pix % IW, ih = pix / IW;
+            const int h = q.h0 + ih - 3, w = q.w0 + iw - 3;
+            if (h >= 0 && h < H && w >= 0 && w < W)
+                pre[k] = *reinterpret_cast<const typename Raw4<TX>::type*>(x + (((int64_t)q.b * H + h) * W + w) * C + c0 + 4 * cv);
         }
-        *reinterpret_cast<float4*>(tile + pix * CB + 4 * cv) = v;
     }
 }
 
-template <typename TX, typename TY>
+template <typename TX>
+__device__ __forceinline__ void halo_commit(float* __restrict__ tile, const typename Raw4<TX>::type (&pre)[NPRE]) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < NV) *reinterpret_cast<float4*>(tile + 4 * i) = widen(pre[k]);  // tile[pix*CB + 4*cv] == tile[4*i]
+    }
+}
+
+template <typename TX, typename TY, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
     __shared__ __attribute__((aligned(16))) float tile[IH * IW * CB];
-    int bid = blockIdx.x;
-    const int cb = bid % p.cblocks;
-    bid /= p.cblocks;
-    const int tw = bid % p.tiles_w;
-    bid /= p.tiles_w;
-    const int th = bid % p.tiles_h;
-    const int b = bid / p.tiles_h;
-    const int h0 = th * TH, w0 = tw * TW, c0 = cb * CB;
-
-    load_halo_tile<TX>(tile, reinterpret_cast<const TX*>(p.x), b, h0, w0, c0, p.H, p.W, p.C);
-    __syncthreads();
-
+    __shared__ float wtile[49 * CB];
+    const int ntile = p.B * p.tiles_h * p.tiles_w;
+    const int chunks = (ntile + p.tiles_per_wg - 1) / p.tiles_per_wg;
+    const int cb = blockIdx.x / chunks;
+    const int t_begin = (blockIdx.x % chunks) * p.tiles_per_wg;
+    const int t_end = min(ntile, t_begin + p.tiles_per_wg);
+    const int c0 = cb * CB;
     const int cl = threadIdx.x & 31;
     const int r = threadIdx.x >> 5;
     const int c = c0 + cl;
-    float acc[TW];
-    const float bv = p.bias ? p.bias[c] : 0.f;
-#pragma unroll
-    for (int j = 0; j < TW; ++j) acc[j] = bv;
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-        float wv[7];
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            const int tap = p.flip ? (6 - ky) * 7 + (6 - kx) : ky * 7 + kx;
-            wv[kx] = p.w49[tap * p.C + c];
-        }
-        float in[IW];
-        const float* row = tile + ((r + ky) * IW) * CB + cl;
-#pragma unroll
-        for (int j = 0; j < IW; ++j) in[j] = row[j * CB];
-#pragma unroll
-        for (int j = 0; j < TW; ++j)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) acc[j] = fmaf(wv[kx], in[j + kx], acc[j]);
+    const TX* xg = reinterpret_cast<const TX*>(p.x);
+
+    for (int i = threadIdx.x; i < 49 * CB; i += 256) {
+        const int t = i / CB, cc = i % CB;
+        wtile[i] = p.w49[(FLIP ? 48 - t : t) * p.C + c0 + cc];
     }
-    const int h = h0 + r;
-    if (h >= p.H) return;
+    const float bv = p.bias ? p.bias[c] : 0.f;
+
+    typename Raw4<TX>::type pre[NPRE];
+    halo_issue<TX>(pre, xg, tile_pos(t_begin, p.tiles_h, p.tiles_w), c0, p.H, p.W, p.C);
+    halo_commit<TX>(tile, pre);
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const TilePos q = tile_pos(t, p.tiles_h, p.tiles_w);
+        const bool more = t + 1 < t_end;
+        if (more) halo_issue<TX>(pre, xg, tile_pos(t + 1, p.tiles_h, p.tiles_w), c0, p.H, p.W, p.C);
+
+        float acc[TW];
 #pragma unroll
-    for (int j = 0; j < TW; ++j) {
-        const int w = w0 + j;
-        if (w < p.W) {
-            const int64_t off = (((int64_t)b * p.H + h) * p.W + w) * p.C + c;
-            float v = acc[j];
-            if (p.res) v += p.res[off];
-            reinterpret_cast<TY*>(p.y)[off] = from_f<TY>(v);
+        for (int j = 0; j < TW; ++j) acc[j] = bv;
+#pragma unroll 1
+        for (int ky = 0; ky < 7; ++ky) {
+            float wv[7];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) wv[kx] = wtile[(ky * 7 + kx) * CB + cl];
+            float in[IW];
+            const float* row = tile + ((r + ky) * IW) * CB + cl;
+#pragma unroll
+            for (int j = 0; j < IW; ++j) in[j] = row[j * CB];
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) acc[j] = fmaf(wv[kx], in[j + kx], acc[j]);
+        }
+        const int h = q.h0 + r;
+        if (h < p.H) {
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                const int w = q.w0 + j;
+                if (w < p.W) {
+                    const int64_t off = (((int64_t)q.b * p.H + h) * p.W + w) * p.C + c;
+                    float v = acc[j];
+                    if (p.res) v += p.res[off];
+                    reinterpret_cast<TY*>(p.y)[off] = from_f<TY>(v);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done reading this tile
+        if (more) {
+            halo_commit<TX>(tile, pre);
+            __syncthreads();
         }
     }
 }
@@ -115,9 +166,24 @@ struct DwWgP {
     int tiles_h, tiles_w, cblocks, ntile;  // ntile = B * tiles_h * tiles_w
 };
 
+template <typename TDY>
+__device__ __forceinline__ void dy_issue(typename Raw4<TDY>::type (&pre)[NDY], const TDY* __restrict__ dy, const TilePos& q, int c0, int H, int W, int C) {
+#pragma unroll
+    for (int k = 0; k < NDY; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int cv = i % (CB / 4);
+        const int pix = i / (CB / 4);
+        const int j = pix % TW, rr = pix / TW;
+        const int h = q.h0 + rr, w = q.w0 + j;
+        zero_raw(pre[k]);
+        if (h < H && w < W) pre[k] = *reinterpret_cast<const typename Raw4<TDY>::type*>(dy + (((int64_t)q.b * H + h) * W + w) * C + c0 + 4 * cv);
+    }
+}
+
 // dW[c, ky, kx] += sum dY[b,h,w,c] * x[b,h+ky-3,w+kx-3,c];   db[c] += sum dY
-// Each workgroup owns one 32-channel block and walks tiles grid-stride, keeping its
-// 49 tap sums per thread in registers; one LDS reduction + one atomic per tap at the end.
+// Each workgroup owns one 32-channel block and walks tiles grid-stride with the same
+// register-prefetch pipeline, keeping its 49 tap sums per thread in registers; one LDS
+// reduction + one atomic per tap at the end.
 template <typename TX, typename TDY>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const DwWgP p) {
     __shared__ __attribute__((aligned(16))) float tile[IH * IW * CB];
@@ -128,39 +194,32 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const DwWgP p) {
     const int c0 = cb * CB;
     const int cl = threadIdx.x & 31;
     const int r = threadIdx.x >> 5;
+    const TX* xg = reinterpret_cast<const TX*>(p.x);
+    const TDY* dg = reinterpret_cast<const TDY*>(p.dy);
 
     float acc[49];
 #pragma unroll
     for (int t = 0; t < 49; ++t) acc[t] = 0.f;
     float accb = 0.f;
 
+    typename Raw4<TX>::type pre[NPRE];
+    typename Raw4<TDY>::type pdy[NDY];
+    if (walker < p.ntile) {
+        const TilePos q0 = tile_pos(walker, p.tiles_h, p.tiles_w);
+        halo_issue<TX>(pre, xg, q0, c0, p.H, p.W, p.C);
+        dy_issue<TDY>(pdy, dg, q0, c0, p.H, p.W, p.C);
+        halo_commit<TX>(tile, pre);
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) *reinterpret_cast<float4*>(dyt + 4 * (threadIdx.x + 256 * k)) = widen(pdy[k]);
+    }
+    __syncthreads();
     for (int t = walker; t < p.ntile; t += nwalk) {
-        const int tw = t % p.tiles_w;
-        const int t2 = t / p.tiles_w;
-        const int th = t2 % p.tiles_h;
-        const int b = t2 / p.tiles_h;
-        const int h0 = th * TH, w0 = tw * TW;
-        __syncthreads();  // previous iteration's readers are done
-        load_halo_tile<TX>(tile, reinterpret_cast<const TX*>(p.x), b, h0, w0, c0, p.H, p.W, p.C);
-        for (int i = threadIdx.x; i < TH * TW * (CB / 4); i += 256) {
-            const int cv = i % (CB / 4);
-            const int pix = i / (CB / 4);
-            const int j = pix % TW, rr = pix / TW;
-            const int h = h0 + rr, w = w0 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h < p.H && w < p.W) {
-                const TDY* q = reinterpret_cast<const TDY*>(p.dy) + (((int64_t)b * p.H + h) * p.W + w) * p.C + c0 + 4 * cv;
-                if constexpr (sizeof(TDY) == 4) {
-                    v = *reinterpret_cast<const float4*>(q);
-                } else {
-                    const uint2 rw = *reinterpret_cast<const uint2*>(q);
-                    const bf16_t* hh = reinterpret_cast<const bf16_t*>(&rw);
-                    v = make_float4((float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]);
-                }
-            }
-            *reinterpret_cast<float4*>(dyt + pix * CB + 4 * cv) = v;
+        const bool more = t + nwalk < p.ntile;
+        if (more) {
+            const TilePos qn = tile_pos(t + nwalk, p.tiles_h, p.tiles_w);
+            halo_issue<TX>(pre, xg, qn, c0, p.H, p.W, p.C);
+            dy_issue<TDY>(pdy, dg, qn, c0, p.H, p.W, p.C);
         }
-        __syncthreads();
         float d[TW];
 #pragma unroll
         for (int j = 0; j < TW; ++j) {
@@ -178,11 +237,18 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const DwWgP p) {
 #pragma unroll
                 for (int j = 0; j < TW; ++j) acc[ky * 7 + kx] = fmaf(d[j], in[j + kx], acc[ky * 7 + kx]);
         }
+        __syncthreads();
+        if (more) {
+            halo_commit<TX>(tile, pre);
+#pragma unroll
+            for (int k = 0; k < NDY; ++k) *reinterpret_cast<float4*>(dyt + 4 * (threadIdx.x + 256 * k)) = widen(pdy[k]);
+            __syncthreads();
+        }
     }
-    // reduce over the 8 row-threads of each channel through LDS (reuse `tile`)
-    __syncthreads();
-    float* red = tile;  // [8][50][32] floats = 12800 <= IH*IW*CB = 9856? no -> use two passes
-    // pass A: taps 0..24, pass B: taps 25..48 + bias  (8*25*32 = 6400 floats each)
+    // reduce over the 8 row-threads of each channel through LDS (reusing `tile`), two passes of 25
+    // slots: taps 0..24, then taps 25..48 + the bias sum
+    float* red = tile;
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int tbeg = pass * 25;
         const int tcnt = pass == 0 ? 25 : 24;
@@ -213,17 +279,29 @@ extern "C" int lnx_dwconv7_fwd(const lnx_dwconv_args* a, void* stream) {
     p.x = a->x; p.w49 = a->w49; p.bias = a->bias; p.res = a->res; p.y = a->y;
     p.B = a->B; p.H = a->H; p.W = a->W; p.C = a->C; p.flip = a->flip;
     p.tiles_h = cdiv(a->H, TH); p.tiles_w = cdiv(a->W, TW); p.cblocks = a->C / CB;
-    const int64_t grid = (int64_t)a->B * p.tiles_h * p.tiles_w * p.cblocks;
+    // each workgroup walks the tiles of (up to) one image; with fewer than ~3 workgroups per CU the
+    // walk is shortened so the chip stays full
+    const int64_t ntile = (int64_t)a->B * p.tiles_h * p.tiles_w;
+    int per = p.tiles_h * p.tiles_w;
+    while (per > 1 && (int64_t)cdiv(ntile, per) * p.cblocks < 3 * 256) per = (per + 1) / 2;
+    p.tiles_per_wg = per;
+    const int64_t grid = (int64_t)cdiv(ntile, per) * p.cblocks;
     LNX_CHECK(grid < (1ll << 31), "lnx_dwconv7_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    const int code = a->x_dtype * 2 + a->y_dtype;
+    const int code = a->x_dtype * 2 + a->y_dtype + (a->flip ? 4 : 0);
+#define DWL(TX, TY, F) hipLaunchKernelGGL((dwconv7_kernel<TX, TY, F>), dim3((int)grid), dim3(256), 0, st, p)
     switch (code) {
-        case 0: hipLaunchKernelGGL((dwconv7_kernel<float, float>), dim3((int)grid), dim3(256), 0, st, p); break;
-        case 1: hipLaunchKernelGGL((dwconv7_kernel<float, bf16_t>), dim3((int)grid), dim3(256), 0, st, p); break;
-        case 2: hipLaunchKernelGGL((dwconv7_kernel<bf16_t, float>), dim3((int)grid), dim3(256), 0, st, p); break;
-        case 3: hipLaunchKernelGGL((dwconv7_kernel<bf16_t, bf16_t>), dim3((int)grid), dim3(256), 0, st, p); break;
+        case 0: DWL(float, float, false); break;
+        case 1: DWL(float, bf16_t, false); break;
+        case 2: DWL(bf16_t, float, false); break;
+        case 3: DWL(bf16_t, bf16_t, false); break;
+        case 4: DWL(float, float, true); break;
+        case 5: DWL(float, bf16_t, true); break;
+        case 6: DWL(bf16_t, float, true); break;
+        case 7: DWL(bf16_t, bf16_t, true); break;
         default: LNX_CHECK(false, "lnx_dwconv7_fwd: bad dtypes");
     }
+#undef DWL
     LNX_LAUNCH_CHECK();
     return 0;
 }
@@ -236,7 +314,7 @@ extern "C" int lnx_dwconv7_wgrad(const lnx_dwconv_wgrad_args* a, void* stream) {
     p.B = a->B; p.H = a->H; p.W = a->W; p.C = a->C;
     p.tiles_h = cdiv(a->H, TH); p.tiles_w = cdiv(a->W, TW); p.cblocks = a->C / CB;
     p.ntile = a->B * p.tiles_h * p.tiles_w;
-    int walkers = 1024 / p.cblocks;
+    int walkers = 768 / p.cblocks;
     if (walkers < 1) walkers = 1;
     if (walkers > p.ntile) walkers = p.ntile;
     const int grid = walkers * p.cblocks;

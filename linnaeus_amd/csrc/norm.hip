@@ -1,9 +1,13 @@
 // LayerNorm over the last (channel) dimension, forward and backward, for gfx950.
 //
-// One 64-lane wave owns one row: the row lives in registers (<= 2048 channels), statistics
-// are two-pass fp32 (mean, then centred variance -- the formulation of nn.LayerNorm and of
-// the reference's LayerNormChannelsFirst, blocks/convnext.py:36-38), loads/stores are
-// 16-byte vectors.  HBM-bound: algorithmic traffic is one read + one write of the row.
+// A row is owned by a group of G lanes (G = 8/16/32/64 chosen from C so that each lane holds
+// <= 3 float4; C up to 2048 uses a full wave with up to 8), i.e. a 64-lane wave processes
+// 64/G consecutive rows at once: for the ConvNeXt widths (C = 96/192) every lane is busy and a
+// wave-instruction touches 1 KiB of consecutive memory.  The row lives in registers,
+// statistics are two-pass fp32 (mean, then centred variance -- the formulation of
+// nn.LayerNorm and of the reference's LayerNormChannelsFirst, blocks/convnext.py:36-38),
+// loads/stores are 16-byte (fp32) / 8-byte (bf16) vectors.  HBM-bound: algorithmic traffic is
+// one read + one write of the row.
 //
 // In NHWC (channels-last) memory the reference's channels-first LayerNorm is this same
 // kernel, so stem.1 / downsample_layers.*.norm / block norms / norm1 / norm2 / norm_1 /
@@ -13,7 +17,7 @@
 
 namespace {
 
-constexpr int MAXV = 8;  // up to 8 float4 per lane: C <= 2048
+constexpr int MAXC = 2048;
 
 struct LnP {
     const void* x;
@@ -48,44 +52,57 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
     *reinterpret_cast<uint2*>(p) = r;
 }
 
-template <typename TX, typename TY>
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename TX, typename TY, int G, int V>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
+    constexpr int R = 64 / G;  // rows per wave
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int sub = lane % G, rw = lane / G;
     const int nvec = p.C >> 2;
     const float invC = 1.0f / (float)p.C;
-    for (int m = blockIdx.x * 4 + wave; m < p.M; m += gridDim.x * 4) {
-        const TX* xr = reinterpret_cast<const TX*>(p.x) + map_row(p.xmap, m) * p.ldx;
-        float4 v[MAXV];
+    for (int m0 = (blockIdx.x * 4 + wave) * R; m0 < p.M; m0 += gridDim.x * 4 * R) {
+        const int m = m0 + rw;
+        const bool rv = m < p.M;
+        const int mc = rv ? m : p.M - 1;
+        const TX* xr = reinterpret_cast<const TX*>(p.x) + map_row(p.xmap, mc) * p.ldx;
+        float4 v[V];
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
+        for (int i = 0; i < V; ++i) {
+            const int c4 = sub + G * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c4 < nvec) {
                 v[i] = load4<TX>(xr + 4 * c4);
                 sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
         }
-        const float mu = wave_sum(sum) * invC;
+        const float mu = group_sum<G>(sum) * invC;
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
+        for (int i = 0; i < V; ++i) {
+            const int c4 = sub + G * i;
             if (c4 < nvec) {
                 v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
                 sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
             }
         }
-        const float rs = 1.0f / sqrtf(wave_sum(sq) * invC + p.eps);
-        if (lane == 0) {
+        const float rs = 1.0f / sqrtf(group_sum<G>(sq) * invC + p.eps);
+        if (!rv) continue;
+        if (sub == 0) {
             if (p.mean) p.mean[m] = mu;
             if (p.rstd) p.rstd[m] = rs;
         }
         TY* yr = reinterpret_cast<TY*>(p.y) + map_row(p.ymap, m) * p.ldy;
         const TX* ar = p.add ? reinterpret_cast<const TX*>(p.add) + (int64_t)m * p.ldadd : nullptr;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
+        for (int i = 0; i < V; ++i) {
+            const int c4 = sub + G * i;
             if (c4 < nvec) {
                 const float4 w = *reinterpret_cast<const float4*>(p.w + 4 * c4);
                 const float4 b = *reinterpret_cast<const float4*>(p.b + 4 * c4);
@@ -114,52 +131,65 @@ struct LnBwdP {
     RowMap dymap, xmap;
     int M, C;
     int relu_mask;
+    float* part;      // optional workspace [gridDim.x][2][C]: per-workgroup column partials (no atomics)
 };
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd
 // dw += sum_m dy * xhat,  db += sum_m dy
-template <typename TDY, typename TX, typename TDX>
+template <typename TDY, typename TX, typename TDX, int G, int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
-    __shared__ float red[4][64 * 4];
+    constexpr int R = 64 / G;
+    __shared__ float red[4][G * V * 4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int sub = lane % G, rw = lane / G;
     const int nvec = p.C >> 2;
     const float invC = 1.0f / (float)p.C;
-    float4 adw[MAXV], adb[MAXV];
+    float4 adw[V], adb[V], wv[V];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) adw[i] = adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < V; ++i) {
+        adw[i] = adb[i] = wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c4 = sub + G * i;
+        if (c4 < nvec) wv[i] = *reinterpret_cast<const float4*>(p.w + 4 * c4);
+    }
 
-    for (int m = blockIdx.x * 4 + wave; m < p.M; m += gridDim.x * 4) {
-        const int64_t xrow = map_row(p.xmap, m);
+    for (int m0 = (blockIdx.x * 4 + wave) * R; m0 < p.M; m0 += gridDim.x * 4 * R) {
+        const int m = m0 + rw;
+        const bool rv = m < p.M;
+        const int mc = rv ? m : p.M - 1;
+        const int64_t xrow = map_row(p.xmap, mc);
         const TX* xr = reinterpret_cast<const TX*>(p.x) + xrow * p.ldx;
-        const TDY* dr = reinterpret_cast<const TDY*>(p.dy) + map_row(p.dymap, m) * p.lddy;
-        const float mu = p.mean[m], rs = p.rstd[m];
-        float4 xh[MAXV], g[MAXV];
-        unsigned pos[MAXV];  // bit j: x element j > 0 (ReLU mask)
+        const TDY* dr = reinterpret_cast<const TDY*>(p.dy) + map_row(p.dymap, mc) * p.lddy;
+        const float mu = p.mean[mc], rs = p.rstd[mc];
+        float4 xh[V], g[V];
+        unsigned pos[V];  // bit j: x element j > 0 (ReLU mask)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
+        for (int i = 0; i < V; ++i) {
+            const int c4 = sub + G * i;
+            xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pos[i] = 0;
             if (c4 < nvec) {
                 const float4 xv = load4<TX>(xr + 4 * c4);
-                const float4 dv = load4<TDY>(dr + 4 * c4);
+                float4 dv = load4<TDY>(dr + 4 * c4);
+                if (!rv) dv = make_float4(0.f, 0.f, 0.f, 0.f);
                 pos[i] = (xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u);
-                const float4 w = *reinterpret_cast<const float4*>(p.w + 4 * c4);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                g[i] = make_float4(dv.x * w.x, dv.y * w.y, dv.z * w.z, dv.w * w.w);
+                g[i] = make_float4(dv.x * wv[i].x, dv.y * wv[i].y, dv.z * wv[i].z, dv.w * wv[i].w);
                 s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
                 s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
                 adw[i].x += dv.x * xh[i].x; adw[i].y += dv.y * xh[i].y; adw[i].z += dv.z * xh[i].z; adw[i].w += dv.w * xh[i].w;
                 adb[i].x += dv.x; adb[i].y += dv.y; adb[i].z += dv.z; adb[i].w += dv.w;
             }
         }
-        const float m1 = wave_sum(s1) * invC;
-        const float m2 = wave_sum(s2) * invC;
+        const float m1 = group_sum<G>(s1) * invC;
+        const float m2 = group_sum<G>(s2) * invC;
+        if (!rv) continue;
         TDX* ox = reinterpret_cast<TDX*>(p.dx) + xrow * p.lddx;
         const float* gi = p.gin ? p.gin + xrow * p.ldgin : nullptr;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c4 = lane + 64 * i;
+        for (int i = 0; i < V; ++i) {
+            const int c4 = sub + G * i;
             if (c4 < nvec) {
                 float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
                                        rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
@@ -178,26 +208,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         }
     }
     if (p.dw == nullptr && p.db == nullptr) return;
-    // reduce the four waves' partial column sums through LDS, one atomic per column per block
+    // column partials: sum the 64/G row groups of the wave (shuffles), then the 4 waves (LDS),
+    // then one atomic per column per workgroup
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float* dst = pass == 0 ? p.dw : p.db;
         if (dst == nullptr) continue;
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            if (64 * i >= nvec) break;
-            const float4 a = pass == 0 ? adw[i] : adb[i];
-            __syncthreads();
-            *reinterpret_cast<float4*>(&red[wave][lane * 4]) = a;
-            __syncthreads();
-            if (wave == 0) {
-                const int c4 = lane + 64 * i;
-                if (c4 < nvec) {
-                    float4 t = *reinterpret_cast<float4*>(&red[0][lane * 4]);
+        for (int i = 0; i < V; ++i) {
+            float4 a = pass == 0 ? adw[i] : adb[i];
 #pragma unroll
-                    for (int ww = 1; ww < 4; ++ww) {
-                        const float4 u = *reinterpret_cast<float4*>(&red[ww][lane * 4]);
-                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-                    }
+            for (int o = G; o < 64; o <<= 1) {
+                a.x += __shfl_xor(a.x, o, 64);
+                a.y += __shfl_xor(a.y, o, 64);
+                a.z += __shfl_xor(a.z, o, 64);
+                a.w += __shfl_xor(a.w, o, 64);
+            }
+            if (rw == 0) *reinterpret_cast<float4*>(&red[wave][(i * G + sub) * 4]) = a;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < G * V; e += 256) {
+            const int i = e / G, sb = e % G;
+            const int c4 = sb + G * i;
+            if (c4 < nvec) {
+                float4 t = *reinterpret_cast<float4*>(&red[0][e * 4]);
+#pragma unroll
+                for (int ww = 1; ww < 4; ++ww) {
+                    const float4 u = *reinterpret_cast<float4*>(&red[ww][e * 4]);
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                if (p.part) {
+                    *reinterpret_cast<float4*>(p.part + ((int64_t)blockIdx.x * 2 + pass) * p.C + 4 * c4) = t;
+                } else {
                     atomicAdd(dst + 4 * c4 + 0, t.x);
                     atomicAdd(dst + 4 * c4 + 1, t.y);
                     atomicAdd(dst + 4 * c4 + 2, t.z);
@@ -208,16 +251,98 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
     }
 }
 
-inline int ln_grid(int M) {
-    const int wg = cdiv(M, 4);
-    return wg < 2048 ? wg : 2048;
+// second stage of the dw/db reduction: sums the per-workgroup partials of a slice of workgroups
+// (blockIdx.y) for 256 consecutive (pass, column) entries; one atomic per entry per slice
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nwg, int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;  // entry in [0, 2C): pass * C + col
+    if (e >= 2 * C) return;
+    const int per = (nwg + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;  // independent chains keep 4+ loads in flight
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+        t0 += part[(int64_t)w * 2 * C + e];
+        t1 += part[(int64_t)(w + 1) * 2 * C + e];
+        t2 += part[(int64_t)(w + 2) * 2 * C + e];
+        t3 += part[(int64_t)(w + 3) * 2 * C + e];
+    }
+    for (; w < w1; ++w) t0 += part[(int64_t)w * 2 * C + e];
+    const float t = (t0 + t1) + (t2 + t3);
+    float* dst = e < C ? dw : db;
+    if (dst) atomicAdd(dst + (e < C ? e : e - C), t);
+}
+
+// (G, V) from C: smallest lane group whose lanes hold <= 3 float4; full wave with 8 otherwise
+inline void pick_gv(int C, int& G, int& V) {
+    const int nvec = C / 4;
+    for (int g = 8; g <= 64; g <<= 1)
+        if ((nvec + g - 1) / g <= 3) {
+            G = g;
+            V = 3;
+            return;
+        }
+    G = 64;
+    V = 8;
+}
+
+template <typename TX, typename TY>
+void launch_fwd(const LnP& p, hipStream_t st) {
+    int G, V;
+    pick_gv(p.C, G, V);
+    const int rows_per_wg = 4 * (64 / G);
+    int grid = cdiv(p.M, rows_per_wg);
+    if (grid > 4096) grid = 4096;
+    const dim3 g(grid), b(256);
+    if (V == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8>), g, b, 0, st, p);
+    else if (G == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3>), g, b, 0, st, p);
+    else if (G == 16) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3>), g, b, 0, st, p);
+    else if (G == 32) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 3>), g, b, 0, st, p);
+}
+
+constexpr int LN_WS_WGS = 2048;  // workgroups the partial-sum workspace is sized for
+
+template <typename TDY, typename TX, typename TDX>
+void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats) {
+    int G, V;
+    pick_gv(p.C, G, V);
+    const int rows_per_wg = 4 * (64 / G);
+    // same-address float atomics serialise (~0.1 us each): with a workspace every workgroup stores its
+    // 2C column partials and a second tiny kernel sums them; without one the grid is kept at ~2
+    // workgroups per CU so that few workgroups contend
+    int grid = cdiv(p.M, rows_per_wg * 2);
+    const bool need_cols = p.dw != nullptr || p.db != nullptr;
+    int cap = 512;
+    if (p.part && need_cols) {
+        cap = (int)(ws_floats / (2 * (int64_t)p.C));
+        if (cap > LN_WS_WGS) cap = LN_WS_WGS;
+        if (cap < 1) {
+            p.part = nullptr;
+            cap = 512;
+        }
+    } else {
+        p.part = nullptr;
+        if (!need_cols) cap = 4096;
+    }
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    const dim3 g(grid), b(256);
+    if (V == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8>), g, b, 0, st, p);
+    else if (G == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3>), g, b, 0, st, p);
+    else if (G == 16) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3>), g, b, 0, st, p);
+    else if (G == 32) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3>), g, b, 0, st, p);
+    else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3>), g, b, 0, st, p);
+    if (p.part) {
+        const int slices = grid >= 64 ? 64 : 1;
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * p.C, 256), slices), dim3(256), 0, st, p.part, grid, p.C, p.dw, p.db);
+    }
 }
 
 }  // namespace
 
 extern "C" int lnx_layernorm_fwd(const lnx_ln_args* a, void* stream) {
     LNX_CHECK(a && a->x && a->y && a->w && a->b, "lnx_layernorm_fwd: null operand");
-    LNX_CHECK(a->M > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 64 * 4 * MAXV, "lnx_layernorm_fwd: bad shape M=%d C=%d", a->M, a->C);
+    LNX_CHECK(a->M > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= MAXC, "lnx_layernorm_fwd: bad shape M=%d C=%d", a->M, a->C);
     LNX_CHECK(a->ldx % 4 == 0 && a->ldy % 4 == 0, "lnx_layernorm_fwd: ldx/ldy must be multiples of 4");
     LnP p;
     p.x = a->x; p.add = a->add; p.y = a->y; p.w = a->w; p.b = a->b; p.mean = a->mean; p.rstd = a->rstd;
@@ -226,12 +351,11 @@ extern "C" int lnx_layernorm_fwd(const lnx_ln_args* a, void* stream) {
     p.ymap = RowMap{a->y_map.group, a->y_map.pad, a->y_map.off};
     p.M = a->M; p.C = a->C; p.eps = a->eps;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(ln_grid(a->M)), block(256);
     const int xi = a->x_dtype, yi = a->y_dtype;
-    if (xi == LNX_F32 && yi == LNX_F32) hipLaunchKernelGGL((ln_fwd_kernel<float, float>), grid, block, 0, st, p);
-    else if (xi == LNX_F32 && yi == LNX_BF16) hipLaunchKernelGGL((ln_fwd_kernel<float, bf16_t>), grid, block, 0, st, p);
-    else if (xi == LNX_BF16 && yi == LNX_F32) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, float>), grid, block, 0, st, p);
-    else if (xi == LNX_BF16 && yi == LNX_BF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, bf16_t>), grid, block, 0, st, p);
+    if (xi == LNX_F32 && yi == LNX_F32) launch_fwd<float, float>(p, st);
+    else if (xi == LNX_F32 && yi == LNX_BF16) launch_fwd<float, bf16_t>(p, st);
+    else if (xi == LNX_BF16 && yi == LNX_F32) launch_fwd<bf16_t, float>(p, st);
+    else if (xi == LNX_BF16 && yi == LNX_BF16) launch_fwd<bf16_t, bf16_t>(p, st);
     else LNX_CHECK(false, "lnx_layernorm_fwd: bad dtypes %d %d", xi, yi);
     LNX_LAUNCH_CHECK();
     return 0;
@@ -239,7 +363,7 @@ extern "C" int lnx_layernorm_fwd(const lnx_ln_args* a, void* stream) {
 
 extern "C" int lnx_layernorm_bwd(const lnx_ln_bwd_args* a, void* stream) {
     LNX_CHECK(a && a->dy && a->x && a->w && a->mean && a->rstd && a->dx, "lnx_layernorm_bwd: null operand");
-    LNX_CHECK(a->M > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= 64 * 4 * MAXV, "lnx_layernorm_bwd: bad shape M=%d C=%d", a->M, a->C);
+    LNX_CHECK(a->M > 0 && a->C > 0 && a->C % 4 == 0 && a->C <= MAXC, "lnx_layernorm_bwd: bad shape M=%d C=%d", a->M, a->C);
     LNX_CHECK(a->ldx % 4 == 0 && a->lddy % 4 == 0 && a->lddx % 4 == 0, "lnx_layernorm_bwd: leading dims must be multiples of 4");
     LnBwdP p;
     p.dy = a->dy; p.x = a->x; p.w = a->w; p.mean = a->mean; p.rstd = a->rstd; p.gin = a->gin; p.dx = a->dx; p.dw = a->dw; p.db = a->db;
@@ -247,24 +371,21 @@ extern "C" int lnx_layernorm_bwd(const lnx_ln_bwd_args* a, void* stream) {
     p.dymap = RowMap{a->dy_map.group, a->dy_map.pad, a->dy_map.off};
     p.xmap = RowMap{a->x_map.group, a->x_map.pad, a->x_map.off};
     p.M = a->M; p.C = a->C; p.relu_mask = a->relu_mask;
+    p.part = a->ws;
+    const int64_t wsf = a->ws ? a->ws_floats : 0;
     hipStream_t st = (hipStream_t)stream;
-    int g = cdiv(a->M, 4);
-    if (g > 1024) g = 1024;
-    const dim3 grid(g), block(256);
     const int code = a->dy_dtype * 4 + a->x_dtype * 2 + a->dx_dtype;
-#define LNB(TDY, TX, TDX) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX>), grid, block, 0, st, p)
     switch (code) {
-        case 0: LNB(float, float, float); break;
-        case 1: LNB(float, float, bf16_t); break;
-        case 2: LNB(float, bf16_t, float); break;
-        case 3: LNB(float, bf16_t, bf16_t); break;
-        case 4: LNB(bf16_t, float, float); break;
-        case 5: LNB(bf16_t, float, bf16_t); break;
-        case 6: LNB(bf16_t, bf16_t, float); break;
-        case 7: LNB(bf16_t, bf16_t, bf16_t); break;
+        case 0: launch_bwd<float, float, float>(p, st, wsf); break;
+        case 1: launch_bwd<float, float, bf16_t>(p, st, wsf); break;
+        case 2: launch_bwd<float, bf16_t, float>(p, st, wsf); break;
+        case 3: launch_bwd<float, bf16_t, bf16_t>(p, st, wsf); break;
+        case 4: launch_bwd<bf16_t, float, float>(p, st, wsf); break;
+        case 5: launch_bwd<bf16_t, float, bf16_t>(p, st, wsf); break;
+        case 6: launch_bwd<bf16_t, bf16_t, float>(p, st, wsf); break;
+        case 7: launch_bwd<bf16_t, bf16_t, bf16_t>(p, st, wsf); break;
         default: LNX_CHECK(false, "lnx_layernorm_bwd: bad dtypes");
     }
-#undef LNB
     LNX_LAUNCH_CHECK();
     return 0;
 }

@@ -116,6 +116,7 @@ struct lnx_plan {
     int64_t o_c2n, o_n2_mean, o_n2_rstd, o_agg, o_fin_mean, o_fin_rstd, o_feats, o_featsT;
     int64_t o_g[4];           // fp32 gradient streams per stage
     int64_t o_sA, o_sC, o_sD; // T scratch: [M,4C] / [M,C] / [M,C]
+    int64_t o_lnws = 0, lnws_floats = 0;
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     const float* last_drop = nullptr;
     const unsigned char* last_mask = nullptr;
@@ -565,6 +566,8 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             if (p->logit_ld[t] > maxld) maxld = p->logit_ld[t];
         p->o_dlT = cv.take((int64_t)B * maxld * esz);
     }
+    p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
+    p->o_lnws = cv.take(p->lnws_floats * 4);
     p->o_sA = cv.take(maxM4C * esz);
     p->o_sC = cv.take(maxMC * esz);
     p->o_sD = cv.take(maxMC * esz);
@@ -764,6 +767,8 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     a.dx = dx; a.dx_dtype = dxdt; a.lddx = lddx;
     a.dw = c.p->G[wi]; a.db = c.p->G[bi];
     a.relu_mask = relu ? 1 : 0;
+    a.ws = c.at<float>(c.p->o_lnws);
+    a.ws_floats = c.p->lnws_floats;
     return lnx_layernorm_bwd(&a, c.st);
 }
 

@@ -102,7 +102,7 @@ def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=None, lddx=None, dy_map=None, x_map=None, gin=None,
-                  ldgin=None, dw=None, db=None, relu_mask=False):
+                  ldgin=None, dw=None, db=None, relu_mask=False, ws=None):
     a = L.LnBwdArgs()
     a.M = M if M is not None else dy.shape[0]
     a.C = C_ if C_ is not None else x.shape[-1]
@@ -112,6 +112,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=N
     a.gin, a.ldgin = _p(gin), ((ldgin if ldgin is not None else gin.stride(-2)) if gin is not None else 0)
     a.dx, a.dx_dtype, a.lddx = _p(dx), code_of(dx), (lddx if lddx is not None else dx.stride(-2))
     a.dw, a.db, a.relu_mask = _p(dw), _p(db), int(relu_mask)
+    a.ws, a.ws_floats = _p(ws), (ws.numel() if ws is not None else 0)
     L.check(L.lib().lnx_layernorm_bwd(C.byref(a), _stream()), "lnx_layernorm_bwd")
     return dx
 

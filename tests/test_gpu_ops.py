@@ -42,6 +42,14 @@ def test_layernorm_fwd_bwd(C_, xd, yd):
     dw = torch.zeros(C_, device="cuda")
     db = torch.zeros(C_, device="cuda")
     ops.layernorm_bwd(dy, x, w, mean, rstd, dx, gin=gin, dw=dw, db=db)
+    # same thing through the partial-sum workspace (two-kernel column reduction, no contended atomics)
+    dx2 = torch.empty(M, C_, device="cuda")
+    dw2 = torch.zeros(C_, device="cuda")
+    db2 = torch.zeros(C_, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx2, gin=gin, dw=dw2, db=db2, ws=torch.empty(2048 * 2 * C_, device="cuda"))
+    torch.testing.assert_close(dx2, dx, rtol=0, atol=0)
+    torch.testing.assert_close(dw2, dw, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(db2, db, rtol=1e-5, atol=1e-5)
     ref.backward(dy.double().cpu())
     torch.testing.assert_close(dx.double().cpu(), xr.grad + gin.double().cpu(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dw.double().cpu(), wr.grad, rtol=1e-4, atol=2e-4)
