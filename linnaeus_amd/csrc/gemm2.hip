@@ -1,0 +1,385 @@
+// gemm_nt v2: 256x128 output tile, 8 waves (4x2, each the same 64x64 / 4x4-MFMA wave tile as
+// gemm.hip), bf16 only, K % 64 == 0.
+//
+// What changes against the 128x128 register-staged kernel is the memory pipeline.  That kernel is
+// bound by global-load latency: one tile of prefetch in VGPRs cannot cover ~2 us of loaded-chip
+// latency with 512 cycles of MFMA work.  Here operand tiles go HBM/L2 -> LDS directly
+// (global_load_lds_dwordx4: no VGPRs, no ds_write pass) into a 3-deep ring of 48 KiB stages, two
+// K tiles always in flight behind a COUNTED s_waitcnt vmcnt(6) and a raw s_barrier (a
+// __syncthreads() would drain the queue with vmcnt(0)).  One barrier per K tile:
+//
+//   iteration t:  wait(tile t landed) ; barrier ; issue tile t+2 -> stage (t+2)%3 ; MFMA on stage t%3
+//
+// Stage (t+2)%3 was last read in iteration t-1, and every wave has consumed those reads (its MFMAs
+// need them) before it can arrive at this iteration's barrier, so the refill is WAR-safe.
+// LDS-DMA writes are lane-linear (wave-uniform base + lane*16 B), so the bank-conflict swizzle is
+// applied on the per-lane GLOBAL source address: LDS slot (row, c) receives global chunk
+// c ^ key(row), and fragment reads use the same key (gemm.hip's conflict-free permutation).
+// Rows beyond M / N are clamped to the last valid row (their results are never stored).
+#include "gemm_common.hpp"
+
+namespace lnxg {
+
+// four 16-byte fragment reads at rows +0, +4, +8, +12 (byte offsets 0/512/1024/1536) from one address
+#define DS_READ4(dst, addr)                                                                              \
+    do {                                                                                                 \
+        const uint32_t a_ = (addr);                                                                      \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(a_) : "memory");                         \
+        asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(dst[1]) : "v"(a_) : "memory");              \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(dst[2]) : "v"(a_) : "memory");             \
+        asm volatile("ds_read_b128 %0, %1 offset:1536" : "=v"(dst[3]) : "v"(a_) : "memory");             \
+    } while (0)
+
+constexpr int BM2 = 256, BN2 = 128;
+constexpr int STAGE_BYTES = (BM2 + BN2) * ROWB;  // 48 KiB
+constexpr int NSTAGE = 3;
+constexpr int LD_PER_WAVE = (BM2 + BN2) / 8 / 8;  // 1 KiB wave-instructions per wave per stage = 6
+
+template <bool OUT_F32, bool PATCH>
+__global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmP p) {
+    typedef bf16_t T;
+    constexpr int BK = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NSTAGE][A 256 rows | W 128 rows][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int s = lane & 15, g = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tn = logical % p.tiles_n;
+    const int tm = logical / p.tiles_n;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    // ---- LDS-DMA source addresses: wave w issues wave-instructions i = w + 8 j (j < 6); instruction
+    // i fills LDS rows 8i..8i+7 of the stage (rows 0..255 = A, 256..383 = W), lane -> (row l>>3, slot l&7)
+    const unsigned char* src[LD_PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < LD_PER_WAVE; ++j) {
+        const int i = wave + 8 * j;
+        const int row = 8 * i + (lane >> 3);
+        const int slot = lane & 7;
+        if (row < BM2) {
+            const int chunk = slot ^ row_key(row);
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            const int64_t base = PATCH ? patch_base(p.pg, m) : (int64_t)m * p.lda;
+            // PATCH2: a 16-byte chunk never straddles a (kh) segment because 2*Cin % 8 == 0
+            src[j] = p.A + (base + chunk * 8) * 2;
+        } else {
+            const int wr = row - BM2;
+            const int chunk = slot ^ row_key(wr);
+            int n = n0 + wr;
+            if (n >= p.N) n = p.N - 1;
+            src[j] = p.W + ((int64_t)n * p.ldw + chunk * 8) * 2;
+        }
+    }
+    auto issue_tile = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < LD_PER_WAVE; ++j) {
+            const int i = wave + 8 * j;
+            const unsigned char* gp = src[j];
+            if (PATCH && 8 * i < BM2) {
+                // element offset k -> patch_col(k): add the row jump of the (kh) segment this chunk is in
+                const int slot = lane & 7;
+                const int row = 8 * i + (lane >> 3);
+                const int kk = k0 + ((slot ^ row_key(row)) * 8);
+                gp = src[j] + (patch_col(p.pg, kk) - ((slot ^ row_key(row)) * 8)) * 2;
+            } else {
+                gp += (int64_t)k0 * 2;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    const int frag_row = (s >> 2) * 16 + (s & 3);
+    const int frag_key = ((s >> 1) & 1) | ((s >> 2) << 1);
+    const int a_row0 = wm * 64 + frag_row;
+    const int w_row0 = BM2 + wn * 64 + frag_row;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t ch0 = (uint32_t)((g ^ frag_key) << 4), ch1 = (uint32_t)(((g + 4) ^ frag_key) << 4);
+    const uint32_t a_off0 = a_row0 * ROWB + ch0, a_off1 = a_row0 * ROWB + ch1;
+    const uint32_t w_off0 = w_row0 * ROWB + ch0, w_off1 = w_row0 * ROWB + ch1;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue_tile(kt + 2, (kt + 2) % NSTAGE);
+        // Fragment reads are inline asm on purpose: with compiler-visible LDS loads hipcc puts an
+        // s_waitcnt vmcnt(0) in front of them (it must assume they alias the in-flight LDS-DMA writes),
+        // which would drain the two-tile prefetch every iteration.
+        const uint32_t st = lds_base + (kt % NSTAGE) * STAGE_BYTES;
+        uint4 wf0[4], af0[4], wf1[4], af1[4];
+        DS_READ4(wf0, st + w_off0);
+        DS_READ4(af0, st + a_off0);
+        DS_READ4(wf1, st + w_off1);
+        DS_READ4(af1, st + a_off1);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc[ni][mi], wf0[ni], af0[mi]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc[ni][mi], wf1[ni], af1[mi]);
+    }
+    gemm_epilogue<T, OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+bool nt_v2_ok(const GemmP& p, int dtype) {
+    if (dtype != LNX_BF16) return false;
+    if (p.K % 64 != 0 || p.K < 128) return false;
+    if (p.M < 1024) return false;  // tiny-M GEMMs (tail, meta heads) stay on the 128x128 kernel
+    return true;
+}
+
+int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
+    GemmP p = p0;
+    p.tiles_m = cdiv(p.M, BM2);
+    p.tiles_n = cdiv(p.N, BN2);
+    const int grid = p.tiles_m * p.tiles_n;
+    const size_t lds = NSTAGE * STAGE_BYTES;
+    const bool patch = p.a_mode == LNX_ADDR_PATCH2;
+#define V2_LAUNCH(O, P)                                                                                                              \
+    do {                                                                                                                             \
+        static bool attr = false;                                                                                                    \
+        if (!attr) {                                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<O, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = true;                                                                                                             \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_v2_kernel<O, P>), dim3(grid), dim3(512), lds, st, p);                                            \
+    } while (0)
+    if (out_f32 && patch) V2_LAUNCH(true, true);
+    else if (out_f32) V2_LAUNCH(true, false);
+    else if (patch) V2_LAUNCH(false, true);
+    else V2_LAUNCH(false, false);
+#undef V2_LAUNCH
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// gemm_tn v2: dW[N,K] += dY[M,N]^T . A[M,K] with the same LDS-DMA ring (3 stages of 64
+// contraction rows, two in flight).  R operand = dY (RW output rows), C operand = A (CW output
+// columns), (RW, CW) = (256,128) or (128,256); 8 waves, each a 64x64 output sub-tile.
+// Both operands are contracted over their ROW index, so fragments are read transposed with
+// ds_read_b64_tr_b16; the 16-byte-chunk XOR key (row & 7) << 1 (applied on the DMA source side)
+// makes every 32-lane half of a transposed read hit 16 distinct 16-byte bank slots.
+// Requires bf16, M % 64 == 0, plain (non-patch) A.
+// ------------------------------------------------------------------------------------
+constexpr int TBM = 64;
+
+#define DS_READ_TR2(lo, hi, addr, off2)                                                                                  \
+    do {                                                                                                                 \
+        const uint32_t a_ = (addr);                                                                                      \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a_) : "memory");                                       \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a_), "i"(off2) : "memory");                 \
+    } while (0)
+
+template <int RW, int CW>
+__global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
+    typedef bf16_t T;
+    constexpr int RROW = RW * 2, CROW = CW * 2;            // bytes per LDS row of each tile
+    constexpr int RBYTES = TBM * RROW, CBYTES = TBM * CROW;
+    constexpr int STG = RBYTES + CBYTES;                    // 48 KiB
+    constexpr int RINS = RBYTES / 1024, CINS = CBYTES / 1024;
+    constexpr int NINS = (RINS + CINS) / 8;                 // wave-instructions per wave per stage = 6
+    constexpr int WC = CW / 64;                             // waves along the C operand
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int s = lane & 15, g = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.splits;
+    bid /= p.splits;
+    const int tc = bid % p.tiles_k;
+    const int tr = bid / p.tiles_k;
+    const int n0 = tr * RW, k0 = tc * CW;
+    const int m_begin = split * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+    if (m_begin >= m_end) return;
+    const int ntile = (m_end - m_begin) / TBM;
+
+    const unsigned char* src[NINS];
+    int64_t step[NINS];
+#pragma unroll
+    for (int j = 0; j < NINS; ++j) {
+        const int i = wave + 8 * j;
+        if (i < RINS) {
+            constexpr int CPR = RW / 8, RPI = 64 / CPR;  // chunks per row, rows per wave-instruction
+            const int row = i * RPI + lane / CPR, slot = lane % CPR;
+            int col = n0 + ((slot ^ ((row & 7) << 1)) << 3);
+            const int lim = ((p.N + 7) >> 3) << 3;
+            if (col >= lim) col = lim - 8;
+            src[j] = p.dY + ((int64_t)(m_begin + row) * p.lddy + col) * 2;
+            step[j] = (int64_t)TBM * p.lddy * 2;
+        } else {
+            constexpr int CPR = CW / 8, RPI = 64 / CPR;
+            const int row = (i - RINS) * RPI + lane / CPR, slot = lane % CPR;
+            int col = k0 + ((slot ^ ((row & 7) << 1)) << 3);
+            const int lim = ((p.K + 7) >> 3) << 3;
+            if (col >= lim) col = lim - 8;
+            src[j] = p.A + ((int64_t)(m_begin + row) * p.lda + col) * 2;
+            step[j] = (int64_t)TBM * p.lda * 2;
+        }
+    }
+    auto issue_tile = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < NINS; ++j) {
+            const int i = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[j],
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STG + i * 1024), 16, 0, 0);
+            src[j] += step[j];
+        }
+    };
+
+    // lane-constant fragment offsets (relative to the stage base): transposed block of rows
+    // ks*32 + 4g + q (+16), columns 16 i + 4 pp .. +3 of the wave's 64-column slice
+    const int q = s >> 2, pp = s & 3;
+    uint32_t offR[2][4], offC[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int row = ks * 32 + 4 * g + q;
+        const int key = (row & 7) << 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cr = (wr * 64 + i * 16 + 4 * pp) >> 3, cc = (wc * 64 + i * 16 + 4 * pp) >> 3;
+            offR[ks][i] = row * RROW + ((cr ^ key) << 4) + (pp & 1) * 8;
+            offC[ks][i] = RBYTES + row * CROW + ((cc ^ key) << 4) + (pp & 1) * 8;
+        }
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    f32x4_t acc[4][4], accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.db != nullptr && tc == 0 && wc == 0;
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+
+    issue_tile(0);
+    if (ntile > 1) issue_tile(1);
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < ntile) issue_tile((t + 2) % NSTAGE);
+        const uint32_t st = lds_base + (t % NSTAGE) * STG;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint2 rl[4], rh[4], cl[4], chh[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                DS_READ_TR2(rl[i], rh[i], st + offR[ks][i], 16 * RROW);
+                DS_READ_TR2(cl[i], chh[i], st + offC[ks][i], 16 * CROW);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 rf[4], cf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rf[i] = make_uint4(rl[i].x, rl[i].y, rh[i].x, rh[i].y);
+                cf[i] = make_uint4(cl[i].x, cl[i].y, chh[i].x, chh[i].y);
+            }
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) Mfma<T>::run(acc[ri][ci], rf[ri], cf[ci]);
+            if (do_bias) {
+#pragma unroll
+                for (int ri = 0; ri < 4; ++ri) Mfma<T>::run(accb[ri], rf[ri], ones);
+            }
+        }
+    }
+    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wr * 64 + ri * 16 + 4 * g + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const int k = k0 + wc * 64 + ci * 16 + s;
+                if (k >= p.k_store) continue;
+                int col = k;
+                if (p.k_perm_c > 0) {
+                    const int P = p.K / p.k_perm_c;
+                    const int pq = k / p.k_perm_c;
+                    col = (k - pq * p.k_perm_c) * P + pq;
+                }
+                atomicAdd(p.dW + (int64_t)n * p.lddw + col, acc[ri][ci][r]);
+            }
+            if (do_bias && s == 0) atomicAdd(p.db + n, accb[ri][r]);
+        }
+    }
+}
+
+bool tn_v2_ok(const WgradP& p, int dtype) {
+    return dtype == LNX_BF16 && p.a_mode == LNX_ADDR_PLAIN && p.M % TBM == 0 && p.M >= 4096 && p.N >= 8 && p.K >= 8;
+}
+
+int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
+    WgradP p = p0;
+    // tile orientation with the least padding waste
+    auto waste = [&](int rw, int cw) { return (double)cdiv(p.N, rw) * rw * cdiv(p.K, cw) * cw; };
+    const bool wide_r = waste(256, 128) <= waste(128, 256);
+    const int RW = wide_r ? 256 : 128, CW = wide_r ? 128 : 256;
+    p.tiles_n = cdiv(p.N, RW);
+    p.tiles_k = cdiv(p.K, CW);
+    const int tiles = p.tiles_n * p.tiles_k;
+    const int mtiles = p.M / TBM;
+    int splits = splits_hint;
+    if (splits <= 0) {
+        splits = 256 / tiles;  // the 144 KiB ring allows one workgroup per CU: at most one full round
+        if (splits < 1) splits = 1;
+        const int max_splits = mtiles / 8 > 0 ? mtiles / 8 : 1;  // ... with >= 8 contraction tiles each
+        if (splits > max_splits) splits = max_splits;
+    }
+    if (splits > mtiles) splits = mtiles;
+    if (splits < 1) splits = 1;
+    const int per = cdiv(mtiles, splits);
+    p.m_per_split = per * TBM;
+    p.splits = cdiv(mtiles, per);
+    const int grid = tiles * p.splits;
+    const size_t lds = NSTAGE * (size_t)(TBM * (RW + CW) * 2);
+#define TNV2(R, C)                                                                                                                   \
+    do {                                                                                                                             \
+        static bool attr = false;                                                                                                    \
+        if (!attr) {                                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<R, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = true;                                                                                                             \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<R, C>), dim3(grid), dim3(512), lds, st, p);                                            \
+    } while (0)
+    if (wide_r) TNV2(256, 128);
+    else TNV2(128, 256);
+#undef TNV2
+    return 0;
+}
+
+}  // namespace lnxg

@@ -1,0 +1,225 @@
+// Shared pieces of the MFMA GEMM kernels (gemm.hip: 128x128 register-staged kernels for both
+// storage types; gemm2.hip: 256x128 LDS-DMA pipelined bf16 kernel).
+#pragma once
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace lnxg {
+
+constexpr int TILE = 128;        // rows of each operand tile
+constexpr int ROWB = 128;        // bytes of K per tile row
+constexpr int TILE_BYTES = TILE * ROWB;
+
+struct PatchGeom {
+    int Hin, Win, Cin;
+};
+
+struct GemmP {
+    const unsigned char* A;
+    const unsigned char* W;
+    unsigned char* C;
+    unsigned char* C2;
+    const unsigned char* aux;
+    const float* bias;
+    const float* gamma;
+    const float* rowscale;
+    const float* res;
+    int64_t lda, ldw, ldc, ldc2, ldaux, ldres;
+    int M, N, K;
+    int a_mode, c_mode;
+    PatchGeom pg;
+    RowMap cmap;
+    int act;
+    int rows_per_sample;
+    int tiles_m, tiles_n;
+};
+
+// XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on
+// the same XCD (blocks b and b+8 share an XCD under round-robin dispatch) so that the
+// n-tiles that re-read one A panel hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// 3-bit XOR key of an LDS tile row; chosen so that the permuted fragment reads below
+// (rows {0..3,16..19,32..35,48..51}+4i per 16-lane group) are bank-conflict free.
+__device__ __forceinline__ int row_key(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mfma<float> {
+    static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+        const float* fa = reinterpret_cast<const float*>(&a);
+        const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc, 0, 0, 0);
+    }
+};
+
+// element offset of the 2x2 patch origin of output pixel m in an NHWC tensor
+__device__ __forceinline__ int64_t patch_base(const PatchGeom& g, int m) {
+    const int Wo = g.Win >> 1, Ho = g.Hin >> 1;
+    const int wo = m % Wo;
+    const int t = m / Wo;
+    const int ho = t % Ho;
+    const int b = t / Ho;
+    return (((int64_t)b * g.Hin + 2 * ho) * g.Win + 2 * wo) * g.Cin;
+}
+// offset inside a patch for patch-column k = (kh*2 + kw)*Cin + c
+__device__ __forceinline__ int64_t patch_col(const PatchGeom& g, int k) {
+    const int two_c = 2 * g.Cin;
+    const int kh = k / two_c;
+    return (int64_t)kh * g.Win * g.Cin + (k - kh * two_c);
+}
+
+// Shared epilogue: the wave's 64x64 sub-tile starts at (mrow0, ncol0); lane (s, g) holds, for each
+// mi, 16 consecutive n of row m (see the orientation note in gemm.hip).
+template <typename T, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][4], int mrow0, int ncol0, int lane) {
+    constexpr int EPV = TT<T>::EPV;
+    const int s = lane & 15, g = lane >> 4;
+    const int nb = ncol0 + g * 16;  // first n of this lane
+    if (nb >= p.N) return;
+    const int nvalid = min(16, p.N - nb);
+    float bias[16], gam[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        bias[j] = (p.bias && j < nvalid) ? p.bias[nb + j] : 0.f;
+        gam[j] = (p.gamma && j < nvalid) ? p.gamma[nb + j] : 1.f;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mrow0 + (s >> 2) * 16 + mi * 4 + (s & 3);
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[ni][mi][r] + bias[ni * 4 + r];
+        if (p.C2) {
+            T* c2 = reinterpret_cast<T*>(p.C2) + (int64_t)m * p.ldc2 + nb;
+            if (nvalid == 16 && ((((uintptr_t)c2) & 15) == 0)) {
+                Vec16<T> o;
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                    st16(c2 + h * EPV, o.raw);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) c2[j] = from_f<T>(v[j]);
+            }
+        }
+        if (p.act == LNX_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
+        } else if (p.act == LNX_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD) {
+            const T* ax = reinterpret_cast<const T*>(p.aux) + (int64_t)m * p.ldaux + nb;
+            float a[16];
+            if (nvalid == 16 && ((((uintptr_t)ax) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+                    Vec16<T> t;
+                    t.raw = ld16(ax + h * EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) a[h * EPV + j] = t.get(j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] = j < nvalid ? to_f(ax[j]) : 0.f;
+            }
+            if (p.act == LNX_ACT_GELU_BWD) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(a[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
+            }
+        }
+        float rs = 1.f;
+        if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] *= gam[j] * rs;
+
+        int64_t coff;  // element offset of (m, nb) in C / res
+        int64_t roff;
+        if (p.c_mode == LNX_ADDR_PATCH2) {
+            coff = patch_base(p.pg, m) + patch_col(p.pg, nb);
+            roff = coff;
+        } else {
+            const int64_t row = map_row(p.cmap, m);
+            coff = row * p.ldc + nb;
+            roff = row * p.ldres + nb;
+        }
+        if (p.res) {
+            const float* rp = p.res + roff;
+            if (nvalid == 16 && ((((uintptr_t)rp) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
+                    v[4 * h + 0] += t.x;
+                    v[4 * h + 1] += t.y;
+                    v[4 * h + 2] += t.z;
+                    v[4 * h + 3] += t.w;
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) v[j] += rp[j];
+            }
+        }
+        if (OUT_F32) {
+            float* cp = reinterpret_cast<float*>(p.C) + coff;
+            if (nvalid == 16 && ((((uintptr_t)cp) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(cp + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            } else {
+                for (int j = 0; j < nvalid; ++j) cp[j] = v[j];
+            }
+        } else {
+            T* cp = reinterpret_cast<T*>(p.C) + coff;
+            if (nvalid == 16 && ((((uintptr_t)cp) & 15) == 0)) {
+                Vec16<T> o;
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                    st16(cp + h * EPV, o.raw);
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) cp[j] = from_f<T>(v[j]);
+            }
+        }
+    }
+}
+
+struct WgradP {
+    const unsigned char* dY;
+    const unsigned char* A;
+    float* dW;
+    float* db;
+    int64_t lddy, lda, lddw;
+    int M, N, K;
+    int a_mode;
+    PatchGeom pg;
+    int k_perm_c, k_store;
+    int dbg;  // benchmarking only: 1 = skip the atomic epilogue
+    int tiles_n, tiles_k, splits, m_per_split;
+};
+
+// gemm2.hip: 256x128 LDS-DMA pipelined kernels (bf16)
+int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);
+bool nt_v2_ok(const GemmP& p, int dtype);
+int launch_tn_v2(const WgradP& p, int splits_hint, hipStream_t st);
+bool tn_v2_ok(const WgradP& p, int dtype);
+
+}  // namespace lnxg
+using namespace lnxg;

@@ -40,7 +40,7 @@ def run_nt(A, W, dtype, out_f32, bias=None, act=0, aux=None, gamma=None, rowscal
     return out, c2
 
 
-SHAPES = [(128, 128, 64), (256, 384, 96), (200, 96, 384), (333, 1000, 768), (64, 20, 768), (1, 7, 32), (777, 1152, 384)]
+SHAPES = [(2000, 384, 384), (4096, 1536, 384), (1300, 96, 1536), (1024, 1000, 768), (5000, 200, 128), (128, 128, 64), (256, 384, 96), (200, 96, 384), (333, 1000, 768), (64, 20, 768), (1, 7, 32), (777, 1152, 384)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -120,11 +120,12 @@ def _patches_nhwc(x):  # x [B,H,W,C] -> [B*Ho*Wo, 4C] with k = (kh*2+kw)*C + c
     return p.reshape(B * (H // 2) * (W // 2), 4 * Cc)
 
 
+@pytest.mark.parametrize("small", [True, False])
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
-def test_nt_patch2_modes(dtype):
+def test_nt_patch2_modes(dtype, small):
     tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
     g = torch.Generator().manual_seed(11)
-    B, H, Wd, Cc, N = 2, 6, 10, 32, 48
+    B, H, Wd, Cc, N = (2, 6, 10, 32, 48) if small else (3, 40, 36, 64, 200)
     x = torch.randn(B, H, Wd, Cc, generator=g).cuda().to(tdt)
     W = (torch.randn(N, 4 * Cc, generator=g) / (4 * Cc) ** 0.5).cuda().to(tdt)
     M = B * (H // 2) * (Wd // 2)
@@ -171,7 +172,7 @@ def run_tn(dY, A, dtype, bias=True, splits=0, k_perm_c=0, patch=None):
     return dW, db
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 96, 384), (5000, 384, 96), (199, 1152, 384), (77, 24, 16), (4096, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(8192, 96, 384), (6400, 1000, 768), (4096, 384, 96), (12800, 384, 1536), (256, 128, 128), (1000, 96, 384), (5000, 384, 96), (199, 1152, 384), (77, 24, 16), (4096, 768, 3072)])
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_tn(M, N, K, dtype):
     tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
@@ -214,3 +215,25 @@ def test_tn_patch2_conv_weight_layout(dtype):
     y = torch.nn.functional.conv2d(xn, w, stride=2)
     y.backward(dY.double().view(B, H // 2, Wd // 2, N).permute(0, 3, 1, 2))
     torch.testing.assert_close(dW.double().view(N, Cc, 2, 2), w.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M", [4096, 640])
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_tn_padded_logits_rows(M, dtype):
+    """dY rows padded to a multiple of 8 (N = 300 classes in 304 columns), as the head wgrad uses."""
+    tdt = torch.float32 if dtype == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(M)
+    N, K = 300, 768
+    buf = torch.zeros(M, 304, device="cuda", dtype=tdt)
+    buf[:, :N] = torch.randn(M, N, generator=g).cuda().to(tdt)
+    dY = buf[:, :N]
+    A = torch.randn(M, K, generator=g).cuda().to(tdt)
+    dW = torch.zeros(N, K, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    a = L.WgradArgs()
+    a.dtype, a.M, a.N, a.K = dtype, M, N, K
+    a.dY, a.lddy, a.A, a.lda, a.dW, a.lddw, a.db = _ptr(dY), 304, _ptr(A), K, _ptr(dW), K, _ptr(db)
+    L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dW.double(), dY.double().T @ A.double(), rtol=1e-4, atol=2e-5 * M**0.5)
+    torch.testing.assert_close(db.double(), dY.double().sum(0), rtol=1e-4, atol=2e-5 * M**0.5)

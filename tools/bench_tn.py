@@ -1,0 +1,23 @@
+import ctypes as C, sys, torch
+sys.path.insert(0, ".")
+from linnaeus_amd import _lib as L
+def ptr(t): return C.c_void_p(t.data_ptr())
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def time_it(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+for name, M, N, K in [("r0.fc1", 50944, 1536, 384), ("r0.fc2", 50944, 384, 1536), ("r0.proj", 50944, 384, 384), ("r1.fc1", 13312, 3072, 768), ("s0.pw1", 802816, 384, 96), ("s1.pw2", 200704, 192, 768)]:
+    A = torch.randn(M, K, device="cuda").bfloat16(); dY = torch.randn(M, N, device="cuda").bfloat16()
+    dW = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    res = []
+    for splits in (0, 1, 2, 4, 8, 16, 32, 64):
+        w = L.WgradArgs(); w.dtype, w.M, w.N, w.K = L.BF16, M, N, K
+        w.dY, w.lddy, w.A, w.lda, w.dW, w.lddw, w.db, w.splits = ptr(dY), N, ptr(A), K, ptr(dW), K, ptr(db), splits
+        t = time_it(lambda: L.check(L.lib().lnx_gemm_tn(C.byref(w), st()), "tn"))
+        res.append(f"s{splits}:{t*1e6:.0f}us/{2.0*M*N*K/t/1e12:.0f}TF")
+    print(name, " ".join(res), flush=True)
