@@ -193,7 +193,7 @@ def main():
 
         lib = L.lib()
         st = model._active
-        NC = 6
+        NC = 8
         L.check(lib.lnx_plan_profile_begin(st["handle"]), "profile_begin")
         hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
         for _ in range(args.profile_steps):
@@ -205,13 +205,13 @@ def main():
         work = (C.c_double * NC)()
         cnt = (C.c_int * NC)()
         L.check(lib.lnx_plan_profile_end(st["handle"], ms, work, cnt), "profile_end")
-        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad"]
+        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
         for i, nm in enumerate(names):
             if cnt[i] == 0:
                 continue
             per = {"ms_per_step": round(ms[i] / args.profile_steps, 4), "launches_per_step": cnt[i] // args.profile_steps,
                    "avg_launch_us": round(ms[i] * 1e3 / cnt[i], 2)}
-            if i < 4:
+            if i < 4 or i >= 6:
                 per["tflops"] = round(work[i] / (ms[i] * 1e-3) / 1e12, 2)
             else:
                 per["gbs"] = round(work[i] / (ms[i] * 1e-3) / 1e9, 1)

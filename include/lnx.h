@@ -273,6 +273,50 @@ int lnx_prep_weights(const lnx_prep_desc* descs_dev, int ndesc, int total_blocks
 int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t);
 
 
+
+/* ------------------------------------------------------------------------------------
+ * Fused ConvNeXt MLP branch (bf16 storage, C in {32,64,96,128,192}):
+ *   out = x + rowscale * gamma * (GELU(ln . W1^T + b1) . W2^T + b2)
+ * = pwconv1 -> GELU -> pwconv2 -> LayerScale -> DropPath -> residual (blocks/convnext.py:79-86)
+ * with the 4C hidden activation kept on chip; the backward recomputes it per tile.
+ * -----------------------------------------------------------------------------------*/
+int lnx_convmlp_supported(int dtype, int C);
+typedef struct lnx_convmlp_args {
+    int dtype, M, C;
+    const void* ln;        /* [M, C] bf16 (block LayerNorm output) */
+    const void* w1;        /* [4C, C] bf16 pwconv1.weight */
+    const float* b1;       /* [4C] */
+    const void* w2;        /* [C, 4C] bf16 pwconv2.weight */
+    const float* b2;       /* [C] */
+    const float* gamma;    /* [C] */
+    const float* rowscale; /* per-sample DropPath multiplier or NULL */
+    int rows_per_sample;
+    const float* x;        /* [M, C] fp32 residual input */
+    float* out;            /* [M, C] fp32 */
+    void* z;               /* optional [M, C] bf16: pwconv2 output before gamma (for the gamma gradient) */
+} lnx_convmlp_args;
+int lnx_convmlp_fwd(const lnx_convmlp_args* args, void* stream);
+
+typedef struct lnx_convmlp_bwd_args {
+    int dtype, M, C;
+    const float* g;        /* [M, C] fp32 gradient of the block output */
+    const void* ln;        /* [M, C] bf16 */
+    const void* z;         /* [M, C] bf16 saved by the forward */
+    const void* w1;        /* [4C, C] bf16 */
+    const float* b1;
+    const void* w2t;       /* [4C, C] bf16 = pwconv2.weight^T */
+    const void* w1t;       /* [C, 4C] bf16 = pwconv1.weight^T */
+    const float* gamma;
+    const float* rowscale;
+    int rows_per_sample;
+    void* act;             /* out [M, 4C] bf16  GELU(h)   (operand of the pwconv2 weight gradient) */
+    void* dh;              /* out [M, 4C] bf16  dL/dh     (operand of the pwconv1 weight gradient) */
+    void* dz;              /* out [M, C]  bf16  rowscale*gamma*g */
+    void* dln;             /* out [M, C]  bf16  gradient wrt the LayerNorm output */
+    float* dgamma;         /* [C] += */
+} lnx_convmlp_bwd_args;
+int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Whole-model plan: mFormerV1 forward and backward as one native call each.
  * Replaces mFormerV1.forward_features/forward (models/mFormerV1.py:407-541) and its
@@ -328,9 +372,9 @@ int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, in
 /* Live per-kernel-class timing with HIP events on the launch stream (used by bench.py for the
  * roofline line; adds event records around the timed launches, so never leave it on in a timed
  * region).  Classes: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd (both kernels),
- * 4 depthwise conv fwd / data-grad, 5 depthwise conv weight-grad.  work = FLOPs for 0-3,
- * algorithmic HBM bytes for 4-5. */
-#define LNX_PROFILE_CLASSES 6
+ * 4 depthwise conv fwd / data-grad, 5 depthwise conv weight-grad, 6 fused conv-MLP forward,
+ * 7 fused conv-MLP backward.  work = FLOPs for 0-3 and 6-7, algorithmic HBM bytes for 4-5. */
+#define LNX_PROFILE_CLASSES 8
 int lnx_plan_profile_begin(lnx_plan* p);
 int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
 /* indices of the parameters whose gradient is final after `segment`; returns their count */

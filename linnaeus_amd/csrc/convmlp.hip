@@ -1,0 +1,844 @@
+// Fused ConvNeXt MLP branch for gfx950 (bf16 storage):
+//
+//   forward   out = x + rowscale * gamma * ( GELU(ln . W1^T + b1) . W2^T + b2 )
+//             (blocks/convnext.py:79-86: pwconv1 -> GELU -> pwconv2 -> LayerScale -> DropPath -> +x)
+//   backward  recomputes h = ln . W1^T + b1 per tile, then
+//             dz = rowscale*gamma*g ; dgamma += sum rowscale*g*z ; dA = dz . W2 ; dH = dA * GELU'(h) ;
+//             dln = dH . W1 ; and writes act = GELU(h), dH, dz for the weight-gradient GEMMs.
+//
+// Why: at C = 96/192 the two pointwise GEMMs are HBM-bound (arithmetic intensity far below the
+// ridge); unfused, the 4C-wide hidden tensor is written twice and read back twice in the forward
+// alone.  Here the hidden activation never leaves the chip in the forward, and in the backward it
+// is produced once (recompute is ~K=C cheap) instead of saved.
+//
+// Structure: a 256-thread workgroup owns MT*64 rows (wave = MT m-tiles of 16 rows); the rows'
+// ln fragments stay in registers for the whole kernel.  The hidden dimension is walked in chunks
+// of 64: the chunk's weight slices arrive by LDS-DMA into a 2-stage ring (prefetch chunk j+1
+// under chunk j's MFMAs), the first product is computed TRANSPOSED with a row-slot permutation of
+// the weight rows such that its accumulator (after bias+GELU, packed to bf16) is directly the
+// B operand of the second product in natural k order -- the hidden tile never touches LDS.
+// Weight tiles are laid out [k-step][row][64 B] with the 16-byte unit XOR-swizzled by a 2-bit
+// row key (applied on the DMA source address) so every ds_read_b128 group is conflict-free.
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+struct CmP {
+    const unsigned char* ln;
+    const unsigned char* w1;    // [4C, C]
+    const unsigned char* w2;    // fwd: [C, 4C]
+    const unsigned char* w2t;   // bwd: [4C, C]
+    const unsigned char* w1t;   // bwd: [C, 4C]
+    const unsigned char* zin;   // bwd: [M, C]
+    const float* b1;
+    const float* b2;
+    const float* gamma;
+    const float* rowscale;
+    const float* x;
+    const float* g;
+    float* out;
+    unsigned char* z;           // fwd: optional [M, C]
+    unsigned char* act;         // bwd out [M, 4C]
+    unsigned char* dh;          // bwd out [M, 4C]
+    unsigned char* dz;          // bwd out [M, C]
+    unsigned char* dln;         // bwd out [M, C]
+    float* dgamma;
+    int M, C, rps;
+};
+
+__device__ __forceinline__ void mfma16(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+
+// swizzle key of a weight-tile row, table {0, 3, 2, 1}: the four rows of one bank class (rows 4 apart
+// share the same four 16-byte bank slots) get distinct slots in every ds_read_b128 lane group
+__device__ __forceinline__ int key4(int a) { return (4 - (a & 3)) & 3; }
+
+// Exact-erf GELU on the VALU with as few instructions as possible (the fused kernels are bound by
+// VALU issue, not by MFMA or HBM).  erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
+//   y = 0.5 * erfc(|v|/sqrt2) = 0.5 * (a1 t + ... + a5 t^5) * exp(-v^2/2),  t = 1/(1 + p |v|/sqrt2)
+//   Phi(v) = v >= 0 ? 1 - y : y      GELU(v) = v Phi(v) = max(v, 0) - |v y|
+// with u = |v| * sqrt(log2(e)/2) so that exp(-v^2/2) = exp2(-u^2) is one v_exp_f32, and 1/x one v_rcp_f32.
+// 15 VALU instructions (two of them transcendental) per element.
+struct GeluTerms {
+    float y;  // 0.5 * erfc(|v|/sqrt2)
+    float e;  // exp(-v^2/2)
+};
+__device__ __forceinline__ GeluTerms gelu_terms(float v) {
+    constexpr float K = 0.84932180028801904272f;            // sqrt(log2(e) / 2)
+    constexpr float P1 = 0.3275911f * 0.70710678118654752f / K;
+    const float u = fabsf(v) * K;
+    const float t = __builtin_amdgcn_rcpf(fmaf(P1, u, 1.0f));
+    GeluTerms r;
+    r.e = __builtin_amdgcn_exp2f(-(u * u));
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    r.y = poly * t * r.e;
+    return r;
+}
+__device__ __forceinline__ float gelu_lean(float v) {
+    const GeluTerms g = gelu_terms(v);
+    return fmaxf(v, 0.f) - fabsf(v * g.y);
+}
+// act = GELU(v), dgelu = Phi(v) + v phi(v)
+__device__ __forceinline__ void gelu_lean_grad(float v, float& act, float& dgelu) {
+    const GeluTerms g = gelu_terms(v);
+    act = fmaxf(v, 0.f) - fabsf(v * g.y);
+    const float cdf = 0.5f + copysignf(0.5f - g.y, v);
+    dgelu = fmaf(v * 0.39894228040143267794f, g.e, cdf);
+}
+
+#define CM_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
+
+// bytes of one weight part (W1 slice [NK][64][64B] == W2 slice [2][C][64B]) for NK = C/32
+template <int NK> struct Geo {
+    static constexpr int C = 32 * NK;
+    static constexpr int PART = NK * 4096;
+    static constexpr int CT = C / 16;           // c tiles
+};
+
+// issue the DMA of one "n-major" part: rows = 64 hidden units (n0..n0+63), columns = C channels;
+// source matrix [4C, C] row-major.  LDS image [ks][row][4 units]; unit u' holds source unit u' ^ key4(row>>3)
+template <int NK>
+__device__ __forceinline__ void dma_nmajor(unsigned char* lds_part, const unsigned char* W, int n0, int wave, int lane) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int NINS = 4 * NK;  // 1 KiB instructions
+#pragma unroll
+    for (int t = 0; t < NINS / 4; ++t) {
+        const int i = wave + 4 * t;
+        const int ks = i >> 2, rb = i & 3;
+        const int row = 16 * rb + (lane >> 2), u = lane & 3;
+        const unsigned char* src = W + ((int64_t)(n0 + row) * C + ks * 32 + ((u ^ key4(row >> 3)) << 3)) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_part + i * 1024), 16, 0, 0);
+    }
+}
+
+// issue the DMA of one "c-major" part: rows = C channels, columns = 64 hidden units (n0..n0+63);
+// source matrix [C, 4C] row-major.  LDS image [ks2][c][4 units]; unit u' holds source unit u' ^ key4(c>>2)
+template <int NK>
+__device__ __forceinline__ void dma_cmajor(unsigned char* lds_part, const unsigned char* W, int n0, int wave, int lane) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int RB = C / 16;
+    constexpr int NINS = 2 * RB;  // == 4 NK
+#pragma unroll
+    for (int t = 0; t < NINS / 4; ++t) {
+        const int i = wave + 4 * t;
+        const int ks2 = i / RB, rb = i % RB;
+        const int row = 16 * rb + (lane >> 2), u = lane & 3;
+        const unsigned char* src = W + ((int64_t)row * (4 * C) + n0 + ks2 * 32 + ((u ^ key4(row >> 2)) << 3)) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_part + i * 1024), 16, 0, 0);
+    }
+}
+
+// first-kind product:  H^T[n][m] = sum_k Wn[n][k] * X[m][k]   (n: 64 permuted rows of an n-major part)
+template <int NK, int MT>
+__device__ __forceinline__ void prod_nmajor(f32x4_t (&h)[4][MT], uint32_t part_addr, int s, int g, const uint4 (&xf)[MT][NK]) {
+    // fragment row of tile nt for lane s: 32(nt>>1) + 8(s>>2) + 4(nt&1) + (s&3); unit g ^ key4(row>>3) = g ^ key4(s>>2)
+    const uint32_t unit = (uint32_t)((g ^ key4(s >> 2)) << 4);
+    const uint32_t base = part_addr + (uint32_t)((8 * (s >> 2) + (s & 3)) * 64) + unit;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) h[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        uint4 wf[4];
+        const uint32_t a = base + ks * 4096;
+        CM_DS_READ128(wf[0], a, 0);      // nt = 0: row offset 0
+        CM_DS_READ128(wf[1], a, 256);    // nt = 1: +4 rows
+        CM_DS_READ128(wf[2], a, 2048);   // nt = 2: +32 rows
+        CM_DS_READ128(wf[3], a, 2304);   // nt = 3: +36 rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mfma16(h[nt][mt], wf[nt], xf[mt][ks]);
+    }
+}
+
+// second-kind product:  O^T[c][m] += sum_n Wc[c][n] * P[n][m]   (n over the chunk's 64 hidden units)
+template <int NK, int MT>
+__device__ __forceinline__ void prod_cmajor(f32x4_t (&o)[Geo<NK>::CT][MT], uint32_t part_addr, int s, int g, const uint4 (&pf)[MT][2]) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    // row c = 16 ct + s ; unit g ^ key4(c>>2) = g ^ key4(s>>2)  (16 ct does not change (c>>2)&3)
+    const uint32_t base = part_addr + (uint32_t)(s * 64) + (uint32_t)((g ^ key4(s >> 2)) << 4);
+    constexpr int GB = CT % 6 == 0 ? 6 : (CT % 4 == 0 ? 4 : CT);  // fragment reads per batch (one wait per batch)
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+#pragma unroll
+        for (int c0 = 0; c0 < CT; c0 += GB) {
+            uint4 wf[GB];
+#pragma unroll
+            for (int b = 0; b < GB; ++b) {
+                const uint32_t a = base + (uint32_t)(ks2 * C * 64 + (c0 + b) * 1024);
+                CM_DS_READ128(wf[b], a, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < GB; ++b)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mfma16(o[c0 + b][mt], wf[b], pf[mt][ks2]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
+    Vec16<bf16_t> v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v.set(j, lo[j]);
+        v.set(4 + j, hi[j]);
+    }
+    return v.raw;
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+template <int NK, int MT>
+__global__ __launch_bounds__(256) void convmlp_fwd_kernel(const CmP p) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    constexpr int PART = Geo<NK>::PART;
+    constexpr int STAGE = 2 * PART;
+    constexpr int NCH = 4 * C / 64;
+    constexpr int NLD = 2 * NK;  // DMA instructions per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][W1 part | W2 part] + b1 [4C floats]
+    float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const int m_base = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    for (int i = threadIdx.x; i < 4 * C; i += 256) b1s[i] = p.b1[i];
+
+    // this lane's ln fragments: row m (clamped), channels ks*32 + 8g .. +7
+    uint4 xf[MT][NK];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_base + mt * 16 + s;
+        if (m >= p.M) m = p.M - 1;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+    }
+    f32x4_t o[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) o[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();  // b1s staged (plain LDS stores) before any LDS-DMA is in flight
+    dma_nmajor<NK>(smem, p.w1, 0, wave, lane);
+    dma_cmajor<NK>(smem + PART, p.w2, 0, wave, lane);
+    for (int j = 0; j < NCH; ++j) {
+        const int stg = j & 1;
+        __builtin_amdgcn_s_barrier();  // everyone is done reading stage stg^1 (chunk j-1); b1s visible (j = 0)
+        if (j + 1 < NCH) {
+            dma_nmajor<NK>(smem + (stg ^ 1) * STAGE, p.w1, 64 * (j + 1), wave, lane);
+            dma_cmajor<NK>(smem + (stg ^ 1) * STAGE + PART, p.w2, 64 * (j + 1), wave, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // chunk j's slices have landed for every wave
+        const uint32_t st = lds0 + stg * STAGE;
+        f32x4_t h[4][MT];
+        prod_nmajor<NK, MT>(h, st, s, g, xf);
+        // bias + exact-erf GELU on the accumulator; row 4g+r of tile nt <-> hidden n = 64j + 32(nt>>1) + 8g + 4(nt&1) + r
+        uint4 pf[MT][2];
+        {
+            f32x4_t bv[4];
+            const uint32_t ba = lds0 + 2 * STAGE + (uint32_t)((64 * j + 8 * g) * 4);
+            CM_DS_READ128(bv[0], ba, 0);
+            CM_DS_READ128(bv[1], ba, 16);
+            CM_DS_READ128(bv[2], ba, 128);
+            CM_DS_READ128(bv[3], ba, 144);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[nt][mt][r] = gelu_lean(h[nt][mt][r] + bv[nt][r]);
+                    }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                pf[mt][0] = pack8(h[0][mt], h[1][mt]);
+                pf[mt][1] = pack8(h[2][mt], h[3][mt]);
+            }
+        }
+        prod_cmajor<NK, MT>(o, st + PART, s, g, pf);
+    }
+    // epilogue: lane (s = row m, g) holds channels c = 16 ct + 4 g + r
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + s;
+        if (m >= p.M) continue;
+        const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + 4 * g;
+            const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + c);
+            const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c);
+            const float4 xr = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + c);
+            const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
+            if (p.z) {
+                uint2 zz;
+                bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
+                zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
+                *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
+            }
+            *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
+                make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward (data side): act, dH, dz, dln, dgamma
+// ------------------------------------------------------------------------------------
+template <int NK, int MT>
+__global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    constexpr int PART = Geo<NK>::PART;
+    constexpr int STAGE = 3 * PART;  // W1 slice | W2^T slice | W1^T slice
+    constexpr int NCH = 4 * C / 64;
+    constexpr int NLD = 3 * NK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    float* dgs = b1s + 4 * C;  // [C] per-workgroup dgamma partial
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const int m_base = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    for (int i = threadIdx.x; i < 4 * C; i += 256) b1s[i] = p.b1[i];
+    for (int i = threadIdx.x; i < C; i += 256) dgs[i] = 0.f;
+    __syncthreads();
+
+    uint4 xf[MT][NK], zf[MT][NK];  // ln fragments; dz = rowscale*gamma*g fragments (bf16)
+    bool mvalid[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int m = m_base + mt * 16 + s;
+        mvalid[mt] = m < p.M;
+        if (!mvalid[mt]) m = p.M - 1;
+        const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = ks * 32 + 8 * g;
+            xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
+            const float4 g0 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
+            const float4 g1 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(p.gamma + c);
+            const float4 a1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+            Vec16<bf16_t> zin, dzv;
+            zin.raw = ld16(p.zin + ((int64_t)m * C + c) * 2);
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sg = mvalid[mt] ? rs * gv[j] : 0.f;
+                dzv.set(j, sg * av[j]);
+                // dgamma partial: this lane's 8 channels of its row; reduced over rows below
+                const float dgp = sg * zin.get(j);
+                // sum over the 16 rows (lanes s) of this m-tile that share g: xor-shuffle over the low 4 lane bits
+                float t = dgp;
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                t += __shfl_xor(t, 8, 64);
+                if (s == 0) atomicAdd(&dgs[c + j], t);  // LDS atomic, 4 lanes per wave
+            }
+            zf[mt][ks] = dzv.raw;
+            if (mvalid[mt]) st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+        }
+    }
+    f32x4_t dl[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();
+    dma_nmajor<NK>(smem, p.w1, 0, wave, lane);
+    dma_nmajor<NK>(smem + PART, p.w2t, 0, wave, lane);
+    dma_cmajor<NK>(smem + 2 * PART, p.w1t, 0, wave, lane);
+    for (int j = 0; j < NCH; ++j) {
+        const int stg = j & 1;
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < NCH) {
+            unsigned char* nx = smem + (stg ^ 1) * STAGE;
+            dma_nmajor<NK>(nx, p.w1, 64 * (j + 1), wave, lane);
+            dma_nmajor<NK>(nx + PART, p.w2t, 64 * (j + 1), wave, lane);
+            dma_cmajor<NK>(nx + 2 * PART, p.w1t, 64 * (j + 1), wave, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const uint32_t st = lds0 + stg * STAGE;
+        f32x4_t h[4][MT], da[4][MT];
+        prod_nmajor<NK, MT>(h, st, s, g, xf);          // h  = ln . W1^T   (pre-bias)
+        prod_nmajor<NK, MT>(da, st + PART, s, g, zf);  // dA = dz . W2
+        f32x4_t bv[4];
+        const uint32_t ba = lds0 + 2 * STAGE + (uint32_t)((64 * j + 8 * g) * 4);
+        CM_DS_READ128(bv[0], ba, 0);
+        CM_DS_READ128(bv[1], ba, 16);
+        CM_DS_READ128(bv[2], ba, 128);
+        CM_DS_READ128(bv[3], ba, 144);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float act, dg;
+                    gelu_lean_grad(h[nt][mt][r] + bv[nt][r], act, dg);
+                    h[nt][mt][r] = act;        // act = GELU(h)
+                    da[nt][mt][r] *= dg;       // dH = dA * GELU'(h)
+                }
+        uint4 pa[MT][2], pd[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            pa[mt][0] = pack8(h[0][mt], h[1][mt]);
+            pa[mt][1] = pack8(h[2][mt], h[3][mt]);
+            pd[mt][0] = pack8(da[0][mt], da[1][mt]);
+            pd[mt][1] = pack8(da[2][mt], da[3][mt]);
+            // packed element j of k-step ks2 <-> hidden n = 64 j_chunk + 32 ks2 + 8 g + j : 16 contiguous bytes per row
+            const int m = m_base + mt * 16 + s;
+            if (m < p.M) {
+                const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
+                st16(p.act + off, pa[mt][0]);
+                st16(p.act + off + 64, pa[mt][1]);
+                st16(p.dh + off, pd[mt][0]);
+                st16(p.dh + off + 64, pd[mt][1]);
+            }
+        }
+        prod_cmajor<NK, MT>(dl, st + 2 * PART, s, g, pd);  // dln += dH . W1
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + s;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + 4 * g;
+            uint2 v;
+            bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+            vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
+            *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(p.dgamma + i, dgs[i]);
+}
+
+
+// ------------------------------------------------------------------------------------
+// Weight-resident persistent variants for C <= 96 (the whole W1 and W2 / W2^T fit in LDS:
+// 2 * 4C * C * 2 B = 144 KiB at C = 96).  One 512-thread workgroup per CU loads the weights once,
+// then its 8 waves stream 32-row tiles independently with NO barrier in the main loop, so the two
+// waves of a SIMD drift apart and one wave's GELU VALU work runs under the other's MFMAs.
+// ------------------------------------------------------------------------------------
+template <int NK>
+__device__ __forceinline__ void dma_all_nmajor(unsigned char* img, const unsigned char* W, int wave, int lane) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int NCH = 4 * C / 64;
+    constexpr int NINS = 4 * NK;
+    for (int q = wave; q < NCH * NINS; q += 8) {
+        const int j = q / NINS, i = q % NINS;
+        const int ks = i >> 2, rb = i & 3;
+        const int row = 16 * rb + (lane >> 2), u = lane & 3;
+        const unsigned char* src = W + ((int64_t)(64 * j + row) * C + ks * 32 + ((u ^ key4(row >> 3)) << 3)) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(img + j * Geo<NK>::PART + i * 1024), 16, 0, 0);
+    }
+}
+template <int NK>
+__device__ __forceinline__ void dma_all_cmajor(unsigned char* img, const unsigned char* W, int wave, int lane) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int NCH = 4 * C / 64;
+    constexpr int RB = C / 16;
+    constexpr int NINS = 2 * RB;
+    for (int q = wave; q < NCH * NINS; q += 8) {
+        const int j = q / NINS, i = q % NINS;
+        const int ks2 = i / RB, rb = i % RB;
+        const int row = 16 * rb + (lane >> 2), u = lane & 3;
+        const unsigned char* src = W + ((int64_t)row * (4 * C) + 64 * j + ks2 * 32 + ((u ^ key4(row >> 2)) << 3)) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(img + j * Geo<NK>::PART + i * 1024), 16, 0, 0);
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) short cm_s16x4;
+// O^T[c][m] += sum_n Wn[n][c] * P[n][m] with Wn an n-major part (rows = hidden n, cols = channels c):
+// the A operand (rows c, k = n) is gathered with transposed reads from the n-major image
+template <int NK, int MT>
+__device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], uint32_t part_addr, int s, int g, const uint4 (&pf)[MT][2]) {
+    constexpr int CT = Geo<NK>::CT;
+    const int q = s >> 2, pp = s & 3;
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int n = 32 * ks2 + 8 * g + q;  // (n >> 3) & 3 == g for this row and the one 4 below
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int ks = ct >> 1;
+            const int unit = 2 * (ct & 1) + (pp >> 1);
+            const uint32_t a = part_addr + (uint32_t)(ks * 4096 + n * 64 + ((unit ^ key4(g)) << 4) + (pp & 1) * 8);
+            uint2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi) : "v"(a) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4 wf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mfma16(o[ct][mt], wf, pf[mt][ks2]);
+        }
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
+    constexpr int MT = 2;
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    constexpr int PART = Geo<NK>::PART;
+    constexpr int NCH = 4 * C / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [W1 image NCH*PART][W2 image NCH*PART][b1 4C floats]
+    unsigned char* w1img = smem;
+    unsigned char* w2img = smem + NCH * PART;
+    float* b1s = reinterpret_cast<float*>(smem + 2 * NCH * PART);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    for (int i = threadIdx.x; i < 4 * C; i += 512) b1s[i] = p.b1[i];
+    dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
+    dma_all_cmajor<NK>(w2img, p.w2, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int ntile = (p.M + 31) / 32;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
+        const int m_base = tile * 32;
+        uint4 xf[MT][NK];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = m_base + mt * 16 + s;
+            if (m >= p.M) m = p.M - 1;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+        }
+        f32x4_t o[CT][MT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) o[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            f32x4_t h[4][MT];
+            prod_nmajor<NK, MT>(h, lds0 + j * PART, s, g, xf);
+            f32x4_t bv[4];
+            const uint32_t ba = lds0 + 2 * NCH * PART + (uint32_t)((64 * j + 8 * g) * 4);
+            CM_DS_READ128(bv[0], ba, 0);
+            CM_DS_READ128(bv[1], ba, 16);
+            CM_DS_READ128(bv[2], ba, 128);
+            CM_DS_READ128(bv[3], ba, 144);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        h[nt][mt][r] = gelu_lean(h[nt][mt][r] + bv[nt][r]);
+                    }
+            uint4 pf[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                pf[mt][0] = pack8(h[0][mt], h[1][mt]);
+                pf[mt][1] = pack8(h[2][mt], h[3][mt]);
+            }
+            prod_cmajor<NK, MT>(o, lds0 + NCH * PART + j * PART, s, g, pf);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + s;
+            if (m >= p.M) continue;
+            const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + 4 * g;
+                const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + c);
+                const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c);
+                const float4 xr = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + c);
+                const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
+                if (p.z) {
+                    uint2 zz;
+                    bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
+                    zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
+                    *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
+                }
+                *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
+                    make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
+            }
+        }
+    }
+}
+
+template <int NK>
+__global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
+    constexpr int MT = 2;
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    constexpr int PART = Geo<NK>::PART;
+    constexpr int NCH = 4 * C / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [W1 image][W2^T image][b1][dgamma partial]
+    unsigned char* w1img = smem;
+    unsigned char* w2timg = smem + NCH * PART;
+    float* b1s = reinterpret_cast<float*>(smem + 2 * NCH * PART);
+    float* dgs = b1s + 4 * C;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = lane & 15, g = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    for (int i = threadIdx.x; i < 4 * C; i += 512) b1s[i] = p.b1[i];
+    for (int i = threadIdx.x; i < C; i += 512) dgs[i] = 0.f;
+    dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
+    dma_all_nmajor<NK>(w2timg, p.w2t, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float dgp[NK][8];  // dgamma partials of this lane's channels ks*32 + 8g + j, summed over its rows
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dgp[ks][j] = 0.f;
+
+    const int ntile = (p.M + 31) / 32;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
+        const int m_base = tile * 32;
+        uint4 xf[MT][NK], zf[MT][NK];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = m_base + mt * 16 + s;
+            const bool mv = m < p.M;
+            if (!mv) m = p.M - 1;
+            const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int c = ks * 32 + 8 * g;
+                xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
+                const float4 g0 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
+                const float4 g1 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
+                const float4 a0 = *reinterpret_cast<const float4*>(p.gamma + c);
+                const float4 a1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+                Vec16<bf16_t> zin, dzv;
+                zin.raw = ld16(p.zin + ((int64_t)m * C + c) * 2);
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float sg = mv ? rs * gv[j] : 0.f;
+                    dzv.set(j, sg * av[j]);
+                    dgp[ks][j] = fmaf(sg, zin.get(j), dgp[ks][j]);
+                }
+                zf[mt][ks] = dzv.raw;
+                if (mv) st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+            }
+        }
+        f32x4_t dl[CT][MT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int j = 0; j < NCH; ++j) {
+            f32x4_t h[4][MT], da[4][MT];
+            prod_nmajor<NK, MT>(h, lds0 + j * PART, s, g, xf);
+            prod_nmajor<NK, MT>(da, lds0 + NCH * PART + j * PART, s, g, zf);
+            f32x4_t bv[4];
+            const uint32_t ba = lds0 + 2 * NCH * PART + (uint32_t)((64 * j + 8 * g) * 4);
+            CM_DS_READ128(bv[0], ba, 0);
+            CM_DS_READ128(bv[1], ba, 16);
+            CM_DS_READ128(bv[2], ba, 128);
+            CM_DS_READ128(bv[3], ba, 144);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float act, dg;
+                        gelu_lean_grad(h[nt][mt][r] + bv[nt][r], act, dg);
+                        h[nt][mt][r] = act;
+                        da[nt][mt][r] *= dg;
+                    }
+            uint4 pd[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const uint4 pa0 = pack8(h[0][mt], h[1][mt]), pa1 = pack8(h[2][mt], h[3][mt]);
+                pd[mt][0] = pack8(da[0][mt], da[1][mt]);
+                pd[mt][1] = pack8(da[2][mt], da[3][mt]);
+                const int m = m_base + mt * 16 + s;
+                if (m < p.M) {
+                    const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
+                    st16(p.act + off, pa0);
+                    st16(p.act + off + 64, pa1);
+                    st16(p.dh + off, pd[mt][0]);
+                    st16(p.dh + off + 64, pd[mt][1]);
+                }
+            }
+            prod_tr_nmajor<NK, MT>(dl, lds0 + j * PART, s, g, pd);  // dln += dH . W1  (W1 read transposed)
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + s;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + 4 * g;
+                uint2 v;
+                bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+                vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
+                *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+            }
+        }
+    }
+    // dgamma: sum the 16 row-lanes (s) of each g, then LDS atomics across waves, then one global atomic per channel
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = dgp[ks][j];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            if (s == 0) atomicAdd(&dgs[ks * 32 + 8 * g + j], t);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 512) atomicAdd(p.dgamma + i, dgs[i]);
+}
+
+template <int NK>
+int launch_fwd_res(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    int grid = cdiv(cdiv(p.M, 32), 8);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
+    return 0;
+}
+template <int NK>
+int launch_bwd_res(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    int grid = cdiv(cdiv(p.M, 32), 8);
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
+    return 0;
+}
+
+template <int NK, int MT>
+int launch_fwd(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * 2 * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((convmlp_fwd_kernel<NK, MT>), dim3(cdiv(p.M, 64 * MT)), dim3(256), lds, st, p);
+    return 0;
+}
+
+template <int NK, int MT>
+int launch_bwd(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * 3 * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT>), dim3(cdiv(p.M, 64 * MT)), dim3(256), lds, st, p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lnx_convmlp_supported(int dtype, int C) { return dtype == LNX_BF16 && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192); }
+
+extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
+    LNX_CHECK(a && a->ln && a->w1 && a->w2 && a->b1 && a->b2 && a->gamma && a->x && a->out, "lnx_convmlp_fwd: null operand");
+    LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_fwd: unsupported dtype %d / C %d (bf16, C in {32,64,96,128,192})", a->dtype, a->C);
+    LNX_CHECK(a->M > 0, "lnx_convmlp_fwd: empty");
+    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_convmlp_fwd: rowscale needs rows_per_sample");
+    CmP p{};
+    p.ln = (const unsigned char*)a->ln; p.w1 = (const unsigned char*)a->w1; p.w2 = (const unsigned char*)a->w2;
+    p.b1 = a->b1; p.b2 = a->b2; p.gamma = a->gamma; p.rowscale = a->rowscale; p.x = a->x; p.out = a->out; p.z = (unsigned char*)a->z;
+    p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->C) {
+        case 32: launch_fwd_res<1>(p, st); break;
+        case 64: launch_fwd_res<2>(p, st); break;
+        case 96: launch_fwd_res<3>(p, st); break;
+        case 128: launch_fwd<4, 1>(p, st); break;
+        case 192: launch_fwd<6, 1>(p, st); break;
+    }
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
+    LNX_CHECK(a && a->g && a->ln && a->z && a->w1 && a->w2t && a->w1t && a->b1 && a->gamma && a->act && a->dh && a->dz && a->dln && a->dgamma,
+              "lnx_convmlp_bwd: null operand");
+    LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_bwd: unsupported dtype %d / C %d", a->dtype, a->C);
+    LNX_CHECK(a->M > 0, "lnx_convmlp_bwd: empty");
+    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_convmlp_bwd: rowscale needs rows_per_sample");
+    CmP p{};
+    p.g = a->g; p.ln = (const unsigned char*)a->ln; p.zin = (const unsigned char*)a->z; p.w1 = (const unsigned char*)a->w1;
+    p.w2t = (const unsigned char*)a->w2t; p.w1t = (const unsigned char*)a->w1t; p.b1 = a->b1; p.gamma = a->gamma; p.rowscale = a->rowscale;
+    p.act = (unsigned char*)a->act; p.dh = (unsigned char*)a->dh; p.dz = (unsigned char*)a->dz; p.dln = (unsigned char*)a->dln; p.dgamma = a->dgamma;
+    p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->C) {
+        case 32: launch_bwd_res<1>(p, st); break;
+        case 64: launch_bwd_res<2>(p, st); break;
+        case 96: launch_bwd_res<3>(p, st); break;
+        case 128: launch_bwd<4, 1>(p, st); break;
+        case 192: launch_bwd<6, 1>(p, st); break;
+    }
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

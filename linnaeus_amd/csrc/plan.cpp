@@ -10,6 +10,7 @@
 //   parameters/grads fp32, caller-owned; a T-typed operand arena is refreshed every forward
 //   saved-for-backward tensors live in the workspace until the next forward
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -50,6 +51,7 @@ struct OpW {          // a GEMM weight in the T-typed operand arena
 };
 
 struct ConvBlk {
+    bool fused = false;  // pwconv1 -> GELU -> pwconv2 -> LayerScale -> residual in one kernel (hidden tensor stays on chip)
     int gamma, dww, dwb, lnw, lnb, b1, b2;
     OpW w1, w2;
     int64_t w49;  // fp32 [49][C] in the arena
@@ -115,7 +117,7 @@ struct lnx_plan {
     int64_t o_cl_hpre, o_cl_act, o_cl_u, o_cl_mean, o_cl_rstd, o_c1n;
     int64_t o_c2n, o_n2_mean, o_n2_rstd, o_agg, o_fin_mean, o_fin_rstd, o_feats, o_featsT;
     int64_t o_g[4];           // fp32 gradient streams per stage
-    int64_t o_sA, o_sC, o_sD; // T scratch: [M,4C] / [M,C] / [M,C]
+    int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
     int64_t o_lnws = 0, lnws_floats = 0;
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     const float* last_drop = nullptr;
@@ -471,6 +473,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->o_stem_mean = cv.take(M0 * 4);
     p->o_stem_rstd = cv.take(M0 * 4);
     int64_t maxMC = 0, maxM4C = 0;
+    bool any_fused = false;
     for (int s = 0; s < 2; ++s) {
         const int64_t M = (int64_t)B * p->HW[s], C = D[s];
         if (M * C > maxMC) maxMC = M * C;
@@ -481,8 +484,12 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.ln = cv.take(M * C * esz);
             k.mean = cv.take(M * 4);
             k.rstd = cv.take(M * 4);
-            k.hpre = cv.take(M * 4 * C * esz);
-            k.act = cv.take(M * 4 * C * esz);
+            k.fused = lnx_convmlp_supported(c.dtype, (int)C) != 0 && getenv("LNX_NO_FUSED_MLP") == nullptr;
+            any_fused = any_fused || k.fused;
+            if (!k.fused) {
+                k.hpre = cv.take(M * 4 * C * esz);
+                k.act = cv.take(M * 4 * C * esz);
+            }
             k.z = cv.take(M * C * esz);
         }
         p->o_stage_out[s] = cv.take(M * C * 4);
@@ -569,6 +576,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
     p->o_lnws = cv.take(p->lnws_floats * 4);
     p->o_sA = cv.take(maxM4C * esz);
+    if (any_fused) p->o_sB = cv.take(maxM4C * esz);
     p->o_sC = cv.take(maxMC * esz);
     p->o_sD = cv.take(maxMC * esz);
     {
@@ -808,6 +816,17 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
         RUN(lnx_dwconv7_fwd(&d, c.st));
     }
     RUN(ln_fwd(c, M, C, 1e-6f, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<void>(k.ln), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean), c.at<float>(k.rstd)));
+    if (k.fused) {
+        lnx_convmlp_args f;
+        memset(&f, 0, sizeof f);
+        f.dtype = c.dt; f.M = M; f.C = C;
+        f.ln = c.at<void>(k.ln); f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1]; f.w2 = c.wptr(k.w2); f.b2 = p->P[k.b2];
+        f.gamma = p->P[k.gamma]; f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
+        f.x = c.at<float>(k.xin); f.out = xout; f.z = c.at<void>(k.z);
+        Timed t(c, 6, 2.0 * M * C * 4 * C * 2);
+        RUN(lnx_convmlp_fwd(&f, c.st));
+        return 0;
+    }
     lnx_gemm_args g = gemm_base(c, M, 4 * C, C, c.at<void>(k.ln), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.act), 4 * C, false);
     g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
     RUN(gemm_nt_t(c, &g));
@@ -1056,14 +1075,31 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
     void* sA = c.at<void>(p->o_sA);
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
-    RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
-    RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
-    lnx_gemm_args a = gemm_base(c, M, 4 * C, C, sC, C, c.wtptr(k.w2), k.w2.ld_t, sA, 4 * C, false);
-    a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;
-    RUN(gemm_nt_t(c, &a));
-    RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
-    a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
-    RUN(gemm_nt_t(c, &a));
+    if (k.fused) {
+        void* sB = c.at<void>(p->o_sB);
+        lnx_convmlp_bwd_args f;
+        memset(&f, 0, sizeof f);
+        f.dtype = c.dt; f.M = M; f.C = C;
+        f.g = g; f.ln = c.at<void>(k.ln); f.z = c.at<void>(k.z); f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1];
+        f.w2t = c.wtptr(k.w2); f.w1t = c.wtptr(k.w1); f.gamma = p->P[k.gamma];
+        f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
+        f.act = sB; f.dh = sA; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
+        {
+            Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
+            RUN(lnx_convmlp_bwd(&f, c.st));
+        }
+        RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C));
+        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
+    } else {
+        RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
+        RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
+        lnx_gemm_args a = gemm_base(c, M, 4 * C, C, sC, C, c.wtptr(k.w2), k.w2.ld_t, sA, 4 * C, false);
+        a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;
+        RUN(gemm_nt_t(c, &a));
+        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
+        a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
+        RUN(gemm_nt_t(c, &a));
+    }
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<float>(k.mean), c.at<float>(k.rstd), nullptr, sC, c.dt, C, false));
     lnx_dwconv_wgrad_args w;
     memset(&w, 0, sizeof w);

@@ -195,3 +195,21 @@ def agg2_bwd(dout, a, b, w2, da, db, dw2, dbias1, M, Cc):
 
 def pack_meta(meta, off, dim, out):
     L.check(L.lib().lnx_pack_meta(_p(meta), meta.shape[1], off, dim, _p(out), code_of(out), meta.shape[0], _stream()), "lnx_pack_meta")
+
+
+def convmlp_fwd(ln, w1, b1, w2, b2, gamma, x, out, *, rowscale=None, rows_per_sample=0, z=None):
+    a = L.ConvMlpArgs()
+    a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
+    a.ln, a.w1, a.b1, a.w2, a.b2, a.gamma = _p(ln), _p(w1), _p(b1), _p(w2), _p(b2), _p(gamma)
+    a.rowscale, a.rows_per_sample, a.x, a.out, a.z = _p(rowscale), rows_per_sample, _p(x), _p(out), _p(z)
+    L.check(L.lib().lnx_convmlp_fwd(C.byref(a), _stream()), "lnx_convmlp_fwd")
+    return out
+
+
+def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, rowscale=None, rows_per_sample=0):
+    a = L.ConvMlpBwdArgs()
+    a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
+    a.g, a.ln, a.z, a.w1, a.b1, a.w2t, a.w1t, a.gamma = _p(g), _p(ln), _p(z), _p(w1), _p(b1), _p(w2t), _p(w1t), _p(gamma)
+    a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
+    a.act, a.dh, a.dz, a.dln, a.dgamma = _p(act), _p(dh), _p(dz), _p(dln), _p(dgamma)
+    L.check(L.lib().lnx_convmlp_bwd(C.byref(a), _stream()), "lnx_convmlp_bwd")

@@ -251,3 +251,50 @@ def test_small_kernels(dtype):
     pm = torch.full((4, 16), float("nan"), device="cuda", dtype=tdt)
     ops.pack_meta(meta, 2, 3, pm)
     assert torch.equal(pm[:, :3].float(), meta[:, 2:5].to(tdt).float()) and pm[:, 3:].abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("C_,M", [(32, 200), (64, 130), (96, 777), (128, 100), (192, 333), (96, 6272)])
+def test_convmlp_fused_fwd_bwd(C_, M):
+    """Fused pwconv1 -> GELU -> pwconv2 -> LayerScale -> DropPath -> +x against fp64 math on the same
+    bf16 operands (tolerance = bf16 rounding of the on-chip hidden activation and of the outputs)."""
+    gen = g(C_ * 3 + M)
+    bf = torch.bfloat16
+    rps = 50
+    nb = (M + rps - 1) // rps
+    ln = torch.randn(M, C_, generator=gen).cuda().to(bf)
+    w1 = (torch.randn(4 * C_, C_, generator=gen) / C_**0.5).cuda().to(bf)
+    b1 = (0.2 * torch.randn(4 * C_, generator=gen)).cuda()
+    w2 = (torch.randn(C_, 4 * C_, generator=gen) / (4 * C_) ** 0.5).cuda().to(bf)
+    b2 = (0.2 * torch.randn(C_, generator=gen)).cuda()
+    gam = (0.5 + 0.3 * torch.randn(C_, generator=gen)).cuda()
+    rs = (torch.rand(nb, generator=gen) > 0.3).float().cuda() * 1.25
+    x = torch.randn(M, C_, generator=gen).cuda()
+    out = torch.empty(M, C_, device="cuda")
+    z = torch.empty(M, C_, device="cuda", dtype=bf)
+    ops.convmlp_fwd(ln, w1, b1, w2, b2, gam, x, out, rowscale=rs, rows_per_sample=rps, z=z)
+    # reference in fp64 with the same rounding points (hidden activation rounded to bf16 before pwconv2)
+    lnd, w1d, w2d = ln.double(), w1.double(), w2.double()
+    h = lnd @ w1d.T + b1.double()
+    act = torch.nn.functional.gelu(h).to(bf).double()
+    zr = act @ w2d.T + b2.double()
+    s = rs.double().repeat_interleave(rps)[:M, None]
+    ref = x.double() + s * gam.double() * zr
+    torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(z.double(), zr, rtol=1.6e-2, atol=1.6e-2)
+    # backward
+    gout = torch.randn(M, C_, generator=gen).cuda()
+    actb = torch.empty(M, 4 * C_, device="cuda", dtype=bf)
+    dh = torch.empty(M, 4 * C_, device="cuda", dtype=bf)
+    dz = torch.empty(M, C_, device="cuda", dtype=bf)
+    dln = torch.empty(M, C_, device="cuda", dtype=bf)
+    dgam = torch.zeros(C_, device="cuda")
+    ops.convmlp_bwd(gout, ln, z, w1, b1, w2.t().contiguous(), w1.t().contiguous(), gam, actb, dh, dz, dln, dgam, rowscale=rs, rows_per_sample=rps)
+    dz_ref = (s * gam.double() * gout.double())
+    torch.testing.assert_close(dz.double(), dz_ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(actb.double(), torch.nn.functional.gelu(h), rtol=1.6e-2, atol=1.6e-2)
+    hg = h.clone().requires_grad_(True)
+    torch.nn.functional.gelu(hg).sum().backward()
+    dh_ref = (dz.double() @ w2d) * hg.grad
+    torch.testing.assert_close(dh.double(), dh_ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dln.double(), dh.double() @ w1d, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(dgam.double(), (s * gout.double() * z.double()).sum(0), rtol=1e-3, atol=1e-2)

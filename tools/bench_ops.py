@@ -2,7 +2,7 @@
 algorithmic bytes)."""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from linnaeus_amd import ops
 
 def time_it(fn, n=20):
@@ -53,3 +53,19 @@ if which in ("all", "ew"):
     out = torch.empty(M, C, device="cuda", dtype=bf)
     t = time_it(lambda: ops.scale_cast(g, out, M, C, rowscale=rs, rows_per_sample=3136))
     print(f"scale_cast s0 {t*1e6:7.1f}us {M*C*6/t/1e9:6.0f} GB/s")
+if which in ("all", "cm"):
+    for name, M, C in [("s0", 802816, 96), ("s1", 200704, 192)]:
+        gen = torch.Generator().manual_seed(0)
+        ln = torch.randn(M, C, device="cuda").to(bf); w1 = (torch.randn(4 * C, C, device="cuda") / C**0.5).to(bf); b1 = torch.zeros(4 * C, device="cuda")
+        w2 = (torch.randn(C, 4 * C, device="cuda") / (4 * C)**0.5).to(bf); b2 = torch.zeros(C, device="cuda"); gam = torch.ones(C, device="cuda")
+        x = torch.randn(M, C, device="cuda"); out = torch.empty(M, C, device="cuda"); z = torch.empty(M, C, device="cuda", dtype=bf)
+        rs = torch.ones(256, device="cuda")
+        t = time_it(lambda: ops.convmlp_fwd(ln, w1, b1, w2, b2, gam, x, out, rowscale=rs, rows_per_sample=M // 256, z=z))
+        fl = 2.0 * M * C * 4 * C * 2
+        by = M * C * (2 + 4 + 4 + 2)
+        g = torch.randn(M, C, device="cuda"); act = torch.empty(M, 4 * C, device="cuda", dtype=bf); dh = torch.empty_like(act)
+        dz = torch.empty(M, C, device="cuda", dtype=bf); dln = torch.empty_like(dz); dg = torch.zeros(C, device="cuda")
+        w2t = w2.t().contiguous(); w1t = w1.t().contiguous()
+        t2 = time_it(lambda: ops.convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gam, act, dh, dz, dln, dg, rowscale=rs, rows_per_sample=M // 256))
+        by2 = M * C * (4 + 2 + 2 + 2 + 2) + 2 * M * 4 * C * 2
+        print(f"convmlp {name} fwd {t*1e6:7.1f}us {fl/t/1e12:6.0f} TF/s {by/t/1e9:6.0f} GB/s | bwd {t2*1e6:7.1f}us {1.5*fl/t2/1e12:6.0f} TF/s {by2/t2/1e9:6.0f} GB/s", flush=True)
