@@ -118,12 +118,17 @@ struct lnx_plan {
     int64_t o_c2n, o_n2_mean, o_n2_rstd, o_agg, o_fin_mean, o_fin_rstd, o_feats, o_featsT;
     int64_t o_g[4];           // fp32 gradient streams per stage
     int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
-    int64_t o_lnws = 0, lnws_floats = 0;
+    int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     const float* last_drop = nullptr;
     const unsigned char* last_mask = nullptr;
     std::vector<unsigned char> mask_host;
     const float* last_meta = nullptr;
+    // side stream for the tiny M = batch metadata-head chains: they are independent of the image path
+    // until token assembly, so they run concurrently with the conv stages (forward) / the downsample
+    // backward (backward) instead of serialising ~100 small launches on the main stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_meta = nullptr, ev_bfork[2] = {nullptr, nullptr}, ev_bjoin[2] = {nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
     bool profile = false;
     struct Span { hipEvent_t e0, e1; int cls; double work; };
@@ -575,6 +580,8 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     }
     p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
     p->o_lnws = cv.take(p->lnws_floats * 4);
+    p->lnws_side_floats = (int64_t)256 * 2 * D[3];
+    p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
     p->o_sA = cv.take(maxM4C * esz);
     if (any_fused) p->o_sB = cv.take(maxM4C * esz);
     p->o_sC = cv.take(maxMC * esz);
@@ -596,7 +603,21 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     return 0;
 }
 
-extern "C" void lnx_plan_destroy(lnx_plan* p) { delete p; }
+extern "C" void lnx_plan_destroy(lnx_plan* p) {
+    if (!p) return;
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
+        (void)hipEventDestroy(p->ev_fork);
+        (void)hipEventDestroy(p->ev_meta);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(p->ev_bfork[i]);
+            (void)hipEventDestroy(p->ev_bjoin[i]);
+        }
+    }
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    delete p;
+}
 extern "C" int64_t lnx_plan_workspace_bytes(const lnx_plan* p) { return p ? p->ws_bytes : 0; }
 extern "C" int lnx_plan_num_params(const lnx_plan* p) { return p ? (int)p->names.size() : 0; }
 extern "C" const char* lnx_plan_param_name(const lnx_plan* p, int i) {
@@ -678,6 +699,15 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
             if (w->f32) push_w(w);
     p->n_descs_f = (int64_t)d.size() - p->n_descs_t;
     p->prep_blocks_f = blk;
+    if (p->side == nullptr && p->c.n_meta > 0 && getenv("LNX_NO_SIDE_STREAM") == nullptr) {
+        HIPRUN(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        HIPRUN(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        HIPRUN(hipEventCreateWithFlags(&p->ev_meta, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) {
+            HIPRUN(hipEventCreateWithFlags(&p->ev_bfork[i], hipEventDisableTiming));
+            HIPRUN(hipEventCreateWithFlags(&p->ev_bjoin[i], hipEventDisableTiming));
+        }
+    }
     HIPRUN(hipMemcpy(p->ws + p->o_descs, d.data(), d.size() * sizeof(lnx_prep_desc), hipMemcpyHostToDevice));
     HIPRUN(hipDeviceSynchronize());
     p->bound = true;
@@ -775,8 +805,10 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     a.dx = dx; a.dx_dtype = dxdt; a.lddx = lddx;
     a.dw = c.p->G[wi]; a.db = c.p->G[bi];
     a.relu_mask = relu ? 1 : 0;
-    a.ws = c.at<float>(c.p->o_lnws);
-    a.ws_floats = c.p->lnws_floats;
+    // the side stream gets its own partial-sum scratch (both streams run LayerNorm backward concurrently)
+    const bool on_side = c.p->side != nullptr && c.st == (void*)c.p->side;
+    a.ws = c.at<float>(on_side ? c.p->o_lnws_side : c.p->o_lnws);
+    a.ws_floats = on_side ? c.p->lnws_side_floats : c.p->lnws_floats;
     return lnx_layernorm_bwd(&a, c.st);
 }
 
@@ -928,6 +960,18 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
     if (p->n_descs_f > 0)
         RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs) + p->n_descs_t, (int)p->n_descs_f, (int)p->prep_blocks_f, LNX_F32, stream));
 
+    // metadata heads of both RoPE stages: forked onto the side stream right after the weight refresh
+    int mw_all = 0;
+    for (int m = 0; m < cf.n_meta; ++m) mw_all += cf.meta_dims[m];
+    if (p->side && cf.n_meta > 0) {
+        HIPRUN(hipEventRecord(p->ev_fork, (hipStream_t)stream));
+        HIPRUN(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        Ctx cs{p, (void*)p->side, cf.dtype};
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(cs, s2, m, meta, mw_all, c.at<float>(p->o_tok[s2]), s2 == 0 ? p->N2 : p->N3));
+        HIPRUN(hipEventRecord(p->ev_meta, p->side));
+    }
+
     // 1. stem: 4x4/4 patchify conv as im2col + GEMM, then channels-first LN (mFormerV1.py:145-148)
     const int M0 = B * p->HW[0];
     RUN(lnx_im2col_stem(x, B, cf.in_chans, cf.img_h, cf.img_w, c.at<void>(p->o_patches), cf.dtype, 64, stream));
@@ -962,9 +1006,11 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         float* tok = c.at<float>(p->o_tok[s]);
         const lnx_rowmap clsmap = {1, N - 1, 0};
         RUN(lnx_fill_rows(p->P[p->cls[s]], tok, C, clsmap, B, C, stream));
-        int mw = 0;
-        for (int m = 0; m < cf.n_meta; ++m) mw += cf.meta_dims[m];
-        for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(c, s, m, meta, mw, tok, N));
+        if (p->side && cf.n_meta > 0) {
+            if (s == 0) HIPRUN(hipStreamWaitEvent((hipStream_t)stream, p->ev_meta, 0));  // join: all meta tokens written
+        } else {
+            for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(c, s, m, meta, mw_all, tok, N));
+        }
         const int nb = cf.rope_depths[s];
         for (int i = 0; i < nb; ++i) {
             float* xout = i + 1 < nb ? c.at<float>(p->rope[s][i + 1].xin) : c.at<float>(p->o_stage_out[2 + s]);
@@ -1177,7 +1223,22 @@ int tokens_bwd(const Ctx& c, int s, const float* g) {
     const int B = p->c.batch, C = p->c.dims[2 + s], N = s == 0 ? p->N2 : p->N3;
     const lnx_rowmap clsmap = {1, N - 1, 0};
     RUN(lnx_colsum_rows(g, C, clsmap, p->G[p->cls[s]], B, C, c.st));
-    for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(c, s, m, g, N));
+    if (p->side && p->c.n_meta > 0) {
+        // fork: the metadata-head backward only reads g; joined at the end of the segment (join_side)
+        HIPRUN(hipEventRecord(p->ev_bfork[s], (hipStream_t)c.st));
+        HIPRUN(hipStreamWaitEvent(p->side, p->ev_bfork[s], 0));
+        const Ctx cs{p, (void*)p->side, c.dt};
+        for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(cs, s, m, g, N));
+        HIPRUN(hipEventRecord(p->ev_bjoin[s], p->side));
+    } else {
+        for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(c, s, m, g, N));
+    }
+    return 0;
+}
+
+int join_side(const Ctx& c, int s) {
+    lnx_plan* p = c.p;
+    if (p->side && p->c.n_meta > 0) HIPRUN(hipStreamWaitEvent((hipStream_t)c.st, p->ev_bjoin[s], 0));
     return 0;
 }
 
@@ -1263,6 +1324,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         float* g2 = c.at<float>(p->o_g[2]);
         RUN(ln_bwd(c, B * p->N2, C2, dt1, cf.dtype, C2, IDM, c.at<float>(p->o_stage_out[2]), LNX_F32, C2, IDM, p->norm_w[0], p->norm_b[0], c.at<float>(p->o_t1_mean),
                    c.at<float>(p->o_t1_rstd), nullptr, g2, LNX_F32, C2, false));
+        RUN(join_side(c, 1));
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);
@@ -1270,6 +1332,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         RUN(tokens_bwd(c, 0, g2));
         const lnx_rowmap gm = {p->HW[2], p->E, p->E};
         RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
+        RUN(join_side(c, 0));
     }
     if (all || segment == 2) {
         float* g1 = c.at<float>(p->o_g[1]);
