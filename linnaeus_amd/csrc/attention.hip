@@ -15,6 +15,8 @@
 // Kernels:  attn_fwd  -> o, lse
 //           attn_bwd_dq   (per 64 queries: delta, dq, cos-gradient part of q)
 //           attn_bwd_dkv  (per 64 keys:    dk, dv, cos-gradient part of k)
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/lnx.h"
 
@@ -441,6 +443,269 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------
+// "Resident" variants for short sequences (N <= 256, bf16): one workgroup per (batch, head) stages
+// the whole K~/V (forward, dq) or Q~/dO (dk/dv) of the head in LDS ONCE, then its waves walk their
+// 16-row tiles with no barrier in the loop.  Against the tiled kernels above this removes the
+// per-q-tile re-staging of K/V (4x at N = 199) and every in-loop __syncthreads.
+// ---------------------------------------------------------------------------------
+template <typename T, bool COS, bool ROWIMG, bool TRIMG>
+__device__ __forceinline__ void stage_all(unsigned char* rowimg, unsigned char* trimg, const T* __restrict__ base, int64_t ld, int nrows_pad, int N, int E,
+                                          const float* __restrict__ cos_tab, int heads, int head, float scale) {
+    constexpr int NCH = AT<T>::NCH;
+    constexpr int EPV = AT<T>::EPV;
+    for (int i = threadIdx.x; i < nrows_pad * NCH; i += blockDim.x) {
+        const int r = i / NCH, c = i % NCH;
+        const uint4 v = load_chunk<T, COS>(base, ld, r, N, E, c * EPV, cos_tab, heads, head, scale);
+        if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
+        if constexpr (TRIMG) st16(trimg + r * AT<T>::TRB + c * 16, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_res_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nkt = (p.N + BT - 1) / BT;
+    const int npad = nkt * BT;
+    unsigned char* kimg = smem;
+    unsigned char* vimg = smem + npad * AT<T>::ROWB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const float scale = 0.125f;
+    stage_all<T, true, true, false>(kimg, nullptr, kb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+    stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
+    __syncthreads();
+    const int nq16 = (p.N + 15) / 16;
+    for (int qt = wave; qt < nq16; qt += 4) {
+        const int q = qt * 16 + s;
+        uint4 qf[AT<T>::NKK];
+        load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
+        f32x4_t oacc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x4_t sacc[4];
+            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf);
+            float pv[4][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * BT + t * 16 + 4 * g + r;
+                    const float v = key < p.N ? sacc[t][r] : -INFINITY;
+                    pv[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = group_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(pv[t][r] - m_new);
+                    pv[t][r] = e;
+                    psum += e;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+            imgT_times_regs<T>(oacc, vimg + kt * BT * AT<T>::TRB, s, g, pv);
+        }
+        const float l_tot = group_sum(l_run);
+        const float inv = 1.0f / l_tot;
+        if (q < p.N) {
+            T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) op[dt * 16 + 4 * g + r] = from_f<T>(oacc[dt][r] * inv);
+            if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nkt = (p.N + BT - 1) / BT;
+    const int npad = nkt * BT;
+    unsigned char* kimg = smem;
+    unsigned char* vimg = kimg + npad * AT<T>::ROWB;
+    unsigned char* ktr = vimg + npad * AT<T>::ROWB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
+    const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
+    const float scale = 0.125f;
+    stage_all<T, true, true, true>(kimg, ktr, kb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+    stage_all<T, false, true, false>(vimg, nullptr, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
+    __syncthreads();
+    const int nq16 = (p.N + 15) / 16;
+    for (int qt = wave; qt < nq16; qt += 8) {
+        const int q = qt * 16 + s;
+        uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
+        load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
+        load_row_frag<T, false>(dof, dob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+        float dl = 0.f;
+        {
+            uint4 of[AT<T>::NKK];
+            load_row_frag<T, false>(of, ob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+#pragma unroll
+            for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+                Vec16<T> a, bb;
+                a.raw = dof[kk];
+                bb.raw = of[kk];
+#pragma unroll
+                for (int j = 0; j < AT<T>::EPV; ++j) dl += a.get(j) * bb.get(j);
+            }
+        }
+        const float delta = group_sum(dl);
+        const float lse = q < p.N ? p.lse[((int64_t)b * p.heads + head) * p.N + q] : 0.f;
+        if (q < p.N && g == 0) p.delta[((int64_t)b * p.heads + head) * p.N + q] = delta;
+        f32x4_t dq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x4_t sacc[4], dpacc[4];
+            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf);
+            rows_times_frag<T>(dpacc, vimg + kt * BT * AT<T>::ROWB, s, g, dof);
+            float ds[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * BT + t * 16 + 4 * g + r;
+                    const float pr = (key < p.N && q < p.N) ? __expf(sacc[t][r] - lse) : 0.f;
+                    ds[t][r] = pr * (dpacc[t][r] - delta);
+                }
+            imgT_times_regs<T>(dq, ktr + kt * BT * AT<T>::TRB, s, g, ds);
+        }
+        if (q < p.N) {
+            T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
+            const T* qraw = qb + (int64_t)q * ld;
+            const bool img = q >= p.E;
+            const float* cp = img ? p.cos_tab + ((int64_t)(q - p.E) * p.heads + head) * 32 : nullptr;
+            float* gq = img ? p.gcos + (((int64_t)b * (p.N - p.E) + (q - p.E)) * p.heads + head) * 32 : nullptr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d0 = dt * 16 + 4 * g;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int d = d0 + 2 * pr;
+                    const float c = img ? cp[d >> 1] : 1.0f;
+                    const float g0 = dq[dt][2 * pr], g1 = dq[dt][2 * pr + 1];
+                    dqp[d] = from_f<T>(g0 * c * scale);
+                    dqp[d + 1] = from_f<T>(g1 * c * scale);
+                    if (img) gq[d >> 1] = scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1]));
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nqt = (p.N + BT - 1) / BT;
+    const int npad = nqt * BT;
+    unsigned char* qimg = smem;
+    unsigned char* doimg = qimg + npad * AT<T>::ROWB;
+    unsigned char* qtr = doimg + npad * AT<T>::ROWB;
+    unsigned char* dotr = qtr + npad * AT<T>::TRB;
+    float* lse_s = reinterpret_cast<float*>(dotr + npad * AT<T>::TRB);
+    float* del_s = lse_s + npad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = lane & 15, g = lane >> 4;
+    const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
+    const int C = p.heads * HD;
+    const int64_t ld = 3 * C;
+    const T* qb = reinterpret_cast<const T*>(p.qkv) + (int64_t)b * p.N * ld + head * HD;
+    const T* kb = qb + C;
+    const T* vb = qb + 2 * C;
+    const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
+    const float scale = 0.125f;
+    const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
+    stage_all<T, true, true, true>(qimg, qtr, qb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, scale);
+    stage_all<T, false, true, true>(doimg, dotr, dob, C, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
+    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+        lse_s[i] = i < p.N ? p.lse[statbase + i] : 0.f;
+        del_s[i] = i < p.N ? p.delta[statbase + i] : 0.f;
+    }
+    __syncthreads();
+    const int nk16 = (p.N + 15) / 16;
+    for (int ktile = wave; ktile < nk16; ktile += 8) {
+        const int key = ktile * 16 + s;
+        uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
+        load_row_frag<T, true>(kf, kb, ld, key, p.N, p.E, g, p.cos_tab, p.heads, head, 1.0f);
+        load_row_frag<T, false>(vf, vb, ld, key, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+        f32x4_t dk[4], dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dk[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int qt = 0; qt < nqt; ++qt) {
+            f32x4_t sacc[4], dpacc[4];
+            rows_times_frag<T>(sacc, qimg + qt * BT * AT<T>::ROWB, s, g, kf);
+            rows_times_frag<T>(dpacc, doimg + qt * BT * AT<T>::ROWB, s, g, vf);
+            float pr[4][4], ds[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qt * BT + t * 16 + 4 * g + r;
+                    const float pp = (ql < p.N && key < p.N) ? __expf(sacc[t][r] - lse_s[ql]) : 0.f;
+                    pr[t][r] = pp;
+                    ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
+                }
+            imgT_times_regs<T>(dv, dotr + qt * BT * AT<T>::TRB, s, g, pr);
+            imgT_times_regs<T>(dk, qtr + qt * BT * AT<T>::TRB, s, g, ds);
+        }
+        if (key < p.N) {
+            T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
+            T* dvp = dkp + C;
+            const T* kraw = kb + (int64_t)key * ld;
+            const bool img = key >= p.E;
+            const float* cp = img ? p.cos_tab + ((int64_t)(key - p.E) * p.heads + head) * 32 : nullptr;
+            float* gk = img ? p.gcos + (int64_t)p.B * (p.N - p.E) * p.heads * 32 + (((int64_t)b * (p.N - p.E) + (key - p.E)) * p.heads + head) * 32 : nullptr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d0 = dt * 16 + 4 * g;
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq) {
+                    const int d = d0 + 2 * pq;
+                    const float c = img ? cp[d >> 1] : 1.0f;
+                    const float g0 = dk[dt][2 * pq], g1 = dk[dt][2 * pq + 1];
+                    dkp[d] = from_f<T>(g0 * c);
+                    dkp[d + 1] = from_f<T>(g1 * c);
+                    dvp[d] = from_f<T>(dv[dt][2 * pq]);
+                    dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
+                    if (img) gk[d >> 1] = g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // cos table and its backward to the learnable freqs
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out) {
@@ -523,7 +788,17 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
     p.qtiles = cdiv(a->N, BT);
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == LNX_BF16) {
+    if (a->dtype == LNX_BF16 && a->N <= 256 && getenv("LNX_ATTN_TILED") == nullptr) {
+        typedef bf16_t T;
+        const int npad = p.qtiles * BT;
+        const size_t lds = (size_t)npad * (AT<T>::ROWB + AT<T>::TRB);
+        static bool once = false;
+        if (!once) {
+            set_lds(attn_fwd_res_kernel<T>, 256 * (AT<T>::ROWB + AT<T>::TRB));
+            once = true;
+        }
+        hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(256), lds, st, p);
+    } else if (a->dtype == LNX_BF16) {
         const size_t lds = AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG;
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, p);
     } else {
@@ -545,7 +820,20 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     p.qtiles = cdiv(a->N, BT);
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
-    if (a->dtype == LNX_BF16) {
+    if (a->dtype == LNX_BF16 && a->N <= 256 && getenv("LNX_ATTN_TILED") == nullptr) {
+        typedef bf16_t T;
+        const int npad = p.qtiles * BT;
+        const size_t lds_q = (size_t)npad * (2 * AT<T>::ROWB + AT<T>::TRB);
+        const size_t lds_k = (size_t)npad * (2 * AT<T>::ROWB + 2 * AT<T>::TRB + 2 * sizeof(float));
+        static bool once = false;
+        if (!once) {
+            set_lds(attn_bwd_dq_res_kernel<T>, 256 * (2 * AT<T>::ROWB + AT<T>::TRB));
+            set_lds(attn_bwd_dkv_res_kernel<T>, 256 * (2 * AT<T>::ROWB + 2 * AT<T>::TRB + 2 * sizeof(float)));
+            once = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_q, st, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_k, st, p);
+    } else if (a->dtype == LNX_BF16) {
         typedef bf16_t T;
         const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
         const size_t lds_k = 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float);
