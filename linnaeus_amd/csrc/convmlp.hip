@@ -19,6 +19,8 @@
 // B operand of the second product in natural k order -- the hidden tile never touches LDS.
 // Weight tiles are laid out [k-step][row][64 B] with the 16-byte unit XOR-swizzled by a 2-bit
 // row key (applied on the DMA source address) so every ds_read_b128 group is conflict-free.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "../../include/lnx.h"
 
@@ -45,6 +47,7 @@ struct CmP {
     unsigned char* dln;         // bwd out [M, C]
     float* dgamma;
     int M, C, rps;
+    int dbg;  // benchmarking only (LNX_CM_DBG): bit0 skip GELU, bit1 skip epilogue memory ops, bit2 skip ln loads
 };
 
 __device__ __forceinline__ void mfma16(f32x4_t& acc, const uint4& a, const uint4& b) {
@@ -287,12 +290,20 @@ __global__ __launch_bounds__(256) void convmlp_fwd_kernel(const CmP p) {
         const int m = m_base + mt * 16 + s;
         if (m >= p.M) continue;
         const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+        // all loads first: as far as the compiler knows the stores below may alias them, and interleaving
+        // would serialise one full memory round trip per channel tile
+        float4 xrv[CT], b2v[CT], gmv[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int c = ct * 16 + 4 * g;
-            const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + c);
-            const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c);
-            const float4 xr = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + c);
+            xrv[ct] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + c);
+            b2v[ct] = *reinterpret_cast<const float4*>(p.b2 + c);
+            gmv[ct] = *reinterpret_cast<const float4*>(p.gamma + c);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = ct * 16 + 4 * g;
+            const float4 b2 = b2v[ct], gm = gmv[ct], xr = xrv[ct];
             const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
             if (p.z) {
                 uint2 zz;
@@ -339,16 +350,25 @@ __global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
         mvalid[mt] = m < p.M;
         if (!mvalid[mt]) m = p.M - 1;
         const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+        // loads of every k-step first, then compute + dz stores (see the forward epilogue note)
+        float4 g0v[NK], g1v[NK], a0v[NK], a1v[NK];
+        uint4 zraw[NK];
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int c = ks * 32 + 8 * g;
             xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
-            const float4 g0 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
-            const float4 g1 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
-            const float4 a0 = *reinterpret_cast<const float4*>(p.gamma + c);
-            const float4 a1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+            g0v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
+            g1v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
+            a0v[ks] = *reinterpret_cast<const float4*>(p.gamma + c);
+            a1v[ks] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+            zraw[ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int c = ks * 32 + 8 * g;
+            const float4 g0 = g0v[ks], g1 = g1v[ks], a0 = a0v[ks], a1 = a1v[ks];
             Vec16<bf16_t> zin, dzv;
-            zin.raw = ld16(p.zin + ((int64_t)m * C + c) * 2);
+            zin.raw = zraw[ks];
             const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -526,28 +546,56 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     unsigned char* w1img = smem;
     unsigned char* w2img = smem + NCH * PART;
     float* b1s = reinterpret_cast<float*>(smem + 2 * NCH * PART);
+    float* b2s = b1s + 4 * C;
+    float* gms = b2s + C;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     for (int i = threadIdx.x; i < 4 * C; i += 512) b1s[i] = p.b1[i];
+    for (int i = threadIdx.x; i < C; i += 512) {
+        b2s[i] = p.b2[i];
+        gms[i] = p.gamma[i];
+    }
     dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
     dma_all_cmajor<NK>(w2img, p.w2, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Software pipeline over this wave's tiles: the ln fragments of tile t+1 and the residual rows of
+    // tile t are requested BEFORE tile t's MFMA/GELU work, so every HBM round trip runs under
+    // arithmetic (all waves of the chip would otherwise alternate in lockstep between a compute
+    // phase and a memory phase, which is what the ablation showed: the phase times simply added up).
     const int ntile = (p.M + 31) / 32;
-    for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
+    const int tstep = gridDim.x * 8;
+    auto load_x = [&](uint4 (&dst)[MT][NK], int tile) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int m = tile * 32 + mt * 16 + s;
+            if (m >= p.M) m = p.M - 1;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) dst[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+        }
+    };
+    int tile = blockIdx.x * 8 + wave;
+    uint4 xf[MT][NK];
+    if (tile < ntile) load_x(xf, tile);
+
+    for (; tile < ntile; tile += tstep) {
         const int m_base = tile * 32;
-        uint4 xf[MT][NK];
+        // residual rows of this tile (consumed in the epilogue) and next tile's ln fragments
+        float4 xrv[MT][CT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int m = m_base + mt * 16 + s;
             if (m >= p.M) m = p.M - 1;
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+            for (int ct = 0; ct < CT; ++ct) xrv[mt][ct] = (p.dbg & 8) ? make_float4(m, ct, g, 1) : *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + ct * 16 + 4 * g);
         }
+        uint4 xn[MT][NK];
+        const bool more = tile + tstep < ntile;
+        if (more) load_x(xn, tile + tstep);
         f32x4_t o[CT][MT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -570,9 +618,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        h[nt][mt][r] = gelu_lean(h[nt][mt][r] + bv[nt][r]);
-                    }
+                    for (int r = 0; r < 4; ++r) h[nt][mt][r] = (p.dbg & 1) ? h[nt][mt][r] + bv[nt][r] : gelu_lean(h[nt][mt][r] + bv[nt][r]);
             uint4 pf[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -581,27 +627,35 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             }
             prod_cmajor<NK, MT>(o, lds0 + NCH * PART + j * PART, s, g, pf);
         }
+        // epilogue: b2 / gamma come from LDS, the residual from the registers requested above
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = m_base + mt * 16 + s;
-            if (m >= p.M) continue;
-            const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+            if (m < p.M && !((p.dbg & 2) && o[0][mt][0] != 1234.5f)) {
+                const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int c = ct * 16 + 4 * g;
-                const float4 b2 = *reinterpret_cast<const float4*>(p.b2 + c);
-                const float4 gm = *reinterpret_cast<const float4*>(p.gamma + c);
-                const float4 xr = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + c);
-                const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
-                if (p.z) {
-                    uint2 zz;
-                    bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
-                    zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
-                    *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + 4 * g;
+                    const float4 b2 = *reinterpret_cast<const float4*>(b2s + c);
+                    const float4 gm = *reinterpret_cast<const float4*>(gms + c);
+                    const float4 xr = xrv[mt][ct];
+                    const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
+                    if (p.z) {
+                        uint2 zz;
+                        bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
+                        zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
+                        *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
+                    }
+                    *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
+                        make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
                 }
-                *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
-                    make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = xn[mt][ks];
         }
     }
 }
@@ -646,16 +700,25 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             const bool mv = m < p.M;
             if (!mv) m = p.M - 1;
             const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+            // loads of every k-step first, then compute + dz stores (see the forward epilogue note)
+            float4 g0v[NK], g1v[NK], a0v[NK], a1v[NK];
+            uint4 zraw[NK];
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 const int c = ks * 32 + 8 * g;
                 xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
-                const float4 g0 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
-                const float4 g1 = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
-                const float4 a0 = *reinterpret_cast<const float4*>(p.gamma + c);
-                const float4 a1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+                g0v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
+                g1v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
+                a0v[ks] = *reinterpret_cast<const float4*>(p.gamma + c);
+                a1v[ks] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+                zraw[ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int c = ks * 32 + 8 * g;
+                const float4 g0 = g0v[ks], g1 = g1v[ks], a0 = a0v[ks], a1 = a1v[ks];
                 Vec16<bf16_t> zin, dzv;
-                zin.raw = ld16(p.zin + ((int64_t)m * C + c) * 2);
+                zin.raw = zraw[ks];
                 const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -746,7 +809,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
 
 template <int NK>
 int launch_fwd_res(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 6 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -808,6 +871,7 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
     p.ln = (const unsigned char*)a->ln; p.w1 = (const unsigned char*)a->w1; p.w2 = (const unsigned char*)a->w2;
     p.b1 = a->b1; p.b2 = a->b2; p.gamma = a->gamma; p.rowscale = a->rowscale; p.x = a->x; p.out = a->out; p.z = (unsigned char*)a->z;
     p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.dbg = getenv("LNX_CM_DBG") ? atoi(getenv("LNX_CM_DBG")) : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (a->C) {
         case 32: launch_fwd_res<1>(p, st); break;

@@ -138,16 +138,19 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
         }
         const int h = q.h0 + r;
         if (h < p.H) {
+            const int64_t off0 = (((int64_t)q.b * p.H + h) * p.W + q.w0) * p.C + c;
+            if (p.res) {
+                // every residual load before the first store: the compiler must assume y aliases res, so an
+                // interleaved load/store sequence would cost one memory round trip per pixel
+                float rv[TW];
 #pragma unroll
-            for (int j = 0; j < TW; ++j) {
-                const int w = q.w0 + j;
-                if (w < p.W) {
-                    const int64_t off = (((int64_t)q.b * p.H + h) * p.W + w) * p.C + c;
-                    float v = acc[j];
-                    if (p.res) v += p.res[off];
-                    reinterpret_cast<TY*>(p.y)[off] = from_f<TY>(v);
-                }
+                for (int j = 0; j < TW; ++j) rv[j] = (q.w0 + j < p.W) ? p.res[off0 + (int64_t)j * p.C] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[j] += rv[j];
             }
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+                if (q.w0 + j < p.W) reinterpret_cast<TY*>(p.y)[off0 + (int64_t)j * p.C] = from_f<TY>(acc[j]);
         }
         __syncthreads();  // every wave is done reading this tile
         if (more) {

@@ -94,6 +94,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
         bias[j] = (p.bias && j < nvalid) ? p.bias[nb + j] : 0.f;
         gam[j] = (p.gamma && j < nvalid) ? p.gamma[nb + j] : 1.f;
     }
+    // Phase 1: every global load of the epilogue (aux, residual, row scale) for all four row slots, before
+    // the first store.  C / C2 may alias res or aux as far as the compiler knows, so loads issued between
+    // stores would each wait for the previous store: one memory round trip per row slot.
+    const bool has_aux = (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD);
+    // one staging buffer: aux when the activation needs it, else the residual (a launch with both loads
+    // the residual late, in phase 2)
+    const bool res_early = p.res && !has_aux;
+    float av[4][16], rs[4];
+    int64_t roffs[4];
+    int64_t coffs[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mrow0 + (s >> 2) * 16 + mi * 4 + (s & 3);
+        rs[mi] = 1.f;
+        coffs[mi] = 0;
+        roffs[mi] = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) av[mi][j] = 0.f;
+        if (m >= p.M) continue;
+        if (has_aux) {
+            const T* ax = reinterpret_cast<const T*>(p.aux) + (int64_t)m * p.ldaux + nb;
+            if (nvalid == 16 && ((((uintptr_t)ax) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 16 / EPV; ++h) {
+                    Vec16<T> t;
+                    t.raw = ld16(ax + h * EPV);
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) av[mi][h * EPV + j] = t.get(j);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) av[mi][j] = j < nvalid ? to_f(ax[j]) : 0.f;
+            }
+        }
+        if (p.rowscale) rs[mi] = p.rowscale[m / p.rows_per_sample];
+        if (p.c_mode == LNX_ADDR_PATCH2) {
+            coffs[mi] = patch_base(p.pg, m) + patch_col(p.pg, nb);
+            roffs[mi] = coffs[mi];
+        } else {
+            const int64_t row = map_row(p.cmap, m);
+            coffs[mi] = row * p.ldc + nb;
+            roffs[mi] = row * p.ldres + nb;
+        }
+        if (res_early) {
+            const float* rp = p.res + roffs[mi];
+            if (nvalid == 16 && ((((uintptr_t)rp) & 15) == 0)) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
+                    av[mi][4 * h + 0] = t.x;
+                    av[mi][4 * h + 1] = t.y;
+                    av[mi][4 * h + 2] = t.z;
+                    av[mi][4 * h + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) av[mi][j] = j < nvalid ? rp[j] : 0.f;
+            }
+        }
+    }
+    // Phase 2: arithmetic and stores
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = mrow0 + (s >> 2) * 16 + mi * 4 + (s & 3);
@@ -123,59 +184,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
         } else if (p.act == LNX_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
-        } else if (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD) {
-            const T* ax = reinterpret_cast<const T*>(p.aux) + (int64_t)m * p.ldaux + nb;
-            float a[16];
-            if (nvalid == 16 && ((((uintptr_t)ax) & 15) == 0)) {
+        } else if (p.act == LNX_ACT_GELU_BWD) {
 #pragma unroll
-                for (int h = 0; h < 16 / EPV; ++h) {
-                    Vec16<T> t;
-                    t.raw = ld16(ax + h * EPV);
+            for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(av[mi][j]);
+        } else if (p.act == LNX_ACT_RELU_BWD) {
 #pragma unroll
-                    for (int j = 0; j < EPV; ++j) a[h * EPV + j] = t.get(j);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a[j] = j < nvalid ? to_f(ax[j]) : 0.f;
-            }
-            if (p.act == LNX_ACT_GELU_BWD) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(a[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f;
-            }
+            for (int j = 0; j < 16; ++j) v[j] = av[mi][j] > 0.f ? v[j] : 0.f;
         }
-        float rs = 1.f;
-        if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] *= gam[j] * rs;
+        for (int j = 0; j < 16; ++j) v[j] *= gam[j] * rs[mi];
+        if (res_early) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] += av[mi][j];
+        } else if (p.res) {
+            const float* rp = p.res + roffs[mi];
+            for (int j = 0; j < nvalid; ++j) v[j] += rp[j];
+        }
 
-        int64_t coff;  // element offset of (m, nb) in C / res
-        int64_t roff;
-        if (p.c_mode == LNX_ADDR_PATCH2) {
-            coff = patch_base(p.pg, m) + patch_col(p.pg, nb);
-            roff = coff;
-        } else {
-            const int64_t row = map_row(p.cmap, m);
-            coff = row * p.ldc + nb;
-            roff = row * p.ldres + nb;
-        }
-        if (p.res) {
-            const float* rp = p.res + roff;
-            if (nvalid == 16 && ((((uintptr_t)rp) & 15) == 0)) {
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
-                    v[4 * h + 0] += t.x;
-                    v[4 * h + 1] += t.y;
-                    v[4 * h + 2] += t.z;
-                    v[4 * h + 3] += t.w;
-                }
-            } else {
-                for (int j = 0; j < nvalid; ++j) v[j] += rp[j];
-            }
-        }
+        const int64_t coff = coffs[mi];
         if (OUT_F32) {
             float* cp = reinterpret_cast<float*>(p.C) + coff;
             if (nvalid == 16 && ((((uintptr_t)cp) & 15) == 0)) {
