@@ -95,3 +95,34 @@ def model_state_dict_from_oracle(model, sd):
         else:
             out[k] = sd[k]
     return out
+
+
+def load_train_step(golden_dir):
+    """Fixture of caller (ii), SURVEY 8c: two CE + clip + AdamW steps of tiny_a on the reference."""
+    import numpy as np
+    import torch
+
+    spec = CASES["tiny_a"]
+    z = np.load(f"{golden_dir}/train_step.npz", allow_pickle=False)
+    sd = O.seeded_state_dict(O.param_shapes(spec), SEED)
+    targets = {t: torch.from_numpy(z["target_" + t]) for t, _ in spec.heads}
+    weights = {t: float(w) for (t, _), w in zip(spec.heads, z["task_weights"])}
+    return spec, z, sd, torch.from_numpy(z["x"]), torch.from_numpy(z["meta"]), targets, weights
+
+
+def train_steps(forward, params, z, spec, targets, weights):
+    """The step sequence of train.py:147-176,279-316 (no AMP scaler): forward -> weighted per-task mean CE
+    -> backward -> clip_grad_norm_ -> AdamW.  `forward()` returns {task: logits}; `params` is a list."""
+    import torch
+
+    opt = torch.optim.AdamW(params, lr=float(z["lr"]), weight_decay=float(z["wd"]), betas=(0.9, 0.999), eps=1e-8)
+    losses, norms = [], []
+    for _ in range(int(z["steps"])):
+        out = forward()
+        loss = sum(weights[t] * torch.nn.functional.cross_entropy(out[t].float(), targets[t].to(out[t].device)) for t, _ in spec.heads)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, float(z["clip"]))))
+        opt.step()
+        losses.append(loss.item())
+    return losses, norms

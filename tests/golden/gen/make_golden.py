@@ -18,7 +18,8 @@ Cases:
   tiny_c   metadata inactive (E=1), ConditionalClassifier heads on a real TaxonomyTree (F3)
   tiny_dp  tiny_a in train mode with DROP_PATH_RATE=0.5 and recorded per-call masks
   sm       the real mFormerV1_sm config at 224, B=2, 4 Linear heads (1000/300/80/20)
-plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate).
+plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate) and
+  train_step  two optimizer steps of tiny_a (CE loss, clip_grad_norm_, AdamW): losses, grad norms, deltas.
 """
 import os
 import sys
@@ -227,6 +228,43 @@ def run_case(name, spec, img, batch, head_type="Linear", taxonomy=None, train_dr
     return model
 
 
+def run_train_step(name, spec, img, batch, steps=2):
+    """Caller (ii) of SURVEY 8c: forward -> per-task mean CE summed with static weights -> backward ->
+    clip_grad_norm_ -> AdamW step (the sequence of train.py:147-176,279-316 without AMP scaling), on
+    the reference model.  Records loss, pre-clip total gradient norm and parameter deltas per step."""
+    cfg = apply_spec(base_cfg(img), spec, "Linear")
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    load_seeded(model, SEED)
+    model.train()  # DROP_PATH_RATE 0 -> deterministic
+    x, meta = O.seeded_inputs(spec, batch, img, SEED + 1)
+    g = torch.Generator().manual_seed(SEED + 2)
+    targets = {t: torch.randint(0, c, (batch,), generator=g) for t, c in spec.heads}
+    weights = {t: 1.0 / (i + 1) for i, (t, _) in enumerate(spec.heads)}
+    rec = {"x": x.numpy(), "meta": meta.numpy(), "steps": np.array(steps), "lr": np.array(1e-3), "wd": np.array(0.05),
+           "clip": np.array(1.0), "task_weights": np.array([weights[t] for t, _ in spec.heads])}
+    for t, _ in spec.heads:
+        rec["target_" + t] = targets[t].numpy()
+    params = {canonical_name(k): p_ for k, p_ in model.named_parameters()}
+    before = {k: v.detach().clone() for k, v in params.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)
+    for s in range(steps):
+        out = model(x, meta)
+        loss = sum(weights[t] * torch.nn.functional.cross_entropy(out[t].float(), targets[t]) for t, _ in spec.heads)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        total = torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+        rec[f"loss_{s}"] = np.array(loss.item())
+        rec[f"gnorm_{s}"] = np.array(float(total))
+    names = sorted(params)
+    rec["param_names"] = np.array(names)
+    rec["delta_norms"] = np.array([(params[k].detach() - before[k]).double().norm().item() for k in names])
+    for k in names:
+        rec["deltaslice_" + k] = first_slice(params[k].detach() - before[k], 8)
+    print(f"[{name}] losses {[float(rec[f'loss_{s}']) for s in range(steps)]} gnorms {[float(rec[f'gnorm_{s}']) for s in range(steps)]}")
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -286,28 +324,38 @@ def per_op_known_answers():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])  # optional: regenerate just the named fixtures
+
+    def want(n):
+        return not only or n in only
+
     tiny_dims = (32, 64, 128, 256)
     heads2 = (("taxa_L10", 7), ("taxa_L20", 5))
     tiny_a = O.Spec(conv_dims=tiny_dims, conv_depths=(1, 1), rope_depths=(1, 1), rope_heads=(2, 4), heads=heads2)
-    run_case("tiny_a", tiny_a, 64, 2)
-    tiny_b = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4),
-                    meta=(("TEMPORAL", 2), ("SPATIAL", 3), ("ELEVATION", 10)), only_last_cls=True, heads=heads2)
-    run_case("tiny_b", tiny_b, 96, 3)
-
-    from linnaeus.utils.taxonomy.taxonomy_tree import TaxonomyTree
-    h3 = (("taxa_L10", 6), ("taxa_L20", 3), ("taxa_L30", 2))
-    tree = TaxonomyTree(
-        {"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}},
-        [t for t, _ in h3], {t: c for t, c in h3})
-    tiny_c = O.Spec(conv_dims=tiny_dims, conv_depths=(1, 1), rope_depths=(1, 1), rope_heads=(2, 4), meta=(), heads=h3)
-    run_case("tiny_c", tiny_c, 64, 2, head_type="ConditionalClassifier", taxonomy=tree)
-
-    tiny_dp = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4), heads=heads2, drop_path_rate=0.5)
-    run_case("tiny_dp", tiny_dp, 64, 4, train_drop=True)
-
-    sm = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)))
-    run_case("sm", sm, 224, 2)
-    per_op_known_answers()
+    if want("tiny_a"):
+        run_case("tiny_a", tiny_a, 64, 2)
+    if want("tiny_b"):
+        tiny_b = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4),
+                        meta=(("TEMPORAL", 2), ("SPATIAL", 3), ("ELEVATION", 10)), only_last_cls=True, heads=heads2)
+        run_case("tiny_b", tiny_b, 96, 3)
+    if want("tiny_c"):
+        from linnaeus.utils.taxonomy.taxonomy_tree import TaxonomyTree
+        h3 = (("taxa_L10", 6), ("taxa_L20", 3), ("taxa_L30", 2))
+        tree = TaxonomyTree(
+            {"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}},
+            [t for t, _ in h3], {t: c for t, c in h3})
+        tiny_c = O.Spec(conv_dims=tiny_dims, conv_depths=(1, 1), rope_depths=(1, 1), rope_heads=(2, 4), meta=(), heads=h3)
+        run_case("tiny_c", tiny_c, 64, 2, head_type="ConditionalClassifier", taxonomy=tree)
+    if want("tiny_dp"):
+        tiny_dp = O.Spec(conv_dims=tiny_dims, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4), heads=heads2, drop_path_rate=0.5)
+        run_case("tiny_dp", tiny_dp, 64, 4, train_drop=True)
+    if want("sm"):
+        sm = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)))
+        run_case("sm", sm, 224, 2)
+    if want("per_op"):
+        per_op_known_answers()
+    if want("train_step"):
+        run_train_step("train_step", tiny_a, 64, 4)
 
 
 if __name__ == "__main__":

@@ -159,3 +159,36 @@ def test_direct_grad_mode_accumulates():
     O.probe_loss(model(x.cuda(), meta.cuda())).backward()
     for k, p_ in model.named_parameters():
         torch.testing.assert_close(p_.grad, g1[k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_train_step_matches_reference(dtype, golden_dir):
+    """Caller (ii) of SURVEY 8c on the HIP model: forward -> CE -> backward -> clip_grad_norm_ -> AdamW, two
+    steps, against the numbers the reference produced (tests/golden/train_step.npz)."""
+    from tests.cases import load_train_step, train_steps
+
+    spec, z, sd, x, meta, targets, weights = load_train_step(golden_dir)
+    model = build("tiny_a", spec, sd, dtype)
+    model.train()
+    xg, mg = x.cuda(), meta.cuda()
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    losses, norms = train_steps(lambda: model(xg, mg), list(model.parameters()), z, spec, targets, weights)
+    ltol, ntol, dtol = (2e-4, 2e-3, 5e-2) if dtype == "fp32" else (2e-2, 5e-2, 0.3)
+    for s in range(int(z["steps"])):
+        assert abs(losses[s] - float(z[f"loss_{s}"])) <= ltol * abs(float(z[f"loss_{s}"])), (s, losses[s], float(z[f"loss_{s}"]))
+        assert abs(norms[s] - float(z[f"gnorm_{s}"])) <= ntol * float(z[f"gnorm_{s}"]), (s, norms[s], float(z[f"gnorm_{s}"]))
+    names = [str(n) for n in z["param_names"]]
+    got = dict(model.named_parameters())
+    assert sorted(got) == names
+    # Adam's first steps move every element by ~lr*sign(g): delta norms are insensitive to gradient scale but flip with
+    # gradient sign, so they pin the direction of every update
+    for i, k in enumerate(names):
+        d = (got[k].detach() - before[k]).double().norm().item()
+        if k == "aggregate.bias":
+            continue  # a constant shift in front of final_norm: its gradient is exactly zero in real arithmetic, and Adam turns the rounding noise into +-lr
+        floor = 0.05 * float(z["lr"]) * int(z["steps"]) * got[k].numel() ** 0.5
+        assert abs(d - z["delta_norms"][i]) <= dtol * z["delta_norms"][i] + floor, (k, d, z["delta_norms"][i])
+        if dtype == "fp32" and z["delta_norms"][i] > 0.5 * float(z["lr"]) * got[k].numel() ** 0.5:
+            ref = z["deltaslice_" + k]
+            cur = (got[k].detach() - before[k]).reshape(-1)[: ref.size].cpu().numpy()
+            assert np.abs(cur - ref).max() <= 0.2 * np.abs(ref).max() + 1e-7, (k, cur, ref)

@@ -105,3 +105,24 @@ def test_per_op_known_answers(golden_dir):
            "3.norm_fn2.weight": (32,), "3.norm_fn2.bias": (32,), "3.w1.weight": (32, 32), "3.w1.bias": (32,), "3.w2.weight": (32, 32), "3.w2.bias": (32,)}
     sd = {"meta_spatial_head_1." + k: O.seeded_fill("meta_spatial_head_1." + k, s, S) for k, s in shp.items()}
     np.testing.assert_allclose(O.meta_head(sd, "meta_spatial_head_1.", T("mh_x")).numpy(), z["mh_y"], rtol=1e-5, atol=2e-6)
+
+
+def test_train_step_matches_reference(golden_dir):
+    """Caller (ii): loss, pre-clip gradient norm and parameter deltas of two optimizer steps."""
+    from tests.cases import load_train_step, train_steps
+
+    spec, z, sd, x, meta, targets, weights = load_train_step(golden_dir)
+    before = {k: v.clone() for k, v in sd.items()}
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    losses, norms = train_steps(lambda: O.forward(sd, spec, x, meta), list(sd.values()), z, spec, targets, weights)
+    for s in range(int(z["steps"])):
+        assert abs(losses[s] - float(z[f"loss_{s}"])) <= 2e-5 * abs(float(z[f"loss_{s}"])), (s, losses[s])
+        assert abs(norms[s] - float(z[f"gnorm_{s}"])) <= 2e-4 * float(z[f"gnorm_{s}"]), (s, norms[s])
+    names = [str(n) for n in z["param_names"]]
+    assert sorted(sd) == names
+    for i, k in enumerate(names):
+        d = (sd[k].detach() - before[k]).double().norm().item()
+        if k == "aggregate.bias":
+            continue  # a constant shift in front of final_norm: its gradient is exactly zero in real arithmetic, and Adam turns the rounding noise into +-lr
+        floor = 0.05 * float(z["lr"]) * int(z["steps"]) * sd[k].numel() ** 0.5
+        assert abs(d - z["delta_norms"][i]) <= 2e-2 * z["delta_norms"][i] + floor, (k, d, z["delta_norms"][i])
