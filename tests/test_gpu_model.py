@@ -192,3 +192,39 @@ def test_train_step_matches_reference(dtype, golden_dir):
             ref = z["deltaslice_" + k]
             cur = (got[k].detach() - before[k]).reshape(-1)[: ref.size].cpu().numpy()
             assert np.abs(cur - ref).max() <= 0.2 * np.abs(ref).max() + 1e-7, (k, cur, ref)
+
+
+def test_large_384_matches_oracle():
+    """BASELINE config 4's shape: mFormerV1_lg (dims 192..1536, rope depths 10/2, heads 12/24) at 384x384, so
+    N = 24*24 + 3 = 579 tokens in stage 2 (multi-tile attention path) and conv stages the fused C<=192 kernels only
+    partly cover.  Forward (fp32 storage) and gradients against the CPU oracle on the same seeded weights."""
+    spec = O.Spec(conv_dims=(192, 384, 768, 1536), rope_depths=(10, 2), rope_heads=(12, 24), heads=(("taxa_L10", 50), ("taxa_L20", 11)))
+    sd = O.seeded_state_dict(O.param_shapes(spec), 1234)
+    x, meta = O.seeded_inputs(spec, 1, 384, 99)
+    model = build_model(make_config(spec, 384), num_classes={t: c for t, c in spec.heads})
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for v in sd.values())
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta)
+    O.probe_loss(oout).backward()
+    for dtype, ftol, gtol in (("fp32", 2e-4, 2e-3), ("bf16", 0.1, 0.1)):
+        model.set_compute_dtype(dtype)
+        model.train()
+        model.zero_grad()
+        out = model(x.cuda(), meta.cuda())
+        for t, _ in spec.heads:
+            ref = oout[t].detach()
+            err = (out[t].float().cpu() - ref).abs().max().item()
+            assert err <= ftol * max(1.0, ref.abs().max().item()), (dtype, t, err)
+            if dtype == "fp32":
+                assert (out[t].argmax(-1).cpu() == ref.argmax(-1)).all()
+        O.probe_loss(out).backward()
+        tot_err = tot_ref = 0.0
+        for k, p_ in model.named_parameters():
+            ref = osd[k].grad
+            tot_err += (p_.grad.float().cpu() - ref).double().pow(2).sum().item()
+            tot_ref += ref.double().pow(2).sum().item()
+        glob = (tot_err / tot_ref) ** 0.5
+        print(f"[lg@384/{dtype}] global relative gradient error vs oracle: {glob:.2e}")
+        assert glob <= gtol, (dtype, glob)
