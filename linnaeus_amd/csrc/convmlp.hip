@@ -58,42 +58,6 @@ __device__ __forceinline__ void mfma16(f32x4_t& acc, const uint4& a, const uint4
 // share the same four 16-byte bank slots) get distinct slots in every ds_read_b128 lane group
 __device__ __forceinline__ int key4(int a) { return (4 - (a & 3)) & 3; }
 
-// Exact-erf GELU on the VALU with as few instructions as possible (the fused kernels are bound by
-// VALU issue, not by MFMA or HBM).  erfc by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7):
-//   y = 0.5 * erfc(|v|/sqrt2) = 0.5 * (a1 t + ... + a5 t^5) * exp(-v^2/2),  t = 1/(1 + p |v|/sqrt2)
-//   Phi(v) = v >= 0 ? 1 - y : y      GELU(v) = v Phi(v) = max(v, 0) - |v y|
-// with u = |v| * sqrt(log2(e)/2) so that exp(-v^2/2) = exp2(-u^2) is one v_exp_f32, and 1/x one v_rcp_f32.
-// 15 VALU instructions (two of them transcendental) per element.
-struct GeluTerms {
-    float y;  // 0.5 * erfc(|v|/sqrt2)
-    float e;  // exp(-v^2/2)
-};
-__device__ __forceinline__ GeluTerms gelu_terms(float v) {
-    constexpr float K = 0.84932180028801904272f;            // sqrt(log2(e) / 2)
-    constexpr float P1 = 0.3275911f * 0.70710678118654752f / K;
-    const float u = fabsf(v) * K;
-    const float t = __builtin_amdgcn_rcpf(fmaf(P1, u, 1.0f));
-    GeluTerms r;
-    r.e = __builtin_amdgcn_exp2f(-(u * u));
-    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    poly = fmaf(poly, t, 0.5f * 1.421413741f);
-    poly = fmaf(poly, t, 0.5f * -0.284496736f);
-    poly = fmaf(poly, t, 0.5f * 0.254829592f);
-    r.y = poly * t * r.e;
-    return r;
-}
-__device__ __forceinline__ float gelu_lean(float v) {
-    const GeluTerms g = gelu_terms(v);
-    return fmaxf(v, 0.f) - fabsf(v * g.y);
-}
-// act = GELU(v), dgelu = Phi(v) + v phi(v)
-__device__ __forceinline__ void gelu_lean_grad(float v, float& act, float& dgelu) {
-    const GeluTerms g = gelu_terms(v);
-    act = fmaxf(v, 0.f) - fabsf(v * g.y);
-    const float cdf = 0.5f + copysignf(0.5f - g.y, v);
-    dgelu = fmaf(v * 0.39894228040143267794f, g.e, cdf);
-}
-
 #define CM_DS_READ128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr) : "memory")
 
 // bytes of one weight part (W1 slice [NK][64][64B] == W2 slice [2][C][64B]) for NK = C/32

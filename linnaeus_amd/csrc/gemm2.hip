@@ -35,7 +35,8 @@ constexpr int STAGE_BYTES = (BM2 + BN2) * ROWB;  // 48 KiB
 constexpr int NSTAGE = 3;
 constexpr int LD_PER_WAVE = (BM2 + BN2) / 8 / 8;  // 1 KiB wave-instructions per wave per stage = 6
 
-template <bool OUT_F32, bool PATCH>
+// F = feature set of a specialised epilogue (gemm_common.hpp) or F_GENERIC
+template <bool OUT_F32, bool PATCH, int F>
 __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmP p) {
     typedef bf16_t T;
     constexpr int BK = 64;
@@ -111,37 +112,54 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    const int nk = p.K / BK;  // >= 2
     issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 1);
+    issue_tile(1, 1);
+    // Ping-pong schedule: waves 0-3 and 4-7 (one of each per SIMD) run half a K slice apart, so one wave's
+    // memory phase (fragment reads + LDS-DMA issue, ~60+ cycles of issue per 1-KiB piece) sits under its SIMD
+    // partner's 32 MFMAs instead of every wave doing both phases in lock step.  Two barriers per K slice:
+    //   group 0:      mem(0) | comp(0) | mem(1) | comp(1) | ...
+    //   group 1:  --  |  mem(0) | comp(0) | mem(1) | ...
+    // Each wave ends its memory phase k by waiting (counted vmcnt) for its own pieces of stage k+1 and for its
+    // fragment reads; the barrier that follows therefore publishes stage k+1 and retires the reads of stage k,
+    // whose slot is refilled in memory phase k+1 (by stage k+3).  Fragment reads are inline asm on purpose: with
+    // compiler-visible LDS loads hipcc puts an s_waitcnt vmcnt(0) in front of them (it must assume they alias the
+    // in-flight LDS-DMA writes), which would drain the prefetch every iteration.
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue_tile(kt + 2, (kt + 2) % NSTAGE);
-        // Fragment reads are inline asm on purpose: with compiler-visible LDS loads hipcc puts an
-        // s_waitcnt vmcnt(0) in front of them (it must assume they alias the in-flight LDS-DMA writes),
-        // which would drain the two-tile prefetch every iteration.
         const uint32_t st = lds_base + (kt % NSTAGE) * STAGE_BYTES;
         uint4 wf0[4], af0[4], wf1[4], af1[4];
         DS_READ4(wf0, st + w_off0);
         DS_READ4(af0, st + a_off0);
         DS_READ4(wf1, st + w_off1);
         DS_READ4(af1, st + a_off1);
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        if (kt + 2 < nk) {
+            issue_tile(kt + 2, (kt + 2) % NSTAGE);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc[ni][mi], wf0[ni], af0[mi]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc[ni][mi], wf1[ni], af1[mi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp && kt + 1 == nk)) __builtin_amdgcn_s_barrier();
     }
-    gemm_epilogue<T, OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    if (F == F_GENERIC) gemm_epilogue<T, OUT_F32>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    else gemm_epilogue_fast<T, OUT_F32, F>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 bool nt_v2_ok(const GemmP& p, int dtype) {
@@ -153,24 +171,39 @@ bool nt_v2_ok(const GemmP& p, int dtype) {
 
 int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     GemmP p = p0;
+    p.dbg = 0;
     p.tiles_m = cdiv(p.M, BM2);
     p.tiles_n = cdiv(p.N, BN2);
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NSTAGE * STAGE_BYTES;
     const bool patch = p.a_mode == LNX_ADDR_PATCH2;
-#define V2_LAUNCH(O, P)                                                                                                              \
+    static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
+    const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+#define V2_LAUNCH(O, P, FF)                                                                                                          \
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \
         if (!attr) {                                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<O, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v2_kernel<O, P, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr = true;                                                                                                             \
         }                                                                                                                            \
-        hipLaunchKernelGGL((gemm_nt_v2_kernel<O, P>), dim3(grid), dim3(512), lds, st, p);                                            \
+        hipLaunchKernelGGL((gemm_nt_v2_kernel<O, P, FF>), dim3(grid), dim3(512), lds, st, p);                                        \
     } while (0)
-    if (out_f32 && patch) V2_LAUNCH(true, true);
-    else if (out_f32) V2_LAUNCH(true, false);
-    else if (patch) V2_LAUNCH(false, true);
-    else V2_LAUNCH(false, false);
+    if (f == F_GENERIC) {
+        if (out_f32 && patch) V2_LAUNCH(true, true, F_GENERIC);
+        else if (out_f32) V2_LAUNCH(true, false, F_GENERIC);
+        else if (patch) V2_LAUNCH(false, true, F_GENERIC);
+        else V2_LAUNCH(false, false, F_GENERIC);
+    } else if (out_f32) {
+        V2_LAUNCH(true, false, F_BIAS | F_RES);
+    } else if (f == 0) {
+        V2_LAUNCH(false, false, 0);
+    } else if (f == F_BIAS) {
+        V2_LAUNCH(false, false, F_BIAS);
+    } else if (f == (F_BIAS | F_C2 | F_GELU)) {
+        V2_LAUNCH(false, false, F_BIAS | F_C2 | F_GELU);
+    } else {
+        V2_LAUNCH(false, false, F_GELU_BWD);
+    }
 #undef V2_LAUNCH
     return 0;
 }

@@ -32,6 +32,7 @@ struct GemmP {
     int act;
     int rows_per_sample;
     int tiles_m, tiles_n;
+    int dbg;  // benchmarking only (LNX_NT_DBG): 1 skip MFMA, 2 skip LDS-DMA refills, 4 skip fragment reads, 8 skip epilogue
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on
@@ -180,13 +181,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
         }
         if (p.act == LNX_ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
+            for (int j = 0; j < 16; ++j) v[j] = Gelu<T>::fwd(v[j]);
         } else if (p.act == LNX_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
         } else if (p.act == LNX_ACT_GELU_BWD) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(av[mi][j]);
+            for (int j = 0; j < 16; ++j) v[j] *= Gelu<T>::grad(av[mi][j]);
         } else if (p.act == LNX_ACT_RELU_BWD) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = av[mi][j] > 0.f ? v[j] : 0.f;
@@ -225,6 +226,152 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
             }
         }
     }
+}
+
+// Specialised epilogues of the pipelined kernel.  The generic epilogue above decides everything at run time and
+// costs ~850 VALU instructions per wave and 64x64 sub-tile (64-bit address products, zero-filled staging, the
+// unused gamma / row-scale multiplies, row-map divisions): 25 % of a K = 384 launch.  The forms the model launches
+// on large problems are compiled with their feature set F fixed; preconditions, checked by fast_epilogue_mask():
+// identity row map, plain C addressing, N % 16 == 0, every row pitch and base pointer 16-byte aligned, all element
+// offsets < 2^31.
+enum { F_BIAS = 1, F_C2 = 2, F_GELU = 4, F_GELU_BWD = 8, F_RES = 16, F_GENERIC = 1 << 10 };
+
+template <typename T, bool OUT_F32, int F>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc)[4][4], int mrow0, int ncol0, int lane) {
+    constexpr int EPV = TT<T>::EPV;
+    const int s = lane & 15, g = lane >> 4;
+    const int nb = ncol0 + g * 16;
+    if (nb >= p.N) return;
+    const int mbase = mrow0 + (s >> 2) * 16 + (s & 3);  // row of slot mi = mbase + 4 mi
+    float bias[16];
+    if (F & F_BIAS) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float4 t = *reinterpret_cast<const float4*>(p.bias + nb + 4 * h);
+            bias[4 * h + 0] = t.x;
+            bias[4 * h + 1] = t.y;
+            bias[4 * h + 2] = t.z;
+            bias[4 * h + 3] = t.w;
+        }
+    }
+    // loads first (see the generic epilogue): aux for GELU_BWD, or the fp32 residual
+    float ld[4][16];
+    float rs[4];
+    if (F & F_GELU_BWD) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = min(mbase + 4 * mi, p.M - 1);
+            const T* ax = reinterpret_cast<const T*>(p.aux) + (m * (int)p.ldaux + nb);
+#pragma unroll
+            for (int h = 0; h < 16 / EPV; ++h) {
+                Vec16<T> t;
+                t.raw = ld16(ax + h * EPV);
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) ld[mi][h * EPV + j] = t.get(j);
+            }
+        }
+    }
+    if (F & F_RES) {
+        // row scale (DropPath): rows of a 64-row sub-tile span at most two samples when rows_per_sample >= 64
+        const bool scaled = p.rowscale != nullptr;
+        const int q0 = scaled ? mrow0 / p.rows_per_sample : 0;
+        const int edge = (q0 + 1) * p.rows_per_sample;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = min(mbase + 4 * mi, p.M - 1);
+            rs[mi] = 1.f;
+            if (scaled) rs[mi] = p.rows_per_sample >= 64 ? p.rowscale[q0 + (m >= edge ? 1 : 0)] : p.rowscale[m / p.rows_per_sample];
+            const float* rp = p.res + (m * (int)p.ldres + nb);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
+                ld[mi][4 * h + 0] = t.x;
+                ld[mi][4 * h + 1] = t.y;
+                ld[mi][4 * h + 2] = t.z;
+                ld[mi][4 * h + 3] = t.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mbase + 4 * mi;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[ni * 4 + r] = (F & F_BIAS) ? acc[ni][mi][r] + bias[ni * 4 + r] : acc[ni][mi][r];
+        if (F & F_C2) {
+            T* c2 = reinterpret_cast<T*>(p.C2) + (m * (int)p.ldc2 + nb);
+            Vec16<T> o;
+#pragma unroll
+            for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                st16(c2 + h * EPV, o.raw);
+            }
+        }
+        if (F & F_GELU) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = Gelu<T>::fwd(v[j]);
+        }
+        if (F & F_GELU_BWD) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] *= Gelu<T>::grad(ld[mi][j]);
+        }
+        if (F & F_RES) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaf(v[j], rs[mi], ld[mi][j]);
+        }
+        const int coff = m * (int)p.ldc + nb;
+        if (OUT_F32) {
+            float* cp = reinterpret_cast<float*>(p.C) + coff;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) *reinterpret_cast<float4*>(cp + 4 * h) = make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+        } else {
+            T* cp = reinterpret_cast<T*>(p.C) + coff;
+            Vec16<T> o;
+#pragma unroll
+            for (int h = 0; h < 16 / EPV; ++h) {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                st16(cp + h * EPV, o.raw);
+            }
+        }
+    }
+}
+
+// feature set of a launch if one of the specialised epilogues covers it, else F_GENERIC
+static inline int fast_epilogue_mask(const GemmP& p, bool out_f32) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const int esz = 2;  // bf16 kernels only
+    if (p.c_mode != LNX_ADDR_PLAIN || p.cmap.group > 0 || p.cmap.off != 0 || p.gamma) return F_GENERIC;
+    if (p.N % 16 != 0 || !al16(p.C) || (p.ldc * (out_f32 ? 4 : esz)) % 16 != 0) return F_GENERIC;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)p.M * p.ldc >= lim) return F_GENERIC;
+    int f = 0;
+    if (p.bias) {
+        if (!al16(p.bias)) return F_GENERIC;
+        f |= F_BIAS;
+    }
+    if (p.C2) {
+        if (!al16(p.C2) || (p.ldc2 * esz) % 16 != 0 || (int64_t)p.M * p.ldc2 >= lim) return F_GENERIC;
+        f |= F_C2;
+    }
+    if (p.act == LNX_ACT_GELU) f |= F_GELU;
+    else if (p.act == LNX_ACT_GELU_BWD) {
+        if (!al16(p.aux) || (p.ldaux * esz) % 16 != 0 || (int64_t)p.M * p.ldaux >= lim) return F_GENERIC;
+        f |= F_GELU_BWD;
+    } else if (p.act != LNX_ACT_NONE) return F_GENERIC;
+    if (p.res) {
+        if (!al16(p.res) || (p.ldres * 4) % 16 != 0 || (int64_t)p.M * p.ldres >= lim) return F_GENERIC;
+        f |= F_RES;
+    }
+    if (p.rowscale && !p.res) return F_GENERIC;
+    // the compiled forms
+    if (!out_f32 && (f == 0 || f == F_BIAS || f == (F_BIAS | F_C2 | F_GELU) || f == F_GELU_BWD)) return f;
+    if (out_f32 && f == (F_BIAS | F_RES)) return f;
+    return F_GENERIC;
 }
 
 struct WgradP {

@@ -743,7 +743,7 @@ struct Timed {
     hipStream_t st;
     bool on;
     lnx_plan::Span sp;
-    Timed(const Ctx& c, int cls, double work) : p(c.p), st((hipStream_t)c.st), on(c.p->profile) {
+    Timed(const Ctx& c, int cls, double work) : p(c.p), st((hipStream_t)c.st), on(c.p->profile && cls >= 0) {
         if (on) {
             sp.cls = cls;
             sp.work = work;
@@ -760,7 +760,9 @@ struct Timed {
     }
 };
 int gemm_nt_t(const Ctx& c, const lnx_gemm_args* a) {
-    Timed t(c, 0, 2.0 * a->M * a->N * a->K);
+    // profile classes 0/1 are the bulk GEMMs; the M = batch problems of the metadata heads and the tail (another
+    // kernel, partly on the side stream) are not counted
+    Timed t(c, a->M >= 1024 ? 0 : -1, 2.0 * a->M * a->N * a->K);
     return lnx_gemm_nt(a, c.st);
 }
 
@@ -822,7 +824,7 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
     a.dW = c.p->G[wparam]; a.lddw = lddw;
     a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
     a.k_store = k_store;
-    Timed t(c, 1, 2.0 * M * N * K);
+    Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K);
     return lnx_gemm_tn(&a, c.st);
 }
 

@@ -237,3 +237,34 @@ def test_tn_padded_logits_rows(M, dtype):
     torch.cuda.synchronize()
     torch.testing.assert_close(dW.double(), dY.double().T @ A.double(), rtol=1e-4, atol=2e-5 * M**0.5)
     torch.testing.assert_close(db.double(), dY.double().sum(0), rtol=1e-4, atol=2e-5 * M**0.5)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gelu_c2", "gelu_bwd", "res_f32"])
+def test_nt_specialised_epilogues(kind):
+    """Large aligned problems take the pipelined kernel with an epilogue compiled for its feature set (gemm2.hip,
+    gemm_epilogue_fast): check every form the plan launches, on a grid of 523 tiles (more than two per CU)."""
+    M, N, K = 256 * 523, 128, 192
+    g = torch.Generator().manual_seed(11)
+    A = (torch.randn(M, K, generator=g)).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / K**0.5).cuda().bfloat16()
+    b = torch.randn(N, generator=g).cuda()
+    z = A.double() @ W.double().T + b.double()
+    if kind == "plain":
+        out, _ = run_nt(A, W, L.BF16, True, bias=b)
+        torch.testing.assert_close(out.double(), z, rtol=2e-5, atol=1e-4)
+    elif kind == "gelu_c2":
+        out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU, want_c2=True)
+        torch.testing.assert_close(c2.float(), z.float(), rtol=8e-3, atol=8e-3)
+        torch.testing.assert_close(out.float(), torch.nn.functional.gelu(z).float(), rtol=8e-3, atol=8e-3)
+    elif kind == "gelu_bwd":
+        aux = torch.randn(M, N, generator=g).cuda().bfloat16()
+        out, _ = run_nt(A, W, L.BF16, False, act=L.ACT_GELU_BWD, aux=aux)
+        x = aux.double().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        torch.testing.assert_close(out.float(), ((z - b.double()) * x.grad).float(), rtol=1e-2, atol=1e-2)
+    else:
+        res = torch.randn(M, N, generator=g).cuda()
+        rs = (torch.rand(523, generator=g) > 0.3).float().cuda() / 0.7
+        out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
+        ref = res.double() + z * rs.double().repeat_interleave(256)[:, None]
+        torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
