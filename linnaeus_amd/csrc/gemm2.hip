@@ -243,9 +243,11 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
     const int wr = wave / WC, wc = wave % WC;
     const int s = lane & 15, g = lane >> 4;
 
-    int bid = blockIdx.x;
-    const int split = bid % p.splits;
-    bid /= p.splits;
+    // workgroups of one split (the same contraction rows, different output tiles) are consecutive logical ids, i.e.
+    // on one XCD at about the same time: its L2 then serves the tiles_k re-reads of dY and the tiles_n re-reads of A
+    int bid = xcd_remap(blockIdx.x, p.tiles_n * p.tiles_k * p.splits);
+    const int split = bid / (p.tiles_n * p.tiles_k);
+    bid -= split * (p.tiles_n * p.tiles_k);
     const int tc = bid % p.tiles_k;
     const int tr = bid / p.tiles_k;
     const int n0 = tr * RW, k0 = tc * CW;
@@ -316,27 +318,41 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
 
     issue_tile(0);
     if (ntile > 1) issue_tile(1);
+    // Ping-pong schedule as in gemm_nt_v2_kernel: waves 0-3 / 4-7 run half a contraction tile apart, so the 32
+    // transposed fragment reads and the 6 LDS-DMA pieces of one wave are issued under the 40 MFMAs of its SIMD
+    // partner (in lock step a tile took ~2600 cycles on an otherwise idle chip against 1280 cycles of MFMA).
+    const int grp = wave >> 2;
+    if (ntile > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < ntile) issue_tile((t + 2) % NSTAGE);
         const uint32_t st = lds_base + (t % NSTAGE) * STG;
+        uint2 rl[2][4], rh[2][4], cl[2][4], chh[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint2 rl[4], rh[4], cl[4], chh[4];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                DS_READ_TR2(rl[i], rh[i], st + offR[ks][i], 16 * RROW);
-                DS_READ_TR2(cl[i], chh[i], st + offC[ks][i], 16 * CROW);
+                DS_READ_TR2(rl[ks][i], rh[ks][i], st + offR[ks][i], 16 * RROW);
+                DS_READ_TR2(cl[ks][i], chh[ks][i], st + offC[ks][i], 16 * CROW);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntile) {
+            issue_tile((t + 2) % NSTAGE);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             uint4 rf[4], cf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                rf[i] = make_uint4(rl[i].x, rl[i].y, rh[i].x, rh[i].y);
-                cf[i] = make_uint4(cl[i].x, cl[i].y, chh[i].x, chh[i].y);
+                rf[i] = make_uint4(rl[ks][i].x, rl[ks][i].y, rh[ks][i].x, rh[ks][i].y);
+                cf[i] = make_uint4(cl[ks][i].x, cl[ks][i].y, chh[ks][i].x, chh[ks][i].y);
             }
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri)
@@ -347,6 +363,9 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
                 for (int ri = 0; ri < 4; ++ri) Mfma<T>::run(accb[ri], rf[ri], ones);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp && t + 1 == ntile)) __builtin_amdgcn_s_barrier();
     }
     if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
