@@ -81,7 +81,9 @@ typedef struct lnx_gemm_args {
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 
 /* Weight gradient  dW[N,K] += dY[M,N]^T . A[M,K]  and optionally db[N] += colsum(dY).
- * Split over M across workgroups, fp32 atomics into dW/db (caller zeroes them).
+ * Split over M across workgroups.  Partial tiles are added to dW/db with fp32 atomics, or, when the
+ * caller passes a workspace (ws), stored there and summed into dW/db by a second kernel in a fixed
+ * order (faster: no memory-side atomics; and bit-reproducible).  dW/db accumulate: caller zeroes them.
  * Replaces autograd's weight/bias gradient of every Linear/patchify conv above. */
 typedef struct lnx_wgrad_args {
     int dtype;
@@ -98,7 +100,10 @@ typedef struct lnx_wgrad_args {
     float* db;      /* [N] or NULL */
     int splits;     /* 0: choose automatically */
     int k_store;    /* >0: only columns k < k_store are stored (zero-padded K) */
+    float* ws;      /* optional split-K workspace (device), NULL = atomics */
+    int64_t ws_floats; /* its size; LNX_TN_WS_FLOATS always suffices */
 } lnx_wgrad_args;
+#define LNX_TN_WS_FLOATS (256 * (256 * 128 + 256))
 
 int lnx_gemm_tn(const lnx_wgrad_args* args, void* stream);
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liblnx_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+TN_WS_FLOATS = 256 * (256 * 128 + 256)  # == LNX_TN_WS_FLOATS
 ADDR_PLAIN, ADDR_PATCH2 = 0, 1
 
 
@@ -52,6 +53,8 @@ class WgradArgs(C.Structure):
         ("k_perm_c", C.c_int),
         ("db", C.c_void_p),
         ("splits", C.c_int),
+        ("k_store", C.c_int),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

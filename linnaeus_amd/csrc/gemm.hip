@@ -427,6 +427,8 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     p.a_mode = a->a_mode;
     p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
     p.k_perm_c = a->k_perm_c;
+    p.ws = a->ws;
+    p.ws_floats = a->ws ? a->ws_floats : 0;
     p.dbg = getenv("LNX_TN_DBG") ? atoi(getenv("LNX_TN_DBG")) : 0;
     p.k_store = (a->k_store > 0 && a->k_store < a->K) ? a->k_store : a->K;
     p.tiles_n = cdiv(a->N, TILE);

@@ -368,6 +368,21 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
         if (!(grp && t + 1 == ntile)) __builtin_amdgcn_s_barrier();
     }
     if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+    if (p.ws) {
+        // split-K partials: this workgroup's whole RW x CW tile, unmasked, to its slot of the workspace
+        const int tiles = p.tiles_n * p.tiles_k;
+        float* wt = p.ws + (size_t)(split * tiles + tr * p.tiles_k + tc) * (RW * CW);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wr * 64 + ri * 16 + 4 * g + r;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) wt[row * CW + wc * 64 + ci * 16 + s] = acc[ri][ci][r];
+                if (do_bias && s == 0) p.ws[(size_t)p.splits * tiles * (RW * CW) + (size_t)(split * p.tiles_n + tr) * RW + row] = accb[ri][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
 #pragma unroll
@@ -387,6 +402,59 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
                 atomicAdd(p.dW + (int64_t)n * p.lddw + col, acc[ri][ci][r]);
             }
             if (do_bias && s == 0) atomicAdd(p.db + n, accb[ri][r]);
+        }
+    }
+}
+
+// second stage of the workspace path: dW[n, col(k)] += sum over splits of the partial tiles, db likewise
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int RW, int CW) {
+    const int kq = (p.k_store + 3) >> 2;  // float4 groups per output row
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int tiles = p.tiles_n * p.tiles_k;
+    const size_t tile_floats = (size_t)RW * CW;
+    if (idx < (int64_t)p.N * kq) {
+        const int n = (int)(idx / kq), k = (int)(idx - (int64_t)n * kq) * 4;
+        const int tr = n / RW, tc = k / CW;
+        const float* src = p.ws + (size_t)(tr * p.tiles_k + tc) * tile_floats + (size_t)(n - tr * RW) * CW + (k - tc * CW);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < p.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sp * tiles * tile_floats);
+            a.x += v.x;
+            a.y += v.y;
+            a.z += v.z;
+            a.w += v.w;
+        }
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float* drow = p.dW + (int64_t)n * p.lddw;
+        if (p.k_perm_c > 0) {
+            const int P = p.K / p.k_perm_c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k + j;
+                if (kk >= p.k_store) break;
+                const int pq = kk / p.k_perm_c;
+                drow[(kk - pq * p.k_perm_c) * P + pq] += av[j];
+            }
+        } else if (k + 3 < p.k_store && ((((uintptr_t)(drow + k)) & 15) == 0)) {
+            float4 d = *reinterpret_cast<float4*>(drow + k);
+            d.x += a.x;
+            d.y += a.y;
+            d.z += a.z;
+            d.w += a.w;
+            *reinterpret_cast<float4*>(drow + k) = d;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k + j < p.k_store) drow[k + j] += av[j];
+        }
+    } else if (p.db != nullptr) {
+        const int64_t n = idx - (int64_t)p.N * kq;
+        if (n < p.N) {
+            const int tr = (int)n / RW;
+            const float* src = p.ws + (size_t)p.splits * tiles * tile_floats + (size_t)tr * RW + (n - tr * RW);
+            float a = 0.f;
+            for (int sp = 0; sp < p.splits; ++sp) a += src[(size_t)sp * p.tiles_n * RW];
+            p.db[n] += a;
         }
     }
 }
@@ -428,9 +496,16 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
         }                                                                                                                            \
         hipLaunchKernelGGL((gemm_tn_v2_kernel<R, C>), dim3(grid), dim3(512), lds, st, p);                                            \
     } while (0)
+    static const bool no_ws = getenv("LNX_TN_ATOMIC") != nullptr;  // A/B switch for benchmarking
+    const size_t need = (size_t)p.splits * tiles * (256 * 128) + (size_t)p.splits * p.tiles_n * RW;
+    if (no_ws || p.ws == nullptr || (size_t)p.ws_floats < need || p.splits < 2) p.ws = nullptr;
     if (wide_r) TNV2(256, 128);
     else TNV2(128, 256);
 #undef TNV2
+    if (p.ws) {
+        const int64_t work = (int64_t)p.N * ((p.k_store + 3) >> 2) + (p.db ? p.N : 0);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, st, p, RW, CW);
+    }
     return 0;
 }
 

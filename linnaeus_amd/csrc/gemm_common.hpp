@@ -385,6 +385,8 @@ struct WgradP {
     PatchGeom pg;
     int k_perm_c, k_store;
     int dbg;  // benchmarking only: 1 = skip the atomic epilogue
+    float* ws;  // split-K partial tiles (gemm2.hip) or nullptr = atomics
+    int64_t ws_floats;
     int tiles_n, tiles_k, splits, m_per_split;
 };
 

@@ -119,6 +119,7 @@ struct lnx_plan {
     int64_t o_g[4];           // fp32 gradient streams per stage
     int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
     int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
+    int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     const float* last_drop = nullptr;
     const unsigned char* last_mask = nullptr;
@@ -582,6 +583,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->o_lnws = cv.take(p->lnws_floats * 4);
     p->lnws_side_floats = (int64_t)256 * 2 * D[3];
     p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
+    p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
     p->o_sA = cv.take(maxM4C * esz);
     if (any_fused) p->o_sB = cv.take(maxM4C * esz);
     p->o_sC = cv.take(maxMC * esz);
@@ -824,6 +826,10 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
     a.dW = c.p->G[wparam]; a.lddw = lddw;
     a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
     a.k_store = k_store;
+    if (!(c.p->side != nullptr && c.st == (void*)c.p->side)) {  // one workspace: never from the side stream
+        a.ws = c.at<float>(c.p->o_tnws);
+        a.ws_floats = LNX_TN_WS_FLOATS;
+    }
     Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K);
     return lnx_gemm_tn(&a, c.st);
 }

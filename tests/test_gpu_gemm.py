@@ -154,11 +154,11 @@ def test_nt_patch2_modes(dtype, small):
     torch.testing.assert_close(_patches_nhwc(dx).double(), refp, rtol=3e-5, atol=3e-5)
 
 
-def run_tn(dY, A, dtype, bias=True, splits=0, k_perm_c=0, patch=None):
+def run_tn(dY, A, dtype, bias=True, splits=0, k_perm_c=0, patch=None, ws=False, k_store=0, init=0.0):
     M, N = dY.shape
     K = A.shape[1] if patch is None else 4 * patch[2]
-    dW = torch.zeros(N, K, device="cuda")
-    db = torch.zeros(N, device="cuda") if bias else None
+    dW = torch.full((N, K), init, device="cuda")
+    db = torch.full((N,), init, device="cuda") if bias else None
     a = L.WgradArgs()
     a.dtype, a.M, a.N, a.K = dtype, M, N, K
     a.dY, a.lddy, a.A = _ptr(dY), dY.stride(0), _ptr(A)
@@ -166,7 +166,10 @@ def run_tn(dY, A, dtype, bias=True, splits=0, k_perm_c=0, patch=None):
         a.lda = A.stride(0)
     else:
         a.a_mode, a.Hin, a.Win, a.Cin = L.ADDR_PATCH2, *patch
-    a.dW, a.lddw, a.db, a.splits, a.k_perm_c = _ptr(dW), K, _ptr(db), splits, k_perm_c
+    a.dW, a.lddw, a.db, a.splits, a.k_perm_c, a.k_store = _ptr(dW), K, _ptr(db), splits, k_perm_c, k_store
+    if ws:
+        wsb = torch.full((L.TN_WS_FLOATS,), float("nan"), device="cuda")
+        a.ws, a.ws_floats = _ptr(wsb), wsb.numel()
     L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
     torch.cuda.synchronize()
     return dW, db
@@ -268,3 +271,20 @@ def test_nt_specialised_epilogues(kind):
         out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
         ref = res.double() + z * rs.double().repeat_interleave(256)[:, None]
         torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K,kpc", [(8192, 96, 384, 0), (12800, 384, 1536, 0), (50944, 1536, 384, 0), (6400, 1000, 768, 0), (8192, 192, 384, 96)])
+def test_tn_workspace_reduction(M, N, K, kpc):
+    """Split-K through the workspace (partial tiles + fixed-order reduce kernel) instead of atomics: same result as
+    fp64, accumulates onto what dW/db already hold, honours the conv-weight column permutation, and is bit-reproducible."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dY = torch.randn(M, N, generator=g).cuda().bfloat16()
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    dW, db = run_tn(dY, A, L.BF16, ws=True, k_perm_c=kpc, init=0.5)
+    ref = dY.double().T @ A.double()
+    if kpc:
+        ref = ref.reshape(N, K // kpc, kpc).transpose(1, 2).reshape(N, K)
+    torch.testing.assert_close(dW.double(), ref + 0.5, rtol=1e-4, atol=2e-5 * M**0.5)
+    torch.testing.assert_close(db.double(), dY.double().sum(0) + 0.5, rtol=1e-4, atol=2e-5 * M**0.5)
+    dW2, db2 = run_tn(dY, A, L.BF16, ws=True, k_perm_c=kpc, init=0.5)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)

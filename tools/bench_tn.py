@@ -13,11 +13,12 @@ def time_it(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e-3
 for name, M, N, K in [("r0.fc1", 50944, 1536, 384), ("r0.fc2", 50944, 384, 1536), ("r0.proj", 50944, 384, 384), ("r1.fc1", 13312, 3072, 768), ("s0.pw1", 802816, 384, 96), ("s1.pw2", 200704, 192, 768)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); dY = torch.randn(M, N, device="cuda").bfloat16()
-    dW = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    dW = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda"); wsb = torch.empty(L.TN_WS_FLOATS, device="cuda")
     res = []
-    for splits in (0, 1, 2, 4, 8, 16, 32, 64):
+    for splits in (0,):
         w = L.WgradArgs(); w.dtype, w.M, w.N, w.K = L.BF16, M, N, K
         w.dY, w.lddy, w.A, w.lda, w.dW, w.lddw, w.db, w.splits = ptr(dY), N, ptr(A), K, ptr(dW), K, ptr(db), splits
+        if os.environ.get("TN_WS", "1") == "1": w.ws, w.ws_floats = ptr(wsb), wsb.numel()
         t = time_it(lambda: L.check(L.lib().lnx_gemm_tn(C.byref(w), st()), "tn"))
         res.append(f"s{splits}:{t*1e6:.0f}us/{2.0*M*N*K/t/1e12:.0f}TF")
     print(name, " ".join(res), flush=True)
