@@ -88,7 +88,9 @@ def test_nt_epilogues(dtype):
     tol = dict(rtol=3e-5, atol=3e-5)
     # GELU with second output (pre-activation)
     out, c2 = run_nt(A, W, dtype, True, bias=b, act=L.ACT_GELU, want_c2=True)
-    torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **tol)
+    # bf16 mode evaluates erf by a polynomial with |GELU error| <= 5.8e-5 (common.hpp); fp32 mode uses libm erff
+    gtol = tol if dtype == L.F32 else dict(rtol=3e-5, atol=1e-4)
+    torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **gtol)
     torch.testing.assert_close(c2.double(), z, rtol=1e-5 if dtype == L.F32 else 8e-3, atol=1e-5 if dtype == L.F32 else 8e-3)
     # LayerScale * DropPath + residual, pre-gamma value saved
     out, c2 = run_nt(A, W, dtype, True, bias=b, gamma=gam, rowscale=rs, rps=rows, res=res, want_c2=True)

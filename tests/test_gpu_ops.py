@@ -279,7 +279,7 @@ def test_convmlp_fused_fwd_bwd(C_, M):
     zr = act @ w2d.T + b2.double()
     s = rs.double().repeat_interleave(rps)[:M, None]
     ref = x.double() + s * gam.double() * zr
-    torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(out.double(), ref, rtol=2e-3, atol=4e-3)  # one bf16 ulp flip of a hidden unit ~ 2e-3
     torch.testing.assert_close(z.double(), zr, rtol=1.6e-2, atol=1.6e-2)
     # backward
     gout = torch.randn(M, C_, generator=gen).cuda()
