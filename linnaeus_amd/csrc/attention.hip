@@ -104,11 +104,13 @@ __device__ __forceinline__ void load_row_frag(uint4 (&f)[AT<T>::NKK], const T* _
 }
 
 // acc[t] (t = 0..3, 16 rows each) = Rows(img, row0 + 16 t + s) . frag^T over the 64 channels
+// nt = number of 16-row groups of the tile that hold real tokens (the rest is padding: skipped, acc = 0)
 template <typename T>
-__device__ __forceinline__ void rows_times_frag(f32x4_t (&acc)[4], const unsigned char* rowimg, int s, int g, const uint4 (&frag)[AT<T>::NKK]) {
+__device__ __forceinline__ void rows_times_frag(f32x4_t (&acc)[4], const unsigned char* rowimg, int s, int g, const uint4 (&frag)[AT<T>::NKK], int nt = 4) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (t >= nt) continue;
         const int row = t * 16 + s;
 #pragma unroll
         for (int kk = 0; kk < AT<T>::NKK; ++kk) {
@@ -120,8 +122,9 @@ __device__ __forceinline__ void rows_times_frag(f32x4_t (&acc)[4], const unsigne
 
 // out[dt] += Img^T . P   where P[t][r] holds, for the lane's column, the value of tile row
 // 16 t + 4 g + r (t = 0..3) -- i.e. contraction over the 64 tile rows.
+// nt as above: 32-row contraction steps made of padding only are skipped
 template <typename T>
-__device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigned char* trimg, int s, int g, const float (&p)[4][4]) {
+__device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigned char* trimg, int s, int g, const float (&p)[4][4], int nt = 4) {
     if constexpr (sizeof(T) == 2) {
         uint4 pf[2];
 #pragma unroll
@@ -133,6 +136,7 @@ __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigne
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (2 * ks >= nt) continue;
             const int r0 = ks * 32 + 4 * g + (s >> 2);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -144,7 +148,8 @@ __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigne
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nt) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = t * 16 + 4 * g + r;
@@ -154,6 +159,22 @@ __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigne
                     mfma_f32(out[dt], a, p[t][r]);
                 }
             }
+        }
+    }
+}
+
+// four consecutive elements in one store (8 bytes of bf16 / 16 bytes of fp32); p is 8-/16-byte aligned
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) {
+    if constexpr (sizeof(T) == 2) {
+        uint2 r;
+        T* h = reinterpret_cast<T*>(&r);
+        h[0] = from_f<T>(a);
+        h[1] = from_f<T>(b);
+        h[2] = from_f<T>(c);
+        h[3] = from_f<T>(d);
+        *reinterpret_cast<uint2*>(p) = r;
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
     }
 }
 
@@ -528,9 +549,7 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const AttnP p) {
         if (q < p.N) {
             T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) op[dt * 16 + 4 * g + r] = from_f<T>(oacc[dt][r] * inv);
+            for (int dt = 0; dt < 4; ++dt) store4<T>(op + dt * 16 + 4 * g, oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
             if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
         }
     }
@@ -585,8 +604,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
         for (int i = 0; i < 4; ++i) dq[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nkt; ++kt) {
             f32x4_t sacc[4], dpacc[4];
-            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf);
-            rows_times_frag<T>(dpacc, vimg + kt * BT * AT<T>::ROWB, s, g, dof);
+            const int nt = min(4, (p.N - kt * BT + 15) >> 4);  // 16-key groups of this tile that are not padding
+            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf, nt);
+            rows_times_frag<T>(dpacc, vimg + kt * BT * AT<T>::ROWB, s, g, dof, nt);
             float ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -596,7 +616,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
                     const float pr = (key < p.N && q < p.N) ? __expf(sacc[t][r] - lse) : 0.f;
                     ds[t][r] = pr * (dpacc[t][r] - delta);
                 }
-            imgT_times_regs<T>(dq, ktr + kt * BT * AT<T>::TRB, s, g, ds);
+            imgT_times_regs<T>(dq, ktr + kt * BT * AT<T>::TRB, s, g, ds, nt);
         }
         if (q < p.N) {
             T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
@@ -607,14 +627,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int d = d0 + 2 * pr;
-                    const float c = img ? cp[d >> 1] : 1.0f;
-                    const float g0 = dq[dt][2 * pr], g1 = dq[dt][2 * pr + 1];
-                    dqp[d] = from_f<T>(g0 * c * scale);
-                    dqp[d + 1] = from_f<T>(g1 * c * scale);
-                    if (img) gq[d >> 1] = scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1]));
+                const float c0 = img ? cp[d0 >> 1] * scale : scale, c1 = img ? cp[(d0 >> 1) + 1] * scale : scale;
+                store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
+                if (img) {
+                    gq[d0 >> 1] = scale * (dq[dt][0] * to_f(qraw[d0]) + dq[dt][1] * to_f(qraw[d0 + 1]));
+                    gq[(d0 >> 1) + 1] = scale * (dq[dt][2] * to_f(qraw[d0 + 2]) + dq[dt][3] * to_f(qraw[d0 + 3]));
                 }
             }
         }
@@ -664,8 +681,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
         }
         for (int qt = 0; qt < nqt; ++qt) {
             f32x4_t sacc[4], dpacc[4];
-            rows_times_frag<T>(sacc, qimg + qt * BT * AT<T>::ROWB, s, g, kf);
-            rows_times_frag<T>(dpacc, doimg + qt * BT * AT<T>::ROWB, s, g, vf);
+            const int nt = min(4, (p.N - qt * BT + 15) >> 4);  // 16-query groups of this tile that are not padding
+            rows_times_frag<T>(sacc, qimg + qt * BT * AT<T>::ROWB, s, g, kf, nt);
+            rows_times_frag<T>(dpacc, doimg + qt * BT * AT<T>::ROWB, s, g, vf, nt);
             float pr[4][4], ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -676,8 +694,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
                     pr[t][r] = pp;
                     ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
                 }
-            imgT_times_regs<T>(dv, dotr + qt * BT * AT<T>::TRB, s, g, pr);
-            imgT_times_regs<T>(dk, qtr + qt * BT * AT<T>::TRB, s, g, ds);
+            imgT_times_regs<T>(dv, dotr + qt * BT * AT<T>::TRB, s, g, pr, nt);
+            imgT_times_regs<T>(dk, qtr + qt * BT * AT<T>::TRB, s, g, ds, nt);
         }
         if (key < p.N) {
             T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
@@ -689,16 +707,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
-#pragma unroll
-                for (int pq = 0; pq < 2; ++pq) {
-                    const int d = d0 + 2 * pq;
-                    const float c = img ? cp[d >> 1] : 1.0f;
-                    const float g0 = dk[dt][2 * pq], g1 = dk[dt][2 * pq + 1];
-                    dkp[d] = from_f<T>(g0 * c);
-                    dkp[d + 1] = from_f<T>(g1 * c);
-                    dvp[d] = from_f<T>(dv[dt][2 * pq]);
-                    dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
-                    if (img) gk[d >> 1] = g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]);
+                const float c0 = img ? cp[d0 >> 1] : 1.0f, c1 = img ? cp[(d0 >> 1) + 1] : 1.0f;
+                store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
+                store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+                if (img) {
+                    gk[d0 >> 1] = dk[dt][0] * to_f(kraw[d0]) + dk[dt][1] * to_f(kraw[d0 + 1]);
+                    gk[(d0 >> 1) + 1] = dk[dt][2] * to_f(kraw[d0 + 2]) + dk[dt][3] * to_f(kraw[d0 + 3]);
                 }
             }
         }

@@ -416,14 +416,42 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int
         const int n = (int)(idx / kq), k = (int)(idx - (int64_t)n * kq) * 4;
         const int tr = n / RW, tc = k / CW;
         const float* src = p.ws + (size_t)(tr * p.tiles_k + tc) * tile_floats + (size_t)(n - tr * RW) * CW + (k - tc * CW);
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sp = 0; sp < p.splits; ++sp) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sp * tiles * tile_floats);
-            a.x += v.x;
-            a.y += v.y;
-            a.z += v.z;
-            a.w += v.w;
+        // eight independent loads in flight per thread; the summation order is fixed (partials of splits sp = j mod 8
+        // are added in order, the remainder goes to sum 0, then the eight sums are combined pairwise)
+        float4 part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t sstep = (size_t)tiles * tile_floats;
+        int sp = 0;
+        for (; sp + 8 <= p.splits; sp += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(src + (size_t)(sp + j) * sstep);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                part[j].x += v[j].x;
+                part[j].y += v[j].y;
+                part[j].z += v[j].z;
+                part[j].w += v[j].w;
+            }
         }
+        for (; sp < p.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sp * sstep);
+            part[0].x += v.x;
+            part[0].y += v.y;
+            part[0].z += v.z;
+            part[0].w += v.w;
+        }
+#pragma unroll
+        for (int w = 4; w > 0; w >>= 1)
+#pragma unroll
+            for (int j = 0; j < w; ++j) {
+                part[j].x += part[j + w].x;
+                part[j].y += part[j + w].y;
+                part[j].z += part[j + w].z;
+                part[j].w += part[j + w].w;
+            }
+        const float4 a = part[0];
         const float av[4] = {a.x, a.y, a.z, a.w};
         float* drow = p.dW + (int64_t)n * p.lddw;
         if (p.k_perm_c > 0) {
