@@ -122,6 +122,24 @@ __device__ __forceinline__ void rows_times_frag(f32x4_t (&acc)[4], const unsigne
 
 // out[dt] += Img^T . P   where P[t][r] holds, for the lane's column, the value of tile row
 // 16 t + 4 g + r (t = 0..3) -- i.e. contraction over the 64 tile rows.
+// Same product from the PADDED image (rows of TRB = 160 bytes, unswizzled): at that pitch the 16-byte fragment reads
+// of every 16-lane group of a ds_read_b128 also fall on 16 distinct bank slots, so one image serves both the row
+// fragments and the transposed reads (half the LDS of keeping a swizzled row image beside it).
+template <typename T>
+__device__ __forceinline__ void rows_times_frag_pad(f32x4_t (&acc)[4], const unsigned char* img, int s, int g, const uint4 (&frag)[AT<T>::NKK], int nt) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (t >= nt) continue;
+        const int row = t * 16 + s;
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            const uint4 a = ld16(img + row * AT<T>::TRB + ((kk * 4 + g) << 4));
+            mfma_chunk<T>(acc[t], a, frag[kk]);
+        }
+    }
+}
+
 // nt as above: 32-row contraction steps made of padding only are skipped
 template <typename T>
 __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigned char* trimg, int s, int g, const float (&p)[4][4], int nt = 4) {
@@ -556,13 +574,12 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const AttnP p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkt = (p.N + BT - 1) / BT;
-    const int npad = nkt * BT;
-    unsigned char* kimg = smem;
-    unsigned char* vimg = kimg + npad * AT<T>::ROWB;
-    unsigned char* ktr = vimg + npad * AT<T>::ROWB;
+    const int npad = (p.N + 31) & ~31;  // image rows: padding groups beyond it are never read (nt below)
+    unsigned char* kimg = smem;         // padded-pitch images: row fragments AND transposed reads
+    unsigned char* vimg = kimg + npad * AT<T>::TRB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, g = lane >> 4;
     const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
@@ -574,8 +591,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
     const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
     const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
-    stage_all<T, true, true, true>(kimg, ktr, kb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
-    stage_all<T, false, true, false>(vimg, nullptr, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
+    stage_all<T, true, false, true>(nullptr, kimg, kb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+    stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
     for (int qt = wave; qt < nq16; qt += 8) {
@@ -605,8 +622,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
         for (int kt = 0; kt < nkt; ++kt) {
             f32x4_t sacc[4], dpacc[4];
             const int nt = min(4, (p.N - kt * BT + 15) >> 4);  // 16-key groups of this tile that are not padding
-            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf, nt);
-            rows_times_frag<T>(dpacc, vimg + kt * BT * AT<T>::ROWB, s, g, dof, nt);
+            rows_times_frag_pad<T>(sacc, kimg + kt * BT * AT<T>::TRB, s, g, qf, nt);
+            rows_times_frag_pad<T>(dpacc, vimg + kt * BT * AT<T>::TRB, s, g, dof, nt);
             float ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
                     const float pr = (key < p.N && q < p.N) ? __expf(sacc[t][r] - lse) : 0.f;
                     ds[t][r] = pr * (dpacc[t][r] - delta);
                 }
-            imgT_times_regs<T>(dq, ktr + kt * BT * AT<T>::TRB, s, g, ds, nt);
+            imgT_times_regs<T>(dq, kimg + kt * BT * AT<T>::TRB, s, g, ds, nt);
         }
         if (q < p.N) {
             T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
@@ -639,16 +656,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const AttnP p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dkv_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nqt = (p.N + BT - 1) / BT;
-    const int npad = nqt * BT;
-    unsigned char* qimg = smem;
-    unsigned char* doimg = qimg + npad * AT<T>::ROWB;
-    unsigned char* qtr = doimg + npad * AT<T>::ROWB;
-    unsigned char* dotr = qtr + npad * AT<T>::TRB;
-    float* lse_s = reinterpret_cast<float*>(dotr + npad * AT<T>::TRB);
-    float* del_s = lse_s + npad;
+    const int npad = (p.N + 31) & ~31;
+    unsigned char* qimg = smem;  // padded-pitch images: row fragments AND transposed reads
+    unsigned char* doimg = qimg + npad * AT<T>::TRB;
+    float* lse_s = reinterpret_cast<float*>(doimg + npad * AT<T>::TRB);
+    float* del_s = lse_s + nqt * BT;  // statistics are indexed by every query slot of a 64-query tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = lane & 15, g = lane >> 4;
     const int head = blockIdx.x % p.heads, b = blockIdx.x / p.heads;
@@ -660,9 +675,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
     const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
     const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
-    stage_all<T, true, true, true>(qimg, qtr, qb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, scale);
-    stage_all<T, false, true, true>(doimg, dotr, dob, C, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
-    for (int i = threadIdx.x; i < npad; i += blockDim.x) {
+    stage_all<T, true, false, true>(nullptr, qimg, qb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, scale);
+    stage_all<T, false, false, true>(nullptr, doimg, dob, C, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
+    for (int i = threadIdx.x; i < nqt * BT; i += blockDim.x) {
         lse_s[i] = i < p.N ? p.lse[statbase + i] : 0.f;
         del_s[i] = i < p.N ? p.delta[statbase + i] : 0.f;
     }
@@ -682,8 +697,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
         for (int qt = 0; qt < nqt; ++qt) {
             f32x4_t sacc[4], dpacc[4];
             const int nt = min(4, (p.N - qt * BT + 15) >> 4);  // 16-query groups of this tile that are not padding
-            rows_times_frag<T>(sacc, qimg + qt * BT * AT<T>::ROWB, s, g, kf, nt);
-            rows_times_frag<T>(dpacc, doimg + qt * BT * AT<T>::ROWB, s, g, vf, nt);
+            rows_times_frag_pad<T>(sacc, qimg + qt * BT * AT<T>::TRB, s, g, kf, nt);
+            rows_times_frag_pad<T>(dpacc, doimg + qt * BT * AT<T>::TRB, s, g, vf, nt);
             float pr[4][4], ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -694,8 +709,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const AttnP p) {
                     pr[t][r] = pp;
                     ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
                 }
-            imgT_times_regs<T>(dv, dotr + qt * BT * AT<T>::TRB, s, g, pr, nt);
-            imgT_times_regs<T>(dk, qtr + qt * BT * AT<T>::TRB, s, g, ds, nt);
+            imgT_times_regs<T>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr, nt);
+            imgT_times_regs<T>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds, nt);
         }
         if (key < p.N) {
             T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
@@ -836,13 +851,13 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->dtype == LNX_BF16 && a->N <= 256 && getenv("LNX_ATTN_TILED") == nullptr) {
         typedef bf16_t T;
-        const int npad = p.qtiles * BT;
-        const size_t lds_q = (size_t)npad * (2 * AT<T>::ROWB + AT<T>::TRB);
-        const size_t lds_k = (size_t)npad * (2 * AT<T>::ROWB + 2 * AT<T>::TRB + 2 * sizeof(float));
+        const int npad = (a->N + 31) & ~31;
+        const size_t lds_q = (size_t)npad * (2 * AT<T>::TRB);
+        const size_t lds_k = (size_t)npad * (2 * AT<T>::TRB) + (size_t)p.qtiles * BT * 2 * sizeof(float);
         static bool once = false;
         if (!once) {
-            set_lds(attn_bwd_dq_res_kernel<T>, 256 * (2 * AT<T>::ROWB + AT<T>::TRB));
-            set_lds(attn_bwd_dkv_res_kernel<T>, 256 * (2 * AT<T>::ROWB + 2 * AT<T>::TRB + 2 * sizeof(float)));
+            set_lds(attn_bwd_dq_res_kernel<T>, 256 * (2 * AT<T>::TRB));
+            set_lds(attn_bwd_dkv_res_kernel<T>, 256 * (2 * AT<T>::TRB + 2 * sizeof(float)));
             once = true;
         }
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_q, st, p);
