@@ -501,7 +501,7 @@ __device__ __forceinline__ void stage_all(unsigned char* rowimg, unsigned char* 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_res_kernel(const AttnP p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkt = (p.N + BT - 1) / BT;
     const int npad = nkt * BT;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void attn_fwd_res_kernel(const AttnP p) {
     stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
-    for (int qt = wave; qt < nq16; qt += 4) {
+    for (int qt = wave; qt < nq16; qt += 8) {
         const int q = qt * 16 + s;
         uint4 qf[AT<T>::NKK];
         load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
@@ -826,7 +826,7 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
             set_lds(attn_fwd_res_kernel<T>, 256 * (AT<T>::ROWB + AT<T>::TRB));
             once = true;
         }
-        hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds, st, p);
     } else if (a->dtype == LNX_BF16) {
         const size_t lds = AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG;
         hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, p);
