@@ -217,9 +217,17 @@ def main():
                 per["gbs"] = round(work[i] / (ms[i] * 1e-3) / 1e9, 1)
             kernels[nm] = per
         a = work[0] / (ms[0] * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_kernel<{args.dtype}> (forward + data-gradient GEMMs, fused epilogues)",
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure comes
+        # from the committed rocprofv3 --pmc passes of this same command (profiles/*_gemm_nt_traffic.json); null otherwise
+        traffic = None
+        if args.arch == "sm" and args.batch == 256 and args.dtype == "bf16" and args.img == 224:
+            cands = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_gemm_nt_traffic.json")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
+            if cands:
+                with open(os.path.join(REPO, "profiles", cands[-1])) as f:
+                    traffic = json.load(f)["bytes_per_launch"]
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2_kernel<{args.dtype}> (forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
                     "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
+                    "traffic": traffic, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                     "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
                     "flops_per_step": work[0] / args.profile_steps}
 
