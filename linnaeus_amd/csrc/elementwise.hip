@@ -172,8 +172,13 @@ __global__ __launch_bounds__(256) void pack_meta_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------
 constexpr int PREP_ELEMS = 2048;  // destination elements per workgroup
 
+constexpr int PREP_TR = 32, PREP_TK = 64;  // transposed copy: source tile of 32 rows x 64 columns per workgroup
+
+__host__ __device__ inline int prep_main_blocks(int rows, int ld) { return (int)(((int64_t)rows * ld + PREP_ELEMS - 1) / PREP_ELEMS); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weights_kernel(const lnx_prep_desc* __restrict__ descs, int ndesc) {
+    __shared__ float tile[PREP_TK][PREP_TR + 1];
     // binary search: last descriptor with block_start <= blockIdx.x
     int lo = 0, hi = ndesc - 1;
     while (lo < hi) {
@@ -196,35 +201,38 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const lnx_prep_desc* 
         return;
     }
     const int cols_out = d.cols;  // logical K of the operand
-    for (int64_t i = base + threadIdx.x; i < base + PREP_ELEMS; i += 256) {
-        if (i < n_main) {
+    const int Cc = d.mode == LNX_PREP_CONV_PERM ? d.cols / d.P : 1;
+    auto src_col = [&](int k) {  // CONV_PERM: k = p*C + c  <-  src column c*P + p
+        if (d.mode != LNX_PREP_CONV_PERM) return k;
+        const int pp = k / Cc;
+        return (k - pp * Cc) * d.P + pp;
+    };
+    const int main_blocks = prep_main_blocks(d.rows, d.ld);
+    if (lb < main_blocks) {
+        for (int64_t i = base + threadIdx.x; i < base + PREP_ELEMS && i < n_main; i += 256) {
             const int r = (int)(i / d.ld), k = (int)(i % d.ld);
-            float v = 0.f;
-            if (k < cols_out) {
-                int sk = k;
-                if (d.mode == LNX_PREP_CONV_PERM) {  // k = p*C + c  <-  src column c*P + p
-                    const int Cc = d.cols / d.P;
-                    const int pp = k / Cc;
-                    sk = (k - pp * Cc) * d.P + pp;
-                }
-                v = d.src[(int64_t)r * d.cols + sk];
-            }
+            const float v = k < cols_out ? d.src[(int64_t)r * d.cols + src_col(k)] : 0.f;
             reinterpret_cast<T*>(d.dst)[i] = from_f<T>(v);
-        } else if (d.dst_t != nullptr) {
-            // transposed copy: only the [cols_out, rows] block is written (several tensors may share
-            // one row-padded destination, so padding columns are left as the caller zeroed them)
-            const int64_t j = i - n_main;
-            if (j < (int64_t)cols_out * d.rows) {
-                const int k = (int)(j / d.rows), r = (int)(j % d.rows);
-                int sk = k;
-                if (d.mode == LNX_PREP_CONV_PERM) {
-                    const int Cc = d.cols / d.P;
-                    const int pp = k / Cc;
-                    sk = (k - pp * Cc) * d.P + pp;
-                }
-                reinterpret_cast<T*>(d.dst_t)[(int64_t)k * d.ld_t + r] = from_f<T>(d.src[(int64_t)r * d.cols + sk]);
-            }
         }
+        return;
+    }
+    if (d.dst_t == nullptr) return;
+    // Transposed copy through an LDS tile: rows of the source are read along k (coalesced), rows of the destination
+    // written along r (coalesced).  Only the [cols_out, rows] block is written (several tensors may share one
+    // row-padded destination, so padding columns are left as the caller zeroed them).
+    const int tiles_k = (cols_out + PREP_TK - 1) / PREP_TK;
+    const int tt = lb - main_blocks;
+    const int r0 = (tt / tiles_k) * PREP_TR, k0 = (tt % tiles_k) * PREP_TK;
+    for (int e = threadIdx.x; e < PREP_TR * PREP_TK; e += 256) {
+        const int rr = e / PREP_TK, kk = e % PREP_TK;
+        const int r = r0 + rr, k = k0 + kk;
+        tile[kk][rr] = (r < d.rows && k < cols_out) ? d.src[(int64_t)r * d.cols + src_col(k)] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < PREP_TR * PREP_TK; e += 256) {
+        const int kk = e / PREP_TR, rr = e % PREP_TR;
+        const int r = r0 + rr, k = k0 + kk;
+        if (r < d.rows && k < cols_out) reinterpret_cast<T*>(d.dst_t)[(int64_t)k * d.ld_t + r] = from_f<T>(tile[kk][rr]);
     }
 }
 
@@ -329,9 +337,9 @@ extern "C" int lnx_pack_meta(const float* meta, int width, int off, int dim, voi
 
 extern "C" int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t) {
     (void)ld_t;
-    int64_t n = (int64_t)rows * ld;
-    if (has_t) n += (int64_t)cols * rows;
-    return (int)((n + PREP_ELEMS - 1) / PREP_ELEMS);
+    int n = prep_main_blocks(rows, ld);
+    if (has_t) n += ((rows + PREP_TR - 1) / PREP_TR) * ((cols + PREP_TK - 1) / PREP_TK);
+    return n;
 }
 
 extern "C" int lnx_prep_weights(const lnx_prep_desc* descs_dev, int ndesc, int total_blocks, int dtype, void* stream) {
