@@ -145,6 +145,8 @@ def main():
         model.grad_mode = "direct"
     opt = None if args.no_optim else torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
 
+    from linnaeus_amd.loss import multitask_cross_entropy
+
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(42 + rank)
     x = torch.rand(B, 3, args.img, args.img, device=dev, generator=g)
@@ -154,9 +156,7 @@ def main():
     def step():
         model.zero_grad(set_to_none=True)
         out = net(x, meta)
-        loss = out[TASKS[0][0]].new_zeros(())
-        for t, _ in TASKS:
-            loss = loss + F.cross_entropy(out[t], tg[t])
+        loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE, one HIP launch per task
         loss.backward()
         if opt is not None:
             opt.step()
@@ -199,7 +199,7 @@ def main():
         for _ in range(args.profile_steps):
             model.zero_grad(set_to_none=True)
             out = model(x, meta)
-            sum(F.cross_entropy(out[t], tg[t]) for t, _ in TASKS).backward()
+            multitask_cross_entropy(out, tg).backward()
         model._segment_hook = hook
         ms = (C.c_double * NC)()
         work = (C.c_double * NC)()

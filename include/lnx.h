@@ -280,6 +280,32 @@ int lnx_prep_blocks(int rows, int ld, int cols, int ld_t, int has_t);
 
 
 /* ------------------------------------------------------------------------------------
+ * Soft-label cross entropy, forward and logits gradient in one launch ("loss on device").
+ * Replaces TaxonomyAwareLabelSmoothingCE.forward (loss/taxonomy_label_smoothing.py:233-405):
+ *   loss[b] = class_weight[t_b] * -sum_c soft[t_b, c] * log_softmax(logits[b])[c],  0 where t_b == ignore_index
+ * and, with soft == NULL, torch.nn.functional.cross_entropy(..., label_smoothing = smoothing) per sample.
+ *   dlogits[b, c] = scale * row_scale[b] * class_weight[t_b] * (softmax(logits[b])[c] * sum_c soft[t_b, c] - soft[t_b, c])
+ *   loss_sum     += scale * sum_b row_scale[b] * loss[b]                (atomic; caller zeroes it)
+ * -----------------------------------------------------------------------------------*/
+typedef struct lnx_softce_args {
+    int B, C;
+    const float* logits;       /* [B, ld] fp32 */
+    int64_t ld;
+    const int64_t* target;     /* [B] class indices */
+    const float* soft;         /* [C, C] soft-label matrix (rows sum to 1) or NULL = one-hot */
+    float smoothing;           /* soft == NULL only: uniform label smoothing epsilon */
+    const float* class_weight; /* [C] or NULL */
+    int64_t ignore_index;      /* < 0: none */
+    const float* row_scale;    /* [B] or NULL: per-sample multiplier of the gradient / of loss_sum */
+    float scale;               /* global multiplier (e.g. task_weight / B) */
+    float* loss;               /* [B] per-sample losses or NULL */
+    float* loss_sum;           /* scalar accumulator or NULL */
+    float* dlogits;            /* [B, ldd] or NULL */
+    int64_t ldd;
+} lnx_softce_args;
+int lnx_softce(const lnx_softce_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused ConvNeXt MLP branch (bf16 storage, C in {32,64,96,128,192}):
  *   out = x + rowscale * gamma * (GELU(ln . W1^T + b1) . W2^T + b2)
  * = pwconv1 -> GELU -> pwconv2 -> LayerScale -> DropPath -> residual (blocks/convnext.py:79-86)

@@ -58,6 +58,20 @@ class WgradArgs(C.Structure):
     ]
 
 
+class SoftCEArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("C", C.c_int),
+        ("logits", C.c_void_p), ("ld", C.c_int64),
+        ("target", C.c_void_p),
+        ("soft", C.c_void_p), ("smoothing", C.c_float),
+        ("class_weight", C.c_void_p),
+        ("ignore_index", C.c_int64),
+        ("row_scale", C.c_void_p), ("scale", C.c_float),
+        ("loss", C.c_void_p), ("loss_sum", C.c_void_p),
+        ("dlogits", C.c_void_p), ("ldd", C.c_int64),
+    ]
+
+
 _lib = None
 
 
@@ -91,7 +105,7 @@ EXPORTS = [
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
-    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",

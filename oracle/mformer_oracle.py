@@ -487,3 +487,20 @@ def probe_loss(out: Dict[str, Tensor], feats_like: Optional[Tensor] = None) -> T
         v = (lg.float() * ramp).mean()
         tot = v if tot is None else tot + v
     return tot
+
+
+# --------------------------------------------------------------------------------------
+# loss
+# --------------------------------------------------------------------------------------
+def soft_label_ce(logits: Tensor, target: Tensor, soft: Tensor, class_weight: Optional[Tensor] = None,
+                  ignore_index: Optional[int] = None) -> Tensor:
+    """Per-sample soft-label cross entropy, TaxonomyAwareLabelSmoothingCE.forward
+    (loss/taxonomy_label_smoothing.py:356-401): -sum_c soft[t, c] * log_softmax(logits)[c], zero where
+    t == ignore_index, then * class_weight[t]."""
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    loss = -(soft[target] * logp).sum(1)
+    if ignore_index is not None:
+        loss = loss.masked_fill(target == ignore_index, 0.0)
+    if class_weight is not None:
+        loss = loss * class_weight[target]
+    return loss

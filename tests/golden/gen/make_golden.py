@@ -19,6 +19,7 @@ Cases:
   tiny_dp  tiny_a in train mode with DROP_PATH_RATE=0.5 and recorded per-call masks
   sm       the real mFormerV1_sm config at 224, B=2, 4 Linear heads (1000/300/80/20)
 plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate) and
+  soft_ce     the reference's TaxonomyAwareLabelSmoothingCE (per-sample losses + logits gradient)
   train_step  two optimizer steps of tiny_a (CE loss, clip_grad_norm_, AdamW): losses, grad norms, deltas.
 """
 import os
@@ -265,6 +266,34 @@ def run_train_step(name, spec, img, batch, steps=2):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
 
 
+def soft_ce_known_answers():
+    """TaxonomyAwareLabelSmoothingCE of the reference (loss/taxonomy_label_smoothing.py) on seeded inputs: per-sample
+    losses and the gradient of a weighted sum of them, with and without ignore_index / class weights."""
+    from linnaeus.loss.taxonomy_label_smoothing import TaxonomyAwareLabelSmoothingCE
+
+    g = torch.Generator().manual_seed(SEED + 7)
+    B, Cn = 24, 37
+    logits = (torch.randn(B, Cn, generator=g) * 3).requires_grad_(True)
+    target = torch.randint(0, Cn, (B,), generator=g)
+    target[:5] = 0  # null class rows
+    soft = torch.rand(Cn, Cn, generator=g) * 0.1
+    soft[torch.arange(Cn), torch.arange(Cn)] += 5.0
+    soft = soft / soft.sum(1, keepdim=True)
+    cw = torch.rand(Cn, generator=g) + 0.5
+    wsum = torch.rand(B, generator=g)
+    rec = {"logits": logits.detach().numpy(), "target": target.numpy(), "soft": soft.numpy(), "class_weight": cw.numpy(), "wsum": wsum.numpy()}
+    for name, kw in (("plain", {}), ("ignore0", {"ignore_index": 0}), ("ignore0_cw", {"ignore_index": 0, "weight": cw, "apply_class_weights": True}),
+                     ("cw", {"weight": cw, "apply_class_weights": True})):
+        crit = TaxonomyAwareLabelSmoothingCE(soft, **kw)
+        logits.grad = None
+        loss = crit(logits, target)
+        (loss * wsum).sum().backward()
+        rec[f"loss_{name}"] = loss.detach().numpy()
+        rec[f"grad_{name}"] = logits.grad.numpy().copy()
+        print(f"[soft_ce/{name}] mean loss {loss.mean().item():.5f}")
+    np.savez_compressed(os.path.join(OUT, "soft_ce.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -354,6 +383,8 @@ def main():
         run_case("sm", sm, 224, 2)
     if want("per_op"):
         per_op_known_answers()
+    if want("soft_ce"):
+        soft_ce_known_answers()
     if want("train_step"):
         run_train_step("train_step", tiny_a, 64, 4)
 
