@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
+    ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW(fused=True) instead of linnaeus_amd.optim.FusedAdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -143,7 +144,14 @@ def main():
         net = DataParallel(model)
     else:
         model.grad_mode = "direct"
-    opt = None if args.no_optim else torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    if args.no_optim:
+        opt = None
+    elif args.torch_optim:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    else:
+        from linnaeus_amd.optim import FusedAdamW
+
+        opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05)  # one multi-tensor HIP launch per step
 
     from linnaeus_amd.loss import multitask_cross_entropy
 
@@ -246,7 +254,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"mFormerV1_{args.arch} train step (forward + 4-task CE loss + backward"
-                               f"{' + RCCL gradient all-reduce' if world > 1 else ''}{'' if args.no_optim else ' + fused AdamW'}), "
+                               f"{' + RCCL gradient all-reduce' if world > 1 else ''}{'' if args.no_optim else ' + AdamW (' + ('torch fused' if args.torch_optim else 'one HIP launch') + ')'}), "
                                f"{args.dtype} operands / fp32 accumulate+residual, batch {B}/GPU, 3x{args.img}x{args.img} synthetic, "
                                "DropPath 0.2, gradient checkpointing off",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "tasks": dict(TASKS)},

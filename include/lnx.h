@@ -306,6 +306,37 @@ typedef struct lnx_softce_args {
 int lnx_softce(const lnx_softce_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Optimizer + step glue: multi-tensor AdamW with the global-norm clip folded in.
+ * Replaces torch.optim.AdamW.step as configured by linnaeus/optimizers/build.py:307-686 (per-group lr / weight
+ * decay) and the gradient-norm passes of train.py:282-308 (clip_grad_norm_ semantics:
+ * coef = min(1, max_norm / (||g||_2 + 1e-6))).  `descs` is a DEVICE array, one entry per parameter tensor.
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/bias_c1 * m / (sqrt(v)/sqrt(bias_c2) + eps)
+ * -----------------------------------------------------------------------------------*/
+#define LNX_ADAMW_MAX_GROUPS 16
+typedef struct lnx_adamw_desc {
+    float* p;         /* parameter (fp32 master) */
+    float* m;         /* exp_avg */
+    float* v;         /* exp_avg_sq */
+    const float* g;   /* gradient */
+    int64_t n;        /* elements */
+    int group;        /* index into lnx_adamw_hyper */
+    int block_start;  /* first workgroup of this tensor: exclusive prefix sum of lnx_adamw_blocks(n) */
+} lnx_adamw_desc;
+typedef struct lnx_adamw_hyper {
+    int ngroups;
+    float lr[LNX_ADAMW_MAX_GROUPS], beta1[LNX_ADAMW_MAX_GROUPS], beta2[LNX_ADAMW_MAX_GROUPS], eps[LNX_ADAMW_MAX_GROUPS],
+        weight_decay[LNX_ADAMW_MAX_GROUPS];
+    float bias_c1[LNX_ADAMW_MAX_GROUPS], bias_c2[LNX_ADAMW_MAX_GROUPS]; /* 1 - beta^step of the step being taken */
+    float omb1[LNX_ADAMW_MAX_GROUPS], omb2[LNX_ADAMW_MAX_GROUPS];       /* 1 - beta, rounded from double (1 - 0.999f loses 1e-5) */
+} lnx_adamw_hyper;
+int lnx_adamw_blocks(int64_t numel);
+/* out[0] = sum over all tensors of g^2 (zeroed by the call) */
+int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, void* stream);
+/* sumsq == NULL or max_norm <= 0: no clipping */
+int lnx_adamw_step(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, const lnx_adamw_hyper* hyper, const float* sumsq, float max_norm,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused ConvNeXt MLP branch (bf16 storage, C in {32,64,96,128,192}):
  *   out = x + rowscale * gamma * (GELU(ln . W1^T + b1) . W2^T + b2)
  * = pwconv1 -> GELU -> pwconv2 -> LayerScale -> DropPath -> residual (blocks/convnext.py:79-86)

@@ -72,6 +72,17 @@ class SoftCEArgs(C.Structure):
     ]
 
 
+ADAMW_MAX_GROUPS = 16
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("g", C.c_void_p), ("n", C.c_int64), ("group", C.c_int), ("block_start", C.c_int)]
+
+
+class AdamWHyper(C.Structure):
+    _fields_ = [("ngroups", C.c_int)] + [(k, C.c_float * ADAMW_MAX_GROUPS) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bias_c1", "bias_c2", "omb1", "omb2")]
+
+
 _lib = None
 
 
@@ -105,7 +116,7 @@ EXPORTS = [
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
-    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",

@@ -1,0 +1,96 @@
+// Multi-tensor AdamW with a fused global-norm clip for gfx950 ("optimizer + step glue").
+// Replaces, for the model's parameters: torch.optim.AdamW.step (decoupled weight decay, bias correction) as built
+// by linnaeus/optimizers/build.py, and the gradient-norm / clip passes of train.py:282-308
+// (clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)), gradients scaled by coef).
+// Two launches per step over a device descriptor table (one entry per parameter tensor): sum of squares of all
+// gradients, then the update, which reads the clip coefficient from that scalar.
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+constexpr int OPT_ELEMS = 4096;  // elements per workgroup
+
+__device__ __forceinline__ const lnx_adamw_desc& find_desc(const lnx_adamw_desc* __restrict__ descs, int ndesc, int block) {
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= block) lo = mid;
+        else hi = mid - 1;
+    }
+    return descs[lo];
+}
+
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const lnx_adamw_desc* __restrict__ descs, int ndesc, float* __restrict__ out) {
+    __shared__ float red[4];
+    const lnx_adamw_desc& d = find_desc(descs, ndesc, blockIdx.x);
+    const int64_t base = (int64_t)(blockIdx.x - d.block_start) * OPT_ELEMS;
+    const int64_t end = min(d.n, base + OPT_ELEMS);
+    float s = 0.f;
+    if ((reinterpret_cast<uintptr_t>(d.g) & 15) == 0) {
+        for (int64_t i = base + 4 * threadIdx.x; i + 3 < end; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(d.g + i);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        const int64_t tail = base + ((end - base) & ~(int64_t)3);
+        if (tail + threadIdx.x < end) {
+            const float v = d.g[tail + threadIdx.x];
+            s += v * v;
+        }
+    } else {
+        for (int64_t i = base + threadIdx.x; i < end; i += 256) s += d.g[i] * d.g[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const lnx_adamw_desc* __restrict__ descs, int ndesc, const lnx_adamw_hyper h, const float* __restrict__ sumsq,
+                                                    float max_norm) {
+    const lnx_adamw_desc& d = find_desc(descs, ndesc, blockIdx.x);
+    const int gi = d.group;
+    const float lr = h.lr[gi], b1 = h.beta1[gi], b2 = h.beta2[gi], eps = h.eps[gi], wd = h.weight_decay[gi];
+    const float omb1 = h.omb1[gi], omb2 = h.omb2[gi];
+    const float step_size = lr / h.bias_c1[gi], inv_sqrt_bc2 = 1.0f / sqrtf(h.bias_c2[gi]);
+    float coef = 1.0f;
+    if (sumsq != nullptr && max_norm > 0.f) coef = fminf(1.0f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    const int64_t base = (int64_t)(blockIdx.x - d.block_start) * OPT_ELEMS;
+    const int64_t end = min(d.n, base + OPT_ELEMS);
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+        const float g = d.g[i] * coef;
+        float p = d.p[i], m = d.m[i], v = d.v[i];
+        p *= 1.0f - lr * wd;
+        m = fmaf(b1, m, omb1 * g);
+        v = fmaf(b2, v, omb2 * g * g);
+        const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+        p -= step_size * (m / denom);
+        d.p[i] = p;
+        d.m[i] = m;
+        d.v[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int lnx_adamw_blocks(int64_t numel) { return (int)((numel + OPT_ELEMS - 1) / OPT_ELEMS); }
+
+extern "C" int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, void* stream) {
+    LNX_CHECK(descs_dev && ndesc > 0 && total_blocks > 0 && out, "lnx_grad_sumsq: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    LNX_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(total_blocks), dim3(256), 0, st, descs_dev, ndesc, out);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_adamw_step(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, const lnx_adamw_hyper* hyper, const float* sumsq, float max_norm,
+                              void* stream) {
+    LNX_CHECK(descs_dev && ndesc > 0 && total_blocks > 0 && hyper, "lnx_adamw_step: bad arguments");
+    LNX_CHECK(hyper->ngroups > 0 && hyper->ngroups <= LNX_ADAMW_MAX_GROUPS, "lnx_adamw_step: ngroups=%d (max %d)", hyper->ngroups, LNX_ADAMW_MAX_GROUPS);
+    for (int i = 0; i < hyper->ngroups; ++i)
+        LNX_CHECK(hyper->bias_c1[i] > 0.f && hyper->bias_c2[i] > 0.f, "lnx_adamw_step: bias corrections of group %d must be positive (step >= 1)", i);
+    hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, ndesc, *hyper, sumsq, max_norm);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,71 @@
+"""Optimizer + step glue on device: FusedAdamW (two HIP launches: gradient sum of squares, multi-tensor
+AdamW with the clip folded in) against clip_grad_norm_ + torch.optim.AdamW, and on the reference's train-step fixture."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("clip", [None, 0.5, 1e6])
+def test_fused_adamw_matches_torch(clip):
+    from linnaeus_amd.optim import FusedAdamW
+
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1000, 37), (5,), (4096,), (3, 3, 7, 7), (1,), (12289,)]
+    pa = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    groups = lambda ps: [{"params": ps[:3], "lr": 3e-3, "weight_decay": 0.05}, {"params": ps[3:], "lr": 1e-2, "weight_decay": 0.0, "betas": (0.8, 0.95)}]
+    oa = FusedAdamW(groups(pa), lr=1e-3, max_grad_norm=clip)
+    ob = torch.optim.AdamW(groups(pb), lr=1e-3)
+    for step in range(4):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (0.1 + step)
+            a.grad = gr.clone()
+            b.grad = gr.clone()
+        if step == 2:  # a scheduler changing the learning rate between steps
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 1e-3
+        ref_norm = torch.nn.utils.clip_grad_norm_(pb, clip) if clip is not None else None
+        oa.step()
+        ob.step()
+        if clip is not None:
+            torch.testing.assert_close(oa.grad_norm(), ref_norm, rtol=1e-5, atol=1e-6)
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["step"] == 4
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def test_fused_step_on_reference_train_fixture(golden_dir):
+    """the reference's CE -> clip_grad_norm_(1.0) -> AdamW steps (tests/golden/train_step.npz) with the HIP model, the HIP
+    loss and the HIP optimizer: every piece of the step on device"""
+    from linnaeus_amd.loss import multitask_cross_entropy
+    from linnaeus_amd.optim import FusedAdamW
+    from tests.cases import load_train_step
+    from tests.test_gpu_model import build
+
+    spec, z, sd, x, meta, targets, weights = load_train_step(golden_dir)
+    model = build("tiny_a", spec, sd, "fp32")
+    model.train()
+    model.grad_mode = "direct"
+    xg, mg = x.cuda(), meta.cuda()
+    tg = {t: v.cuda() for t, v in targets.items()}
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = FusedAdamW(model.parameters(), lr=float(z["lr"]), weight_decay=float(z["wd"]), max_grad_norm=float(z["clip"]))
+    for s in range(int(z["steps"])):
+        model.zero_grad(set_to_none=True)
+        loss = multitask_cross_entropy(model(xg, mg), tg, weights)
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - float(z[f"loss_{s}"])) <= 2e-4 * abs(float(z[f"loss_{s}"]))
+        assert abs(opt.grad_norm().item() - float(z[f"gnorm_{s}"])) <= 2e-3 * float(z[f"gnorm_{s}"])
+    names = [str(n) for n in z["param_names"]]
+    got = dict(model.named_parameters())
+    for i, k in enumerate(names):
+        if k == "aggregate.bias":
+            continue  # exactly-zero gradient in real arithmetic (see test_gpu_model.test_train_step_matches_reference)
+        d = (got[k].detach() - before[k]).double().norm().item()
+        floor = 0.05 * float(z["lr"]) * int(z["steps"]) * got[k].numel() ** 0.5
+        assert abs(d - z["delta_norms"][i]) <= 5e-2 * z["delta_norms"][i] + floor, (k, d, z["delta_norms"][i])
