@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
+    ap.add_argument("--force-dp", action="store_true", help="single GPU rehearsal of the data-parallel path: RCCL world size 1, collectives issued")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW(fused=True) instead of linnaeus_amd.optim.FusedAdamW")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -127,10 +128,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(42 + rank)
     cfg, model = make_model(args)
@@ -138,10 +144,10 @@ def main():
     model.set_compute_dtype(args.dtype)
     model.train()
     net = model
-    if world > 1:
+    if world > 1 or args.force_dp:
         from linnaeus_amd.ddp import DataParallel
 
-        net = DataParallel(model)
+        net = DataParallel(model, single_rank_collectives=args.force_dp)
     else:
         model.grad_mode = "direct"
     if args.no_optim:

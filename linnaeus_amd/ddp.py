@@ -30,8 +30,10 @@ import torch.distributed as dist
 class GradBucketReducer:
     """Average contiguous slices ("buckets") of one flat gradient tensor across ranks."""
 
-    def __init__(self, arena: torch.Tensor, bounds: Dict[int, Tuple[int, int]], process_group=None, compress_bf16: bool = False):
+    def __init__(self, arena: torch.Tensor, bounds: Dict[int, Tuple[int, int]], process_group=None, compress_bf16: bool = False,
+                 single_rank_collectives: bool = False):
         self.arena = arena
+        self.force = single_rank_collectives  # issue the collectives even with one rank (exercises the stream logic on one GPU)
         self.bounds = dict(bounds)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -46,7 +48,7 @@ class GradBucketReducer:
     def reduce_bucket(self, key: int) -> None:
         """Issue the all-reduce of one bucket.  On GPU it is enqueued on the side stream behind an
         event recorded on the current (compute) stream."""
-        if self.world == 1 or key not in self.bounds:
+        if (self.world == 1 and not self.force) or key not in self.bounds:
             return
         lo, hi = self.bounds[key]
         if hi <= lo:
@@ -76,7 +78,7 @@ class GradBucketReducer:
 
     def finish(self) -> None:
         """Make the compute stream wait for every issued collective (no host sync)."""
-        if self.cuda and self.world > 1:
+        if self.cuda and (self.world > 1 or self.force):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
 
@@ -96,9 +98,11 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, process_group=
 class DataParallel(torch.nn.Module):
     """Wrap a linnaeus_amd mFormerV1 for one-process-per-GPU data parallelism."""
 
-    def __init__(self, module: torch.nn.Module, process_group=None, compress_bf16: bool = False, broadcast: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, compress_bf16: bool = False, broadcast: bool = True,
+                 single_rank_collectives: bool = False):
         super().__init__()
         self.module = module
+        self.force = single_rank_collectives  # test hook: run the collectives with one rank too
         self.pg = process_group
         self.compress = compress_bf16
         self._reducer: Optional[GradBucketReducer] = None
@@ -113,7 +117,7 @@ class DataParallel(torch.nn.Module):
             return
         m = self.module
         if self._reducer is None or self._reducer.arena.data_ptr() != m._grad_arena.data_ptr():
-            self._reducer = GradBucketReducer(m._grad_arena, m._segment_bounds, self.pg, self.compress)
+            self._reducer = GradBucketReducer(m._grad_arena, m._segment_bounds, self.pg, self.compress, single_rank_collectives=self.force)
         self._reducer.reduce_bucket(seg)
         if seg == 3:
             self._reducer.finish()

@@ -228,3 +228,43 @@ def test_large_384_matches_oracle():
         glob = (tot_err / tot_ref) ** 0.5
         print(f"[lg@384/{dtype}] global relative gradient error vs oracle: {glob:.2e}")
         assert glob <= gtol, (dtype, glob)
+
+
+def test_data_parallel_stream_logic_single_rank(golden_dir):
+    """DataParallel on one GPU with the collectives forced on (RCCL, world size 1): the per-segment all-reduces on the
+    side stream, their events and the final join must leave exactly the gradients of the plain model, for the plain
+    and the bf16-compressed buckets, and with no_sync() accumulation."""
+    import os
+    import torch.distributed as dist
+    from linnaeus_amd.ddp import DataParallel
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        spec, z, sd, x, meta, drops = load_case("tiny_b", golden_dir)
+        ref = build("tiny_b", spec, sd, "fp32")
+        ref.train()
+        O.probe_loss(run(ref, x, meta, None, train=True)).backward()
+        want = {k: p_.grad.clone() for k, p_ in ref.named_parameters()}
+        for compress in (False, True):
+            model = build("tiny_b", spec, sd, "fp32")
+            model.train()
+            dp = DataParallel(model, compress_bf16=compress, single_rank_collectives=True)
+            for rep in range(2):  # second pass: gradients re-zeroed, same answer
+                model.zero_grad(set_to_none=True)
+                O.probe_loss(dp(x.cuda(), meta.cuda())).backward()
+                torch.cuda.synchronize()
+                for k, p_ in model.named_parameters():
+                    tol = dict(rtol=1e-5, atol=1e-7) if not compress else dict(rtol=2e-2, atol=1e-4)
+                    torch.testing.assert_close(p_.grad, want[k], msg=f"{k} (compress={compress}, pass {rep})", **tol)
+            model.zero_grad(set_to_none=True)
+            with dp.no_sync():
+                O.probe_loss(dp(x.cuda(), meta.cuda())).backward()
+            O.probe_loss(dp(x.cuda(), meta.cuda())).backward()
+            torch.cuda.synchronize()
+            if not compress:
+                for k, p_ in model.named_parameters():
+                    torch.testing.assert_close(p_.grad, 2 * want[k], rtol=1e-5, atol=1e-7, msg=f"{k} (accumulated)")
+    finally:
+        dist.destroy_process_group()
