@@ -162,6 +162,147 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmP p) {
     else gemm_epilogue_fast<T, OUT_F32, F>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// ------------------------------------------------------------------------------------
+// gemm_nt v4: 256x256 output tile for problems whose N is a multiple of 256.  The K loop of the 256x128 kernel is
+// bound by the LDS-DMA fill rate (measured ~32 B/clk/CU; it needs 47 B/clk to keep the MFMA pipe full): a 256x256
+// tile moves 1.5x fewer operand bytes per FLOP, 32 B/clk at full MFMA rate.  Eight waves, each a 128x64 wave tile
+// (two 4x4 accumulator sets, 128 registers); K in 32-element slices (64-byte LDS rows: 512 rows = 32 KiB per stage)
+// through a 4-deep ring with three slices in flight; same ping-pong wave groups and specialised epilogues.
+// 64-byte rows keep global chunk c at slot c ^ key, key = 3 * bit4(row): with it the permuted fragment rows
+// {0..3,16..19,32..35,48..51}+4i of every 16-lane group of a ds_read_b128 fall on 16 distinct 16-byte bank slots.
+// ------------------------------------------------------------------------------------
+#define DS4_READ4(dst, addr)                                                                            \
+    do {                                                                                                \
+        const uint32_t a_ = (addr);                                                                     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(a_) : "memory");                        \
+        asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(dst[1]) : "v"(a_) : "memory");             \
+        asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(dst[2]) : "v"(a_) : "memory");             \
+        asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(dst[3]) : "v"(a_) : "memory");             \
+    } while (0)
+
+constexpr int BM4 = 256, BN4 = 256, BK4 = 32, ROWB4 = 64;
+constexpr int STAGE4 = (BM4 + BN4) * ROWB4;   // 32 KiB
+constexpr int NST4 = 4;
+constexpr int PIECES4 = STAGE4 / 1024 / 8;    // 1-KiB LDS-DMA instructions per wave per stage = 4
+
+__device__ __forceinline__ int key4r(int row) { return (row & 16) ? 3 : 0; }
+
+template <bool OUT_F32, int F>
+__global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const GemmP p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST4][A 256 rows | W 256 rows][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;  // waves 0-3 / 4-7 (the ping-pong groups) cover the column halves
+    const int s = lane & 15, g = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tn = logical % p.tiles_n;
+    const int tm = logical / p.tiles_n;
+    const int m0 = tm * BM4, n0 = tn * BN4;
+
+    // piece i (32 per stage) fills LDS rows 16 i .. 16 i + 15 (rows 0..255 = A, 256..511 = W); wave w issues i = w + 8 j
+    const unsigned char* src[PIECES4];
+#pragma unroll
+    for (int j = 0; j < PIECES4; ++j) {
+        const int i = wave + 8 * j;
+        const int row = 16 * i + (lane >> 2);
+        const int slot = lane & 3;
+        if (row < BM4) {
+            const int chunk = slot ^ key4r(row);
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            src[j] = p.A + ((int64_t)m * p.lda + chunk * 8) * 2;
+        } else {
+            const int wr = row - BM4;
+            const int chunk = slot ^ key4r(wr);
+            int n = n0 + wr;
+            if (n >= p.N) n = p.N - 1;
+            src[j] = p.W + ((int64_t)n * p.ldw + chunk * 8) * 2;
+        }
+    }
+    auto issue_stage = [&](int kt, int stage) {
+#pragma unroll
+        for (int j = 0; j < PIECES4; ++j) {
+            const int i = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (int64_t)kt * BK4 * 2),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE4 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    const int frag_row = (s >> 2) * 16 + (s & 3);
+    const uint32_t chunk_off = (uint32_t)((g ^ (((s >> 2) & 1) * 3)) << 4);  // key of every row this lane reads = 3 * bit0(s >> 2)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t a_off = (uint32_t)((wm * 128 + frag_row) * ROWB4) + chunk_off;
+    const uint32_t w_off = (uint32_t)((BM4 + wn * 64 + frag_row) * ROWB4) + chunk_off;
+
+    f32x4_t acc0[4][4], acc1[4][4];  // rows 0..63 / 64..127 of the wave tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+
+    const int nk = p.K / BK4;  // >= 4
+    issue_stage(0, 0);
+    issue_stage(1, 1);
+    issue_stage(2, 2);
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // own pieces of slice 0 have landed (two slices = 8 pieces still in flight)
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t st = lds_base + (kt % NST4) * STAGE4;
+        uint4 wf[4], af0[4], af1[4];
+        DS4_READ4(wf, st + w_off);
+        DS4_READ4(af0, st + a_off);
+        DS4_READ4(af1, st + a_off + 64 * ROWB4);
+        // end of memory phase kt: own pieces of slice kt+1 landed, fragment reads of slice kt done; the slot refilled
+        // in memory phase kt+1 (slice kt+4) is the one read in phase kt
+        if (kt + 3 < nk) {
+            issue_stage(kt + 3, (kt + 3) % NST4);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (kt + 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc0[ni][mi], wf[ni], af0[mi]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp && kt + 1 == nk)) __builtin_amdgcn_s_barrier();
+    }
+    if (F == F_GENERIC) {
+        gemm_epilogue<T, OUT_F32>(p, acc0, m0 + wm * 128, n0 + wn * 64, lane);
+        gemm_epilogue<T, OUT_F32>(p, acc1, m0 + wm * 128 + 64, n0 + wn * 64, lane);
+    } else {
+        gemm_epilogue_fast<T, OUT_F32, F>(p, acc0, m0 + wm * 128, n0 + wn * 64, lane);
+        gemm_epilogue_fast<T, OUT_F32, F>(p, acc1, m0 + wm * 128 + 64, n0 + wn * 64, lane);
+    }
+}
+
+static bool nt_v4_ok(const GemmP& p, int f) {
+    static const bool off = getenv("LNX_NT_V4") && atoi(getenv("LNX_NT_V4")) == 0;  // A/B switch for benchmarking
+    if (off || f == (int)F_GENERIC || p.a_mode == LNX_ADDR_PATCH2) return false;
+    return p.N % BN4 == 0 && p.K % BK4 == 0 && p.K >= 4 * BK4;
+}
+
 bool nt_v2_ok(const GemmP& p, int dtype) {
     if (dtype != LNX_BF16) return false;
     if (p.K % 64 != 0 || p.K < 128) return false;
@@ -179,6 +320,28 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     const bool patch = p.a_mode == LNX_ADDR_PATCH2;
     static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
     const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+    if (nt_v4_ok(p, f)) {
+        p.tiles_m = cdiv(p.M, BM4);
+        p.tiles_n = p.N / BN4;
+        const int grid4 = p.tiles_m * p.tiles_n;
+        const size_t lds4 = NST4 * STAGE4;
+#define V4_LAUNCH(O, FF)                                                                                                             \
+    do {                                                                                                                             \
+        static bool attr = false;                                                                                                    \
+        if (!attr) {                                                                                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v4_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4); \
+            attr = true;                                                                                                             \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((gemm_nt_v4_kernel<O, FF>), dim3(grid4), dim3(512), lds4, st, p);                                         \
+    } while (0)
+        if (out_f32) V4_LAUNCH(true, F_BIAS | F_RES);
+        else if (f == 0) V4_LAUNCH(false, 0);
+        else if (f == F_BIAS) V4_LAUNCH(false, F_BIAS);
+        else if (f == (F_BIAS | F_C2 | F_GELU)) V4_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
+        else V4_LAUNCH(false, F_GELU_BWD);
+#undef V4_LAUNCH
+        return 0;
+    }
 #define V2_LAUNCH(O, P, FF)                                                                                                          \
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \

@@ -244,11 +244,13 @@ def test_tn_padded_logits_rows(M, dtype):
     torch.testing.assert_close(db.double(), dY.double().sum(0), rtol=1e-4, atol=2e-5 * M**0.5)
 
 
-@pytest.mark.parametrize("kind", ["plain", "gelu_c2", "gelu_bwd", "res_f32"])
-def test_nt_specialised_epilogues(kind):
+@pytest.mark.parametrize("N", [128, 256])
+@pytest.mark.parametrize("kind", ["plain", "gelu_c2", "gelu_bwd", "res_f32", "bias_bf16"])
+def test_nt_specialised_epilogues(kind, N):
     """Large aligned problems take the pipelined kernel with an epilogue compiled for its feature set (gemm2.hip,
-    gemm_epilogue_fast): check every form the plan launches, on a grid of 523 tiles (more than two per CU)."""
-    M, N, K = 256 * 523, 128, 192
+    gemm_epilogue_fast): check every form the plan launches, on a grid of 523 tiles (more than two per CU); N = 256
+    takes the 256x256-tile kernel, N = 128 the 256x128 one."""
+    M, K = 256 * 523, 192
     g = torch.Generator().manual_seed(11)
     A = (torch.randn(M, K, generator=g)).cuda().bfloat16()
     W = (torch.randn(N, K, generator=g) / K**0.5).cuda().bfloat16()
@@ -257,6 +259,11 @@ def test_nt_specialised_epilogues(kind):
     if kind == "plain":
         out, _ = run_nt(A, W, L.BF16, True, bias=b)
         torch.testing.assert_close(out.double(), z, rtol=2e-5, atol=1e-4)
+    elif kind == "bias_bf16":
+        out, _ = run_nt(A, W, L.BF16, False, bias=b)
+        torch.testing.assert_close(out.float(), z.float(), rtol=8e-3, atol=8e-3)
+        out, _ = run_nt(A, W, L.BF16, False)
+        torch.testing.assert_close(out.float(), (z - b.double()).float(), rtol=8e-3, atol=8e-3)
     elif kind == "gelu_c2":
         out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU, want_c2=True)
         torch.testing.assert_close(c2.float(), z.float(), rtol=8e-3, atol=8e-3)
