@@ -236,10 +236,7 @@ __global__ __launch_bounds__(256) void convmlp_fwd_kernel(const CmP p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        h[nt][mt][r] = gelu_lean(h[nt][mt][r] + bv[nt][r]);
-                    }
+                    gelu4_bias(h[nt][mt], bv[nt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 pf[mt][0] = pack8(h[0][mt], h[1][mt]);
@@ -392,13 +389,7 @@ __global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float act, dg;
-                    gelu_lean_grad(h[nt][mt][r] + bv[nt][r], act, dg);
-                    h[nt][mt][r] = act;        // act = GELU(h)
-                    da[nt][mt][r] *= dg;       // dH = dA * GELU'(h)
-                }
+                gelu4_bias_grad(h[nt][mt], bv[nt], da[nt][mt]);  // h = act = GELU(h + b), dH = dA * GELU'(h + b)
         uint4 pa[MT][2], pd[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -581,8 +572,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[nt][mt][r] = (p.dbg & 1) ? h[nt][mt][r] + bv[nt][r] : gelu_lean(h[nt][mt][r] + bv[nt][r]);
+                    gelu4_bias(h[nt][mt], bv[nt]);
             uint4 pf[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -717,13 +707,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float act, dg;
-                        gelu_lean_grad(h[nt][mt][r] + bv[nt][r], act, dg);
-                        h[nt][mt][r] = act;
-                        da[nt][mt][r] *= dg;
-                    }
+                    gelu4_bias_grad(h[nt][mt], bv[nt], da[nt][mt]);
             uint4 pd[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

@@ -180,14 +180,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
             }
         }
         if (p.act == LNX_ACT_GELU) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Gelu<T>::fwd(v[j]);
+            Gelu<T>::fwd16(v);
         } else if (p.act == LNX_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
         } else if (p.act == LNX_ACT_GELU_BWD) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] *= Gelu<T>::grad(av[mi][j]);
+            Gelu<T>::mulgrad16(v, av[mi]);
         } else if (p.act == LNX_ACT_RELU_BWD) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = av[mi][j] > 0.f ? v[j] : 0.f;
@@ -312,12 +310,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
             }
         }
         if (F & F_GELU) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = Gelu<T>::fwd(v[j]);
+            Gelu<T>::fwd16(v);
         }
         if (F & F_GELU_BWD) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] *= Gelu<T>::grad(ld[mi][j]);
+            Gelu<T>::mulgrad16(v, ld[mi]);
         }
         if (F & F_RES) {
 #pragma unroll
