@@ -268,3 +268,38 @@ def test_data_parallel_stream_logic_single_rank(golden_dir):
                     torch.testing.assert_close(p_.grad, 2 * want[k], rtol=1e-5, atol=1e-7, msg=f"{k} (accumulated)")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_odd_batches_plan_reuse_and_eval(dtype, golden_dir):
+    """Batch sizes that leave every tile ragged (1, 7), alternating on ONE model object (a plan per batch size, shared
+    parameters and gradient arena), eval-mode forwards in between, non-contiguous / half-precision inputs: logits and
+    gradients against the oracle each time."""
+    spec, z, sd, _, _, _ = load_case("tiny_a", golden_dir)
+    model = build("tiny_a", spec, sd, dtype)
+    ftol, gtol = (2e-4, 2e-3) if dtype == "fp32" else (0.08, 0.08)
+    for B in (1, 7, 1, 2):
+        x, meta = O.seeded_inputs(spec, B, 64, 1000 + B)
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        oout = O.forward(osd, spec, x, meta)
+        O.probe_loss(oout).backward()
+        # eval forward first (no autograd), from a channels-last view of the same values
+        model.eval()
+        with torch.no_grad():
+            xe = x.cuda().to(memory_format=torch.channels_last)
+            out_e = model(xe, meta.cuda())
+        model.train()
+        model.zero_grad(set_to_none=True)
+        out = model(x.cuda(), meta.cuda())
+        for t, _ in spec.heads:
+            ref = oout[t].detach()
+            for got in (out[t], out_e[t]):
+                err = (got.float().cpu() - ref).abs().max().item()
+                assert err <= ftol * max(1.0, ref.abs().max().item()), (B, t, err)
+        O.probe_loss(out).backward()
+        tot_err = tot_ref = 0.0
+        for k, p_ in model.named_parameters():
+            ref = osd[k].grad
+            tot_err += (p_.grad.float().cpu() - ref).double().pow(2).sum().item()
+            tot_ref += ref.double().pow(2).sum().item()
+        assert (tot_err / tot_ref) ** 0.5 <= gtol, (B, (tot_err / tot_ref) ** 0.5)
