@@ -239,7 +239,7 @@ def main():
             if cands:
                 with open(os.path.join(REPO, "profiles", cands[-1])) as f:
                     traffic = json.load(f)["bytes_per_launch"]
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2_kernel<{args.dtype}> (forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2/v4_kernel<{args.dtype}> (pipelined forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
                     "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                     "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
