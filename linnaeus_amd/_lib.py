@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblnx_hip.so")
+LIB_PATH = os.environ.get("LNX_LIB_PATH") or os.path.join(_HERE, "liblnx_hip.so")  # override: A/B runs against another build
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4

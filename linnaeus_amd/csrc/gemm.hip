@@ -283,7 +283,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const WgradP p) {
     }
 
     // D[row = n slot][col = k slot]: lane (s, g) holds n = .. + 4g + r, k = .. + s
-    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
@@ -429,7 +428,6 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     p.k_perm_c = a->k_perm_c;
     p.ws = a->ws;
     p.ws_floats = a->ws ? a->ws_floats : 0;
-    p.dbg = getenv("LNX_TN_DBG") ? atoi(getenv("LNX_TN_DBG")) : 0;
     p.k_store = (a->k_store > 0 && a->k_store < a->K) ? a->k_store : a->K;
     p.tiles_n = cdiv(a->N, TILE);
     p.tiles_k = cdiv(a->K, TILE);

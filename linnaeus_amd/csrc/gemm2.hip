@@ -312,7 +312,6 @@ bool nt_v2_ok(const GemmP& p, int dtype) {
 
 int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     GemmP p = p0;
-    p.dbg = 0;
     p.tiles_m = cdiv(p.M, BM2);
     p.tiles_n = cdiv(p.N, BN2);
     const int grid = p.tiles_m * p.tiles_n;
@@ -530,7 +529,6 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
         __builtin_amdgcn_sched_barrier(0);
         if (!(grp && t + 1 == ntile)) __builtin_amdgcn_s_barrier();
     }
-    if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
     if (p.ws) {
         // split-K partials: this workgroup's whole RW x CW tile, unmasked, to its slot of the workspace
         const int tiles = p.tiles_n * p.tiles_k;

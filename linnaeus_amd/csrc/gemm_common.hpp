@@ -32,7 +32,6 @@ struct GemmP {
     int act;
     int rows_per_sample;
     int tiles_m, tiles_n;
-    int dbg;  // benchmarking only (LNX_NT_DBG): 1 skip MFMA, 2 skip LDS-DMA refills, 4 skip fragment reads, 8 skip epilogue
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on
@@ -380,7 +379,6 @@ struct WgradP {
     int a_mode;
     PatchGeom pg;
     int k_perm_c, k_store;
-    int dbg;  // benchmarking only: 1 = skip the atomic epilogue
     float* ws;  // split-K partial tiles (gemm2.hip) or nullptr = atomics
     int64_t ws_floats;
     int tiles_n, tiles_k, splits, m_per_split;
