@@ -170,7 +170,7 @@ __device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
 // forward
 // ------------------------------------------------------------------------------------
 template <int NK, int MT>
-__global__ __launch_bounds__(256) void convmlp_fwd_kernel(const CmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void convmlp_fwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr int PART = Geo<NK>::PART;
@@ -613,9 +613,8 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     }
 }
 
-template <int NK>
+template <int NK, int MT>
 __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
-    constexpr int MT = 2;
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr int PART = Geo<NK>::PART;
@@ -643,9 +642,9 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dgp[ks][j] = 0.f;
 
-    const int ntile = (p.M + 31) / 32;
+    const int ntile = (p.M + 16 * MT - 1) / (16 * MT);
     for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
-        const int m_base = tile * 32;
+        const int m_base = tile * (16 * MT);
         uint4 xf[MT][NK], zf[MT][NK];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -767,17 +766,17 @@ int launch_fwd_res(const CmP& p, hipStream_t st) {
     hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
     return 0;
 }
-template <int NK>
+template <int NK, int MT>
 int launch_bwd_res(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    int grid = cdiv(cdiv(p.M, 32), 8);
+    int grid = cdiv(cdiv(p.M, 16 * MT), 8);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT>), dim3(grid), dim3(512), lds, st, p);
     return 0;
 }
 
@@ -843,9 +842,11 @@ extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
     p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
     hipStream_t st = (hipStream_t)stream;
     switch (a->C) {
-        case 32: launch_bwd_res<1>(p, st); break;
-        case 64: launch_bwd_res<2>(p, st); break;
-        case 96: launch_bwd_res<3>(p, st); break;
+        // rows per wave tile (16 MT): MT = 2 halves the LDS weight reads per MFMA but needs 256+ registers at C >= 64
+        // (it spilled 26 / 103 of them to scratch)
+        case 32: launch_bwd_res<1, 2>(p, st); break;
+        case 64: launch_bwd_res<2, 1>(p, st); break;
+        case 96: launch_bwd_res<3, 1>(p, st); break;
         case 128: launch_bwd<4, 1>(p, st); break;
         case 192: launch_bwd<6, 1>(p, st); break;
     }
