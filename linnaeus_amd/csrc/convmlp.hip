@@ -68,13 +68,14 @@ template <int NK> struct Geo {
 
 // issue the DMA of one "n-major" part: rows = 64 hidden units (n0..n0+63), columns = C channels;
 // source matrix [4C, C] row-major.  LDS image [ks][row][4 units]; unit u' holds source unit u' ^ key4(row>>3)
-template <int NK>
+template <int NK, int NW>
 __device__ __forceinline__ void dma_nmajor(unsigned char* lds_part, const unsigned char* W, int n0, int wave, int lane) {
     constexpr int C = Geo<NK>::C;
-    constexpr int NINS = 4 * NK;  // 1 KiB instructions
+    constexpr int NINS = 4 * NK;  // 1 KiB instructions, spread over the NW waves
+    static_assert(NINS % NW == 0, "DMA pieces must divide evenly over the waves");
 #pragma unroll
-    for (int t = 0; t < NINS / 4; ++t) {
-        const int i = wave + 4 * t;
+    for (int t = 0; t < NINS / NW; ++t) {
+        const int i = wave + NW * t;
         const int ks = i >> 2, rb = i & 3;
         const int row = 16 * rb + (lane >> 2), u = lane & 3;
         const unsigned char* src = W + ((int64_t)(n0 + row) * C + ks * 32 + ((u ^ key4(row >> 3)) << 3)) * 2;
@@ -85,14 +86,14 @@ __device__ __forceinline__ void dma_nmajor(unsigned char* lds_part, const unsign
 
 // issue the DMA of one "c-major" part: rows = C channels, columns = 64 hidden units (n0..n0+63);
 // source matrix [C, 4C] row-major.  LDS image [ks2][c][4 units]; unit u' holds source unit u' ^ key4(c>>2)
-template <int NK>
+template <int NK, int NW>
 __device__ __forceinline__ void dma_cmajor(unsigned char* lds_part, const unsigned char* W, int n0, int wave, int lane) {
     constexpr int C = Geo<NK>::C;
     constexpr int RB = C / 16;
     constexpr int NINS = 2 * RB;  // == 4 NK
 #pragma unroll
-    for (int t = 0; t < NINS / 4; ++t) {
-        const int i = wave + 4 * t;
+    for (int t = 0; t < NINS / NW; ++t) {
+        const int i = wave + NW * t;
         const int ks2 = i / RB, rb = i % RB;
         const int row = 16 * rb + (lane >> 2), u = lane & 3;
         const unsigned char* src = W + ((int64_t)row * (4 * C) + n0 + ks2 * 32 + ((u ^ key4(row >> 2)) << 3)) * 2;
@@ -169,24 +170,24 @@ __device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-template <int NK, int MT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void convmlp_fwd_kernel(const CmP p) {
+template <int NK, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr int PART = Geo<NK>::PART;
     constexpr int STAGE = 2 * PART;
     constexpr int NCH = 4 * C / 64;
-    constexpr int NLD = 2 * NK;  // DMA instructions per wave per stage
+    constexpr int NLD = 8 * NK / NW;  // DMA instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][W1 part | W2 part] + b1 [4C floats]
     float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
-    const int m_base = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int m_base = blockIdx.x * (16 * NW * MT) + wave * (16 * MT);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    for (int i = threadIdx.x; i < 4 * C; i += 256) b1s[i] = p.b1[i];
+    for (int i = threadIdx.x; i < 4 * C; i += 64 * NW) b1s[i] = p.b1[i];
 
     // this lane's ln fragments: row m (clamped), channels ks*32 + 8g .. +7
     uint4 xf[MT][NK];
@@ -204,14 +205,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int mt = 0; mt < MT; ++mt) o[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();  // b1s staged (plain LDS stores) before any LDS-DMA is in flight
-    dma_nmajor<NK>(smem, p.w1, 0, wave, lane);
-    dma_cmajor<NK>(smem + PART, p.w2, 0, wave, lane);
+    dma_nmajor<NK, NW>(smem, p.w1, 0, wave, lane);
+    dma_cmajor<NK, NW>(smem + PART, p.w2, 0, wave, lane);
     for (int j = 0; j < NCH; ++j) {
         const int stg = j & 1;
         __builtin_amdgcn_s_barrier();  // everyone is done reading stage stg^1 (chunk j-1); b1s visible (j = 0)
         if (j + 1 < NCH) {
-            dma_nmajor<NK>(smem + (stg ^ 1) * STAGE, p.w1, 64 * (j + 1), wave, lane);
-            dma_cmajor<NK>(smem + (stg ^ 1) * STAGE + PART, p.w2, 64 * (j + 1), wave, lane);
+            dma_nmajor<NK, NW>(smem + (stg ^ 1) * STAGE, p.w1, 64 * (j + 1), wave, lane);
+            dma_cmajor<NK, NW>(smem + (stg ^ 1) * STAGE + PART, p.w2, 64 * (j + 1), wave, lane);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -280,14 +281,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------
 // backward (data side): act, dH, dz, dln, dgamma
 // ------------------------------------------------------------------------------------
-template <int NK, int MT>
-__global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
+template <int NK, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr int PART = Geo<NK>::PART;
     constexpr int STAGE = 3 * PART;  // W1 slice | W2^T slice | W1^T slice
     constexpr int NCH = 4 * C / 64;
-    constexpr int NLD = 3 * NK;
+    constexpr int NLD = 12 * NK / NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
     float* dgs = b1s + 4 * C;  // [C] per-workgroup dgamma partial
@@ -295,11 +296,11 @@ __global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
-    const int m_base = blockIdx.x * (64 * MT) + wave * (16 * MT);
+    const int m_base = blockIdx.x * (16 * NW * MT) + wave * (16 * MT);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    for (int i = threadIdx.x; i < 4 * C; i += 256) b1s[i] = p.b1[i];
-    for (int i = threadIdx.x; i < C; i += 256) dgs[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * C; i += 64 * NW) b1s[i] = p.b1[i];
+    for (int i = threadIdx.x; i < C; i += 64 * NW) dgs[i] = 0.f;
     __syncthreads();
 
     uint4 xf[MT][NK], zf[MT][NK];  // ln fragments; dz = rowscale*gamma*g fragments (bf16)
@@ -356,17 +357,17 @@ __global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
         for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();
-    dma_nmajor<NK>(smem, p.w1, 0, wave, lane);
-    dma_nmajor<NK>(smem + PART, p.w2t, 0, wave, lane);
-    dma_cmajor<NK>(smem + 2 * PART, p.w1t, 0, wave, lane);
+    dma_nmajor<NK, NW>(smem, p.w1, 0, wave, lane);
+    dma_nmajor<NK, NW>(smem + PART, p.w2t, 0, wave, lane);
+    dma_cmajor<NK, NW>(smem + 2 * PART, p.w1t, 0, wave, lane);
     for (int j = 0; j < NCH; ++j) {
         const int stg = j & 1;
         __builtin_amdgcn_s_barrier();
         if (j + 1 < NCH) {
             unsigned char* nx = smem + (stg ^ 1) * STAGE;
-            dma_nmajor<NK>(nx, p.w1, 64 * (j + 1), wave, lane);
-            dma_nmajor<NK>(nx + PART, p.w2t, 64 * (j + 1), wave, lane);
-            dma_cmajor<NK>(nx + 2 * PART, p.w1t, 64 * (j + 1), wave, lane);
+            dma_nmajor<NK, NW>(nx, p.w1, 64 * (j + 1), wave, lane);
+            dma_nmajor<NK, NW>(nx + PART, p.w2t, 64 * (j + 1), wave, lane);
+            dma_cmajor<NK, NW>(nx + 2 * PART, p.w1t, 64 * (j + 1), wave, lane);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void convmlp_bwd_kernel(const CmP p) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(p.dgamma + i, dgs[i]);
+    for (int i = threadIdx.x; i < C; i += 64 * NW) atomicAdd(p.dgamma + i, dgs[i]);
 }
 
 
@@ -780,29 +781,32 @@ int launch_bwd_res(const CmP& p, hipStream_t st) {
     return 0;
 }
 
-template <int NK, int MT>
+template <int NK, int MT, int NW>
 int launch_fwd(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * 2 * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((convmlp_fwd_kernel<NK, MT>), dim3(cdiv(p.M, 64 * MT)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((convmlp_fwd_kernel<NK, MT, NW>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
     return 0;
 }
 
-template <int NK, int MT>
+template <int NK, int MT, int NW>
 int launch_bwd(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * 3 * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT>), dim3(cdiv(p.M, 64 * MT)), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
     return 0;
 }
+
+// waves per workgroup of the streamed-weight kernels: 8 (two per SIMD share one weight stream) unless LNX_CM_NW=4
+static const bool nw8 = !(getenv("LNX_CM_NW") && atoi(getenv("LNX_CM_NW")) == 4);
 
 }  // namespace
 
@@ -822,8 +826,8 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
         case 32: launch_fwd_res<1>(p, st); break;
         case 64: launch_fwd_res<2>(p, st); break;
         case 96: launch_fwd_res<3>(p, st); break;
-        case 128: launch_fwd<4, 1>(p, st); break;
-        case 192: launch_fwd<6, 1>(p, st); break;
+        case 128: if (nw8) launch_fwd<4, 1, 8>(p, st); else launch_fwd<4, 1, 4>(p, st); break;
+        case 192: if (nw8) launch_fwd<6, 1, 8>(p, st); else launch_fwd<6, 1, 4>(p, st); break;
     }
     LNX_LAUNCH_CHECK();
     return 0;
@@ -847,8 +851,8 @@ extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
         case 32: launch_bwd_res<1, 2>(p, st); break;
         case 64: launch_bwd_res<2, 1>(p, st); break;
         case 96: launch_bwd_res<3, 1>(p, st); break;
-        case 128: launch_bwd<4, 1>(p, st); break;
-        case 192: launch_bwd<6, 1>(p, st); break;
+        case 128: if (nw8) launch_bwd<4, 1, 8>(p, st); else launch_bwd<4, 1, 4>(p, st); break;
+        case 192: if (nw8) launch_bwd<6, 1, 8>(p, st); else launch_bwd<6, 1, 4>(p, st); break;
     }
     LNX_LAUNCH_CHECK();
     return 0;
