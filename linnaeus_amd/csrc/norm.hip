@@ -52,13 +52,42 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
     *reinterpret_cast<uint2*>(p) = r;
 }
 
+// Column index (in float4 units) of slot i of lane `sub`.  PAIR = 1: lanes interleave single float4 (8-byte accesses for
+// bf16 rows).  PAIR = 2: a lane owns adjacent float4 pairs, so a bf16 row is read / written in 16-byte pieces (8-byte
+// accesses run at 0.54-0.70x the 16-byte rate); used when the streamed operands are bf16.
+template <int G, int PAIR> __device__ __forceinline__ int cidx(int sub, int i) { return PAIR == 1 ? sub + G * i : 2 * sub + (i & 1) + 2 * G * (i >> 1); }
+
+template <typename T> __device__ __forceinline__ void load4x2(const T* p, float4& a, float4& b);
+template <> __device__ __forceinline__ void load4x2<float>(const float* p, float4& a, float4& b) {
+    a = *reinterpret_cast<const float4*>(p);
+    b = *reinterpret_cast<const float4*>(p + 4);
+}
+template <> __device__ __forceinline__ void load4x2<bf16_t>(const bf16_t* p, float4& a, float4& b) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+    a = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    b = make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7]);
+}
+template <typename T> __device__ __forceinline__ void store4x2(T* p, float4 a, float4 b);
+template <> __device__ __forceinline__ void store4x2<float>(float* p, float4 a, float4 b) {
+    *reinterpret_cast<float4*>(p) = a;
+    *reinterpret_cast<float4*>(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store4x2<bf16_t>(bf16_t* p, float4 a, float4 b) {
+    uint4 r;
+    bf16_t* h = reinterpret_cast<bf16_t*>(&r);
+    h[0] = (bf16_t)a.x; h[1] = (bf16_t)a.y; h[2] = (bf16_t)a.z; h[3] = (bf16_t)a.w;
+    h[4] = (bf16_t)b.x; h[5] = (bf16_t)b.y; h[6] = (bf16_t)b.z; h[7] = (bf16_t)b.w;
+    *reinterpret_cast<uint4*>(p) = r;
+}
+
 template <int G> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-template <typename TX, typename TY, int G, int V>
+template <typename TX, typename TY, int G, int V, int PAIR = 1>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
     constexpr int R = 64 / G;  // rows per wave
     const int lane = threadIdx.x & 63;
@@ -74,19 +103,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
         float4 v[V];
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int c4 = sub + G * i;
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < V; i += PAIR) {
+            const int c4 = cidx<G, PAIR>(sub, i);
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q) v[i + q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c4 < nvec) {
-                v[i] = load4<TX>(xr + 4 * c4);
-                sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                if constexpr (PAIR == 2) load4x2<TX>(xr + 4 * c4, v[i], v[i + 1]);
+                else v[i] = load4<TX>(xr + 4 * c4);
+#pragma unroll
+                for (int q = 0; q < PAIR; ++q) sum += (v[i + q].x + v[i + q].y) + (v[i + q].z + v[i + q].w);
             }
         }
         const float mu = group_sum<G>(sum) * invC;
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c4 = sub + G * i;
+            const int c4 = cidx<G, PAIR>(sub, i);
             if (c4 < nvec) {
                 v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
                 sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
@@ -101,17 +133,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
         TY* yr = reinterpret_cast<TY*>(p.y) + map_row(p.ymap, m) * p.ldy;
         const TX* ar = p.add ? reinterpret_cast<const TX*>(p.add) + (int64_t)m * p.ldadd : nullptr;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int c4 = sub + G * i;
+        for (int i = 0; i < V; i += PAIR) {
+            const int c4 = cidx<G, PAIR>(sub, i);
             if (c4 < nvec) {
-                const float4 w = *reinterpret_cast<const float4*>(p.w + 4 * c4);
-                const float4 b = *reinterpret_cast<const float4*>(p.b + 4 * c4);
-                float4 o = make_float4(v[i].x * rs * w.x + b.x, v[i].y * rs * w.y + b.y, v[i].z * rs * w.z + b.z, v[i].w * rs * w.w + b.w);
-                if (ar) {
-                    const float4 a = load4<TX>(ar + 4 * c4);
-                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                float4 o[PAIR];
+#pragma unroll
+                for (int q = 0; q < PAIR; ++q) {
+                    const float4 w = *reinterpret_cast<const float4*>(p.w + 4 * (c4 + q));
+                    const float4 b = *reinterpret_cast<const float4*>(p.b + 4 * (c4 + q));
+                    o[q] = make_float4(v[i + q].x * rs * w.x + b.x, v[i + q].y * rs * w.y + b.y, v[i + q].z * rs * w.z + b.z, v[i + q].w * rs * w.w + b.w);
+                    if (ar) {
+                        const float4 a = load4<TX>(ar + 4 * (c4 + q));
+                        o[q].x += a.x; o[q].y += a.y; o[q].z += a.z; o[q].w += a.w;
+                    }
                 }
-                store4<TY>(yr + 4 * c4, o);
+                if constexpr (PAIR == 2) store4x2<TY>(yr + 4 * c4, o[0], o[1]);
+                else store4<TY>(yr + 4 * c4, o[0]);
             }
         }
     }
@@ -136,7 +173,7 @@ struct LnBwdP {
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd
 // dw += sum_m dy * xhat,  db += sum_m dy
-template <typename TDY, typename TX, typename TDX, int G, int V>
+template <typename TDY, typename TX, typename TDX, int G, int V, int PAIR = 1>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
     constexpr int R = 64 / G;
     __shared__ float red[4][G * V * 4];
@@ -149,7 +186,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         adw[i] = adb[i] = wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c4 = sub + G * i;
+        const int c4 = cidx<G, PAIR>(sub, i);
         if (c4 < nvec) wv[i] = *reinterpret_cast<const float4*>(p.w + 4 * c4);
     }
 
@@ -164,14 +201,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         float4 xh[V], g[V];
         unsigned pos[V];  // bit j: x element j > 0 (ReLU mask)
         float s1 = 0.f, s2 = 0.f;
+        float4 xraw[V], draw[V];
+#pragma unroll
+        for (int i = 0; i < V; i += PAIR) {
+            const int c4 = cidx<G, PAIR>(sub, i);
+            if (c4 < nvec) {
+                if constexpr (PAIR == 2) {
+                    load4x2<TX>(xr + 4 * c4, xraw[i], xraw[i + 1]);
+                    load4x2<TDY>(dr + 4 * c4, draw[i], draw[i + 1]);
+                } else {
+                    xraw[i] = load4<TX>(xr + 4 * c4);
+                    draw[i] = load4<TDY>(dr + 4 * c4);
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c4 = sub + G * i;
+            const int c4 = cidx<G, PAIR>(sub, i);
             xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             pos[i] = 0;
             if (c4 < nvec) {
-                const float4 xv = load4<TX>(xr + 4 * c4);
-                float4 dv = load4<TDY>(dr + 4 * c4);
+                const float4 xv = xraw[i];
+                float4 dv = draw[i];
                 if (!rv) dv = make_float4(0.f, 0.f, 0.f, 0.f);
                 pos[i] = (xv.x > 0.f ? 1u : 0u) | (xv.y > 0.f ? 2u : 0u) | (xv.z > 0.f ? 4u : 0u) | (xv.w > 0.f ? 8u : 0u);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
@@ -188,22 +239,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         TDX* ox = reinterpret_cast<TDX*>(p.dx) + xrow * p.lddx;
         const float* gi = p.gin ? p.gin + xrow * p.ldgin : nullptr;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const int c4 = sub + G * i;
+        for (int i = 0; i < V; i += PAIR) {
+            const int c4 = cidx<G, PAIR>(sub, i);
             if (c4 < nvec) {
-                float4 o = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
-                                       rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
-                if (gi) {
-                    const float4 a = *reinterpret_cast<const float4*>(gi + 4 * c4);
-                    o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                float4 ov[PAIR];
+#pragma unroll
+                for (int q = 0; q < PAIR; ++q) {
+                    const int k = i + q;
+                    float4 o = make_float4(rs * (g[k].x - m1 - xh[k].x * m2), rs * (g[k].y - m1 - xh[k].y * m2),
+                                           rs * (g[k].z - m1 - xh[k].z * m2), rs * (g[k].w - m1 - xh[k].w * m2));
+                    if (gi) {
+                        const float4 a = *reinterpret_cast<const float4*>(gi + 4 * (c4 + q));
+                        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+                    }
+                    if (p.relu_mask) {
+                        if (!(pos[k] & 1u)) o.x = 0.f;
+                        if (!(pos[k] & 2u)) o.y = 0.f;
+                        if (!(pos[k] & 4u)) o.z = 0.f;
+                        if (!(pos[k] & 8u)) o.w = 0.f;
+                    }
+                    ov[q] = o;
                 }
-                if (p.relu_mask) {
-                    if (!(pos[i] & 1u)) o.x = 0.f;
-                    if (!(pos[i] & 2u)) o.y = 0.f;
-                    if (!(pos[i] & 4u)) o.z = 0.f;
-                    if (!(pos[i] & 8u)) o.w = 0.f;
-                }
-                store4<TDX>(ox + 4 * c4, o);
+                if constexpr (PAIR == 2) store4x2<TDX>(ox + 4 * c4, ov[0], ov[1]);
+                else store4<TDX>(ox + 4 * c4, ov[0]);
             }
         }
     }
@@ -230,7 +288,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         __syncthreads();
         for (int e = threadIdx.x; e < G * V; e += 256) {
             const int i = e / G, sb = e % G;
-            const int c4 = sb + G * i;
+            const int c4 = cidx<G, PAIR>(sb, i);
             if (c4 < nvec) {
                 float4 t = *reinterpret_cast<float4*>(&red[0][e * 4]);
 #pragma unroll
@@ -285,10 +343,32 @@ inline void pick_gv(int C, int& G, int& V) {
     V = 8;
 }
 
+// pair mode (16-byte accesses on bf16 rows): lane group of G2 lanes, each holding <= 3 float4 pairs; 0 = not applicable
+inline int pick_pair_g(int C) {
+    if (C % 8 != 0) return 0;
+    const int npair = C / 8;
+    for (int g = 4; g <= 32; g <<= 1)
+        if ((npair + g - 1) / g <= 3) return g;
+    return 0;
+}
+
 template <typename TX, typename TY>
 void launch_fwd(const LnP& p, hipStream_t st) {
     int G, V;
     pick_gv(p.C, G, V);
+    if constexpr (sizeof(TX) == 2) {
+        const int g2 = pick_pair_g(p.C);
+        if (g2 && (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.add) & 15) == 0 && (p.ldx * 2) % 16 == 0 && (p.ldy * sizeof(TY)) % 16 == 0 && (p.ldadd * 2) % 16 == 0) {
+            int grid = cdiv(p.M, 4 * (64 / g2));
+            if (grid > 4096) grid = 4096;
+            const dim3 gg(grid), bb(256);
+            if (g2 == 4) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 4, 6, 2>), gg, bb, 0, st, p);
+            else if (g2 == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 6, 2>), gg, bb, 0, st, p);
+            else if (g2 == 16) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 6, 2>), gg, bb, 0, st, p);
+            else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 6, 2>), gg, bb, 0, st, p);
+            return;
+        }
+    }
     const int rows_per_wg = 4 * (64 / G);
     int grid = cdiv(p.M, rows_per_wg);
     if (grid > 4096) grid = 4096;
@@ -327,7 +407,20 @@ void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats) {
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const dim3 g(grid), b(256);
-    if (V == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8>), g, b, 0, st, p);
+    bool launched = false;
+    if constexpr (sizeof(TDY) == 2 && sizeof(TX) == 2) {
+        const int g2 = pick_pair_g(p.C);
+        if (g2 && (((uintptr_t)p.x | (uintptr_t)p.dy | (uintptr_t)p.dx) & 15) == 0 && (p.ldx * 2) % 16 == 0 && (p.lddy * 2) % 16 == 0 && (p.lddx * sizeof(TDX)) % 16 == 0) {
+            // same grid: the partial-sum workspace is indexed by workgroup, rows are walked grid-stride
+            if (g2 == 4) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 4, 6, 2>), g, b, 0, st, p);
+            else if (g2 == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 6, 2>), g, b, 0, st, p);
+            else if (g2 == 16) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 6, 2>), g, b, 0, st, p);
+            else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 6, 2>), g, b, 0, st, p);
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if (V == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8>), g, b, 0, st, p);
     else if (G == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3>), g, b, 0, st, p);
     else if (G == 16) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3>), g, b, 0, st, p);
     else if (G == 32) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3>), g, b, 0, st, p);
