@@ -178,8 +178,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
     constexpr int STAGE = 2 * PART;
     constexpr int NCH = 4 * C / 64;
     constexpr int NLD = 8 * NK / NW;  // DMA instructions per wave per stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][W1 part | W2 part] + b1 [4C floats]
-    float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 stages][W1 part | W2 part] + b1 [4C floats]
+    float* b1s = reinterpret_cast<float*>(smem + 3 * STAGE);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -205,19 +205,24 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
         for (int mt = 0; mt < MT; ++mt) o[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();  // b1s staged (plain LDS stores) before any LDS-DMA is in flight
+    // 3-stage ring, two chunks of weights in flight: one chunk's MFMA + GELU work (~1100 cycles) does not cover the
+    // ~2000+ cycle LDS-DMA latency, so the double-buffered form stalled on every chunk.  One barrier per chunk: it
+    // publishes chunk j (every wave has waited for its own pieces) and retires the reads of chunk j-1, whose slot
+    // chunk j+2 is then issued into.
     dma_nmajor<NK, NW>(smem, p.w1, 0, wave, lane);
     dma_cmajor<NK, NW>(smem + PART, p.w2, 0, wave, lane);
+    dma_nmajor<NK, NW>(smem + STAGE, p.w1, 64, wave, lane);
+    dma_cmajor<NK, NW>(smem + STAGE + PART, p.w2, 64, wave, lane);
     for (int j = 0; j < NCH; ++j) {
-        const int stg = j & 1;
-        __builtin_amdgcn_s_barrier();  // everyone is done reading stage stg^1 (chunk j-1); b1s visible (j = 0)
-        if (j + 1 < NCH) {
-            dma_nmajor<NK, NW>(smem + (stg ^ 1) * STAGE, p.w1, 64 * (j + 1), wave, lane);
-            dma_cmajor<NK, NW>(smem + (stg ^ 1) * STAGE + PART, p.w2, 64 * (j + 1), wave, lane);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int stg = j % 3;
+        if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < NCH) {
+            unsigned char* nx = smem + ((j + 2) % 3) * STAGE;
+            dma_nmajor<NK, NW>(nx, p.w1, 64 * (j + 2), wave, lane);
+            dma_cmajor<NK, NW>(nx + PART, p.w2, 64 * (j + 2), wave, lane);
         }
-        __builtin_amdgcn_s_barrier();  // chunk j's slices have landed for every wave
         const uint32_t st = lds0 + stg * STAGE;
         f32x4_t h[4][MT];
         prod_nmajor<NK, MT>(h, st, s, g, xf);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
         uint4 pf[MT][2];
         {
             f32x4_t bv[4];
-            const uint32_t ba = lds0 + 2 * STAGE + (uint32_t)((64 * j + 8 * g) * 4);
+            const uint32_t ba = lds0 + 3 * STAGE + (uint32_t)((64 * j + 8 * g) * 4);
             CM_DS_READ128(bv[0], ba, 0);
             CM_DS_READ128(bv[1], ba, 16);
             CM_DS_READ128(bv[2], ba, 128);
@@ -783,7 +788,7 @@ int launch_bwd_res(const CmP& p, hipStream_t st) {
 
 template <int NK, int MT, int NW>
 int launch_fwd(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * 2 * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
+    const size_t lds = 3 * 2 * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
