@@ -157,6 +157,72 @@ __device__ __forceinline__ void prod_cmajor(f32x4_t (&o)[Geo<NK>::CT][MT], uint3
     }
 }
 
+// Software-pipelined forms of the two products for the kernels that have registers to spare: the fragment reads of
+// batch b+1 are in flight while the MFMAs of batch b issue (LDS returns in order, so a counted lgkmcnt wait is enough).
+// In the plain forms every batch of 4-6 MFMAs (64-96 cycles) waits out a full LDS round trip first.
+template <int NK, int MT>
+__device__ __forceinline__ void prod_nmajor_pipe(f32x4_t (&h)[4][MT], uint32_t part_addr, int s, int g, const uint4 (&xf)[MT][NK]) {
+    const uint32_t unit = (uint32_t)((g ^ key4(s >> 2)) << 4);
+    const uint32_t base = part_addr + (uint32_t)((8 * (s >> 2) + (s & 3)) * 64) + unit;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) h[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    uint4 wf[2][4];
+    CM_DS_READ128(wf[0][0], base, 0);
+    CM_DS_READ128(wf[0][1], base, 256);
+    CM_DS_READ128(wf[0][2], base, 2048);
+    CM_DS_READ128(wf[0][3], base, 2304);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + 1 < NK) {
+            const uint32_t a = base + (ks + 1) * 4096;
+            CM_DS_READ128(wf[(ks + 1) & 1][0], a, 0);
+            CM_DS_READ128(wf[(ks + 1) & 1][1], a, 256);
+            CM_DS_READ128(wf[(ks + 1) & 1][2], a, 2048);
+            CM_DS_READ128(wf[(ks + 1) & 1][3], a, 2304);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mfma16(h[nt][mt], wf[ks & 1][nt], xf[mt][ks]);
+    }
+}
+
+template <int NK, int MT>
+__device__ __forceinline__ void prod_cmajor_pipe(f32x4_t (&o)[Geo<NK>::CT][MT], uint32_t part_addr, int s, int g, const uint4 (&pf)[MT][2]) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    const uint32_t base = part_addr + (uint32_t)(s * 64) + (uint32_t)((g ^ key4(s >> 2)) << 4);
+    constexpr int GB = 4;                 // fragment reads per batch
+    constexpr int NB = 2 * CT / GB;       // batches over (ks2, ct)
+    static_assert(CT % GB == 0, "channel tiles must split into batches of 4");
+    uint4 wf[2][GB];
+#pragma unroll
+    for (int b = 0; b < GB; ++b) CM_DS_READ128(wf[0][b], base + (uint32_t)(b * 1024), 0);
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        const int ks2 = (bt * GB) / CT, c0 = (bt * GB) % CT;
+        if (bt + 1 < NB) {
+            const int ks2n = ((bt + 1) * GB) / CT, c0n = ((bt + 1) * GB) % CT;
+#pragma unroll
+            for (int b = 0; b < GB; ++b) CM_DS_READ128(wf[(bt + 1) & 1][b], base + (uint32_t)(ks2n * C * 64 + (c0n + b) * 1024), 0);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < GB; ++b)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mfma16(o[c0 + b][mt], wf[bt & 1][b], pf[mt][ks2]);
+    }
+}
+
 __device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
     Vec16<bf16_t> v;
 #pragma unroll
@@ -225,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
         }
         const uint32_t st = lds0 + stg * STAGE;
         f32x4_t h[4][MT];
-        prod_nmajor<NK, MT>(h, st, s, g, xf);
+        prod_nmajor_pipe<NK, MT>(h, st, s, g, xf);
         // bias + exact-erf GELU on the accumulator; row 4g+r of tile nt <-> hidden n = 64j + 32(nt>>1) + 8g + 4(nt&1) + r
         uint4 pf[MT][2];
         {
@@ -248,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
                 pf[mt][1] = pack8(h[2][mt], h[3][mt]);
             }
         }
-        prod_cmajor<NK, MT>(o, st + PART, s, g, pf);
+        prod_cmajor_pipe<NK, MT>(o, st + PART, s, g, pf);
     }
     // epilogue: lane (s = row m, g) holds channels c = 16 ct + 4 g + r
 #pragma unroll
@@ -380,8 +446,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
         __builtin_amdgcn_s_barrier();
         const uint32_t st = lds0 + stg * STAGE;
         f32x4_t h[4][MT], da[4][MT];
-        prod_nmajor<NK, MT>(h, st, s, g, xf);          // h  = ln . W1^T   (pre-bias)
-        prod_nmajor<NK, MT>(da, st + PART, s, g, zf);  // dA = dz . W2
+        prod_nmajor_pipe<NK, MT>(h, st, s, g, xf);          // h  = ln . W1^T   (pre-bias)
+        prod_nmajor_pipe<NK, MT>(da, st + PART, s, g, zf);  // dA = dz . W2
         f32x4_t bv[4];
         const uint32_t ba = lds0 + 2 * STAGE + (uint32_t)((64 * j + 8 * g) * 4);
         CM_DS_READ128(bv[0], ba, 0);
@@ -412,7 +478,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
                 st16(p.dh + off + 64, pd[mt][1]);
             }
         }
-        prod_cmajor<NK, MT>(dl, st + 2 * PART, s, g, pd);  // dln += dH . W1
+        prod_cmajor_pipe<NK, MT>(dl, st + 2 * PART, s, g, pd);  // dln += dH . W1
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
