@@ -687,7 +687,9 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
     } while (0)
     static const bool no_ws = getenv("LNX_TN_ATOMIC") != nullptr;  // A/B switch for benchmarking
     const size_t need = (size_t)p.splits * tiles * (256 * 128) + (size_t)p.splits * p.tiles_n * RW;
-    if (no_ws || p.ws == nullptr || (size_t)p.ws_floats < need || p.splits < 2) p.ws = nullptr;
+    // padded tiles are stored and re-read whole: with poorly filled tiles (N x K well below tiles x 256 x 128) the atomics move fewer bytes
+    const bool sparse_tiles = (double)p.N * p.k_store < 0.7 * (double)tiles * (256 * 128);
+    if (no_ws || p.ws == nullptr || (size_t)p.ws_floats < need || p.splits < 2 || sparse_tiles) p.ws = nullptr;
     if (wide_r) TNV2(256, 128);
     else TNV2(128, 256);
 #undef TNV2
