@@ -426,10 +426,15 @@ class mFormerV1(nn.Module):
             return torch.stack(rows, 0).contiguous()
         if not self.training or all(p == 0.0 for p in probs):
             return None
-        keep = torch.tensor([1.0 - p for p in probs], device=dev).unsqueeze(1)
+        cache = st.get("drop_keep")
+        if cache is None or cache[0] != tuple(probs) or cache[1].device != dev:
+            # built once per plan: a host->device copy every step would stall the launch queue
+            keep = torch.tensor([1.0 - p for p in probs], device=dev).unsqueeze(1)
+            cache = st["drop_keep"] = (tuple(probs), keep, bytes(int(p > 0.0) for p in probs))
+        _, keep, mask = cache
         scales = torch.floor(keep + torch.rand(len(probs), B, device=dev)) / keep
-        st["drop_mask"] = bytes(int(p > 0.0) for p in probs)
-        return scales.contiguous()
+        st["drop_mask"] = mask
+        return scales
 
     def _plan_forward(self, x, meta, drop):
         st = self._active
