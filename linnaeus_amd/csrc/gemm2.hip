@@ -388,7 +388,7 @@ constexpr int TBM = 64;
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a_), "i"(off2) : "memory");                 \
     } while (0)
 
-template <int RW, int CW>
+template <int RW, int CW, bool PATCH>
 __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
     typedef bf16_t T;
     constexpr int RROW = RW * 2, CROW = CW * 2;            // bytes per LDS row of each tile
@@ -437,17 +437,31 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
             int col = k0 + ((slot ^ ((row & 7) << 1)) << 3);
             const int lim = ((p.K + 7) >> 3) << 3;
             if (col >= lim) col = lim - 8;
-            src[j] = p.A + ((int64_t)(m_begin + row) * p.lda + col) * 2;
-            step[j] = (int64_t)TBM * p.lda * 2;
+            if (PATCH) {
+                // 2x2 patch gather from the NHWC source: row m -> patch origin (recomputed per contraction tile, the row
+                // stride is not constant), column k = (kh, kw, c) -> offset inside the patch; a 16-byte chunk never
+                // straddles a (kh) segment because 2 * Cin % 8 == 0
+                src[j] = p.A + patch_col(p.pg, col) * 2;
+                step[j] = m_begin + row;  // first contraction row of this piece
+            } else {
+                src[j] = p.A + ((int64_t)(m_begin + row) * p.lda + col) * 2;
+                step[j] = (int64_t)TBM * p.lda * 2;
+            }
         }
     }
     auto issue_tile = [&](int stage) {
 #pragma unroll
         for (int j = 0; j < NINS; ++j) {
             const int i = wave + 8 * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[j],
+            const unsigned char* gp = src[j];
+            if (PATCH && i >= RINS) {
+                gp += patch_base(p.pg, (int)step[j]) * 2;
+                step[j] += TBM;
+            } else {
+                src[j] += step[j];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)(smem + stage * STG + i * 1024), 16, 0, 0);
-            src[j] += step[j];
         }
     };
 
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int
 }
 
 bool tn_v2_ok(const WgradP& p, int dtype) {
-    return dtype == LNX_BF16 && p.a_mode == LNX_ADDR_PLAIN && p.M % TBM == 0 && p.M >= 4096 && p.N >= 8 && p.K >= 8;
+    return dtype == LNX_BF16 && p.M % TBM == 0 && p.M >= 4096 && p.N >= 8 && p.K >= 8;
 }
 
 int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
@@ -676,14 +690,19 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
     p.splits = cdiv(mtiles, per);
     const int grid = tiles * p.splits;
     const size_t lds = NSTAGE * (size_t)(TBM * (RW + CW) * 2);
-#define TNV2(R, C)                                                                                                                   \
+#define TNV2_(R, C, P)                                                                                                               \
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \
         if (!attr) {                                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<R, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_v2_kernel<R, C, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr = true;                                                                                                             \
         }                                                                                                                            \
-        hipLaunchKernelGGL((gemm_tn_v2_kernel<R, C>), dim3(grid), dim3(512), lds, st, p);                                            \
+        hipLaunchKernelGGL((gemm_tn_v2_kernel<R, C, P>), dim3(grid), dim3(512), lds, st, p);                                         \
+    } while (0)
+#define TNV2(R, C)                                           \
+    do {                                                     \
+        if (p.a_mode == LNX_ADDR_PATCH2) TNV2_(R, C, true);  \
+        else TNV2_(R, C, false);                             \
     } while (0)
     static const bool no_ws = getenv("LNX_TN_ATOMIC") != nullptr;  // A/B switch for benchmarking
     const size_t need = (size_t)p.splits * tiles * (256 * 128) + (size_t)p.splits * p.tiles_n * RW;
@@ -693,6 +712,7 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
     if (wide_r) TNV2(256, 128);
     else TNV2(128, 256);
 #undef TNV2
+#undef TNV2_
     if (p.ws) {
         const int64_t work = (int64_t)p.N * ((p.k_store + 3) >> 2) + (p.db ? p.N : 0);
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, st, p, RW, CW);
