@@ -62,13 +62,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (weak scaling).  Default: 256 at --gpus 1 (BASELINE config 2) and 128 at --gpus > 1 "
+                         "(config 3: global batch 1024 at 8 GPUs, the point the north-star scaling target is defined at)")
     ap.add_argument("--arch", default="sm")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
     ap.add_argument("--force-dp", action="store_true", help="single GPU rehearsal of the data-parallel path: RCCL world size 1, collectives issued")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW(fused=True) instead of linnaeus_amd.optim.FusedAdamW")
+    ap.add_argument("--drop-in", action="store_true",
+                    help="time the model the way the reference's train.py:147-176,279-316 drives it: torch cross_entropy per task, "
+                         "loss.backward(), clip_grad_norm_, torch.optim.AdamW.step, zero_grad (nothing from linnaeus_amd but the model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -119,6 +124,8 @@ def cpu_baseline(args, cfg):
 
 def main():
     args = parse()
+    if args.batch is None:
+        args.batch = 256 if args.gpus == 1 else 128
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -131,6 +138,7 @@ def main():
     if world > 1 or args.force_dp:
         import torch.distributed as dist
 
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")  # one line on rank 0: the RCCL build that carries the collectives
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29544")
@@ -152,6 +160,8 @@ def main():
         model.grad_mode = "direct"
     if args.no_optim:
         opt = None
+    elif args.drop_in:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)  # what optimizers/build.py builds for OPTIMIZER.NAME adamw
     elif args.torch_optim:
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
     else:
@@ -167,7 +177,19 @@ def main():
     meta = torch.rand(B, 5, device=dev, generator=g)
     tg = {t: torch.randint(1, c, (B,), device=dev, generator=g) for t, c in TASKS}
 
+    params = [p_ for p_ in model.parameters() if p_.requires_grad]
+
     def step():
+        if args.drop_in:
+            # the reference's step glue (train.py:147-176,279-316) around the drop-in model, torch ops only
+            out = net(x, meta)
+            loss = sum(F.cross_entropy(out[t].float(), tg[t]) for t, _ in TASKS)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            if opt is not None:
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+            return loss
         model.zero_grad(set_to_none=True)
         out = net(x, meta)
         loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE, one HIP launch per task
@@ -199,6 +221,31 @@ def main():
     last_loss = float(loss.item())
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
     ips = world * B * args.steps / dt
+
+    # ---- data parallel only: the same steps WITHOUT the gradient collectives (no_sync), outside the timed region.
+    # exposed_allreduce_ms = step time with collectives - without; n1_equiv = what one GPU does alone at this per-GPU
+    # batch, so the scaling efficiency value / (n_gpus * n1_equiv) is computable from this one line.
+    dp_extra = None
+    if dist and hasattr(net, "no_sync"):
+        k = max(3, min(args.steps, 10))
+        with net.no_sync():
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            torch.cuda.synchronize()
+            dt_ns = time.perf_counter() - t1
+        tt = torch.tensor([dt_ns], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms_ns = tt.item() / k * 1e3
+        dp_extra = {"ms_per_step_no_sync": round(ms_ns, 3), "exposed_allreduce_ms": round(dt / args.steps * 1e3 - ms_ns, 3),
+                    "n1_equiv_images_per_sec": round(B / (ms_ns * 1e-3), 2),
+                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                    "nccl_env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith(("NCCL_", "RCCL_"))}}
 
     # ---- live per-kernel-class timing (untimed extra steps, rank 0 only) ----
     roofline, kernels = None, {}
@@ -268,6 +315,10 @@ def main():
         "loss": round(last_loss, 4),
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }
+    if dp_extra:
+        line["data_parallel"] = dp_extra
+    if args.drop_in:
+        line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
     print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

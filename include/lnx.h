@@ -402,6 +402,8 @@ typedef struct lnx_mformer_cfg {
     int only_last_cls;
     int n_tasks;
     int task_classes[LNX_MAX_TASKS];
+    int inference;             /* 1: forward-only plan (model.eval() under no_grad, validation.py:199): no backward scratch,
+                                  blocks share their activation buffers; lnx_plan_backward fails on it */
 } lnx_mformer_cfg;
 
 typedef struct lnx_plan lnx_plan;

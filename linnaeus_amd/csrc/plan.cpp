@@ -480,29 +480,41 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->o_stem_rstd = cv.take(M0 * 4);
     int64_t maxMC = 0, maxM4C = 0;
     bool any_fused = false;
+    // Inference plans: nothing is saved for a backward, so the blocks of a stage share one set of activation buffers
+    // and the residual stream ping-pongs between two (the workspace no longer grows with the depth).
+    const bool inf = c.inference != 0;
     for (int s = 0; s < 2; ++s) {
         const int64_t M = (int64_t)B * p->HW[s], C = D[s];
         if (M * C > maxMC) maxMC = M * C;
         if (M * 4 * C > maxM4C) maxM4C = M * 4 * C;
-        for (auto& k : p->conv[s]) {
-            k.xin = cv.take(M * C * 4);
-            k.y = cv.take(M * C * esz);
-            k.ln = cv.take(M * C * esz);
-            k.mean = cv.take(M * 4);
-            k.rstd = cv.take(M * 4);
+        int64_t pp[2] = {0, 0};
+        if (inf) {
+            pp[0] = cv.take(M * C * 4);
+            pp[1] = cv.take(M * C * 4);
+        }
+        const size_t nb = p->conv[s].size();
+        for (size_t i = 0; i < nb; ++i) {
+            ConvBlk& k = p->conv[s][i];
+            const bool share = inf && i > 0;
+            const ConvBlk& f = p->conv[s][0];
+            k.xin = inf ? pp[i & 1] : cv.take(M * C * 4);
+            k.y = share ? f.y : cv.take(M * C * esz);
+            k.ln = share ? f.ln : cv.take(M * C * esz);
+            k.mean = share ? f.mean : cv.take(M * 4);
+            k.rstd = share ? f.rstd : cv.take(M * 4);
             k.fused = lnx_convmlp_supported(c.dtype, (int)C) != 0 && getenv("LNX_NO_FUSED_MLP") == nullptr;
             any_fused = any_fused || k.fused;
             if (!k.fused) {
-                k.hpre = cv.take(M * 4 * C * esz);
-                k.act = cv.take(M * 4 * C * esz);
+                k.hpre = share ? f.hpre : cv.take(M * 4 * C * esz);
+                k.act = share ? f.act : cv.take(M * 4 * C * esz);
             }
-            k.z = cv.take(M * C * esz);
+            k.z = share ? f.z : cv.take(M * C * esz);
         }
-        p->o_stage_out[s] = cv.take(M * C * 4);
+        p->o_stage_out[s] = inf ? pp[nb & 1] : cv.take(M * C * 4);
         p->down[s].ln = cv.take(M * C * esz);
         p->down[s].mean = cv.take(M * 4);
         p->down[s].rstd = cv.take(M * 4);
-        p->o_g[s] = cv.take(M * C * 4);
+        p->o_g[s] = inf ? 0 : cv.take(M * C * 4);
     }
     for (int s = 0; s < 2; ++s) {
         const int N = s == 0 ? p->N2 : p->N3;
@@ -512,27 +524,34 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         const int64_t wide = hid > 3 * C ? hid : 3 * C;
         if (M * wide > maxM4C) maxM4C = M * wide;
         p->o_tok[s] = cv.take(M * C * 4);
+        int64_t pp[2] = {0, 0};
+        if (inf) {
+            pp[0] = cv.take(M * C * 4);
+            pp[1] = cv.take(M * C * 4);
+        }
         for (size_t i = 0; i < p->rope[s].size(); ++i) {
             RopeBlk& k = p->rope[s][i];
+            const bool share = inf && i > 0;
+            const RopeBlk& f = p->rope[s][0];
             if (i == 0) k.xin = p->o_tok[s];  // later blocks: output buffer of the previous block (set below)
-            k.n1 = cv.take(M * C * esz);
-            k.mean1 = cv.take(M * 4);
-            k.rstd1 = cv.take(M * 4);
-            k.qkvbuf = cv.take(M * 3 * C * esz);
+            k.n1 = share ? f.n1 : cv.take(M * C * esz);
+            k.mean1 = share ? f.mean1 : cv.take(M * 4);
+            k.rstd1 = share ? f.rstd1 : cv.take(M * 4);
+            k.qkvbuf = share ? f.qkvbuf : cv.take(M * 3 * C * esz);
             k.cos = cv.take((int64_t)p->HW[2 + s] * heads * 32 * 4);
-            k.o = cv.take(M * C * esz);
-            k.lse = cv.take((int64_t)B * heads * N * 4);
-            k.xmid = cv.take(M * C * 4);
-            k.n2 = cv.take(M * C * esz);
-            k.mean2 = cv.take(M * 4);
-            k.rstd2 = cv.take(M * 4);
-            k.hpre = cv.take(M * hid * esz);
-            k.act = cv.take(M * hid * esz);
-            const int64_t outb = cv.take(M * C * 4);
+            k.o = share ? f.o : cv.take(M * C * esz);
+            k.lse = share ? f.lse : cv.take((int64_t)B * heads * N * 4);
+            k.xmid = share ? f.xmid : cv.take(M * C * 4);
+            k.n2 = share ? f.n2 : cv.take(M * C * esz);
+            k.mean2 = share ? f.mean2 : cv.take(M * 4);
+            k.rstd2 = share ? f.rstd2 : cv.take(M * 4);
+            k.hpre = share ? f.hpre : cv.take(M * hid * esz);
+            k.act = share ? f.act : cv.take(M * hid * esz);
+            const int64_t outb = inf ? pp[i & 1] : cv.take(M * C * 4);
             if (i + 1 < p->rope[s].size()) p->rope[s][i + 1].xin = outb;
             else p->o_stage_out[2 + s] = outb;
         }
-        p->o_g[2 + s] = cv.take(M * C * 4);
+        p->o_g[2 + s] = inf ? 0 : cv.take(M * C * 4);
         for (auto& k : p->meta[s]) {
             // meta heads run in fp32 storage in both modes (M = batch rows: negligible cost)
             k.t0 = cv.take((int64_t)B * 16 * 4);
@@ -554,7 +573,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_t1 = cv.take(M2 * D[2] * esz);
         p->o_t1_mean = cv.take(M2 * 4);
         p->o_t1_rstd = cv.take(M2 * 4);
-        p->o_dt1 = cv.take(M2 * D[2] * esz);
+        p->o_dt1 = inf ? 0 : cv.take(M2 * D[2] * esz);
         p->down[2].ln = cv.take((int64_t)B * p->HW[2] * D[2] * esz);
         p->down[2].mean = cv.take((int64_t)B * p->HW[2] * 4);
         p->down[2].rstd = cv.take((int64_t)B * p->HW[2] * 4);
@@ -580,15 +599,17 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_dlT = cv.take((int64_t)B * maxld * esz);
     }
     p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
-    p->o_lnws = cv.take(p->lnws_floats * 4);
     p->lnws_side_floats = (int64_t)256 * 2 * D[3];
-    p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
-    p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
-    p->o_sA = cv.take(maxM4C * esz);
-    if (any_fused) p->o_sB = cv.take(maxM4C * esz);
-    p->o_sC = cv.take(maxMC * esz);
-    p->o_sD = cv.take(maxMC * esz);
-    {
+    if (!inf) {
+        p->o_lnws = cv.take(p->lnws_floats * 4);
+        p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
+        p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
+        p->o_sA = cv.take(maxM4C * esz);
+        if (any_fused) p->o_sB = cv.take(maxM4C * esz);
+        p->o_sC = cv.take(maxMC * esz);
+        p->o_sD = cv.take(maxMC * esz);
+    }
+    if (!inf) {
         int64_t gmax = 0, dmax = 0;
         for (int s = 0; s < 2; ++s) {
             const int N = s == 0 ? p->N2 : p->N3;
@@ -1253,6 +1274,7 @@ int join_side(const Ctx& c, int s) {
 }  // namespace
 
 extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, int segment, void* stream) {
+    if (p && p->c.inference) FAIL("lnx_plan_backward: this plan was created for inference (cfg.inference = 1)");
     if (!p || !p->bound || !p->has_grads) FAIL("lnx_plan_backward: plan is not bound with gradient buffers");
     if (!p->fwd_done) FAIL("lnx_plan_backward: no forward to differentiate");
     if (segment < -1 || segment > 3) FAIL("lnx_plan_backward: bad segment %d", segment);

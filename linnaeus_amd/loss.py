@@ -77,6 +77,7 @@ class TaxonomyAwareLabelSmoothingCE(nn.Module):
         self.apply_class_weights = apply_class_weights
         self.ignore_index = ignore_index
         self.config = config
+        self.validate_targets = True
         self.weight = None
         if weight is not None:
             if not isinstance(weight, torch.Tensor):
@@ -112,9 +113,11 @@ class TaxonomyAwareLabelSmoothingCE(nn.Module):
                 self.weight = self.class_weight = self.weight.to(logits.device)
             cw = self.weight
         loss = _SoftCE.apply(logits, target, self.soft_labels, cw, self.ignore_index, 0.0)
-        # out-of-range targets surface as NaN rows from the kernel; raise like the reference (this is the one host sync,
-        # and only on the error path's check)
-        if torch.isnan(loss).any():
+        # Out-of-range targets surface as NaN rows from the kernel; the reference raises IndexError for them
+        # (taxonomy_label_smoothing.py:330-343, itself a host sync).  This check is ONE host<->device sync per call:
+        # set `validate_targets = False` on the criterion to keep the launch queue asynchronous (NaN rows then
+        # propagate into the loss instead of raising).
+        if self.validate_targets and torch.isnan(loss).any():
             bad = ((target < 0) | (target >= self.num_classes)).sum().item()
             if bad:
                 raise IndexError(f"{bad} target indices out of bounds [0, {self.num_classes - 1}].")

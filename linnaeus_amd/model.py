@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+from collections import OrderedDict
 from typing import Any, Dict, List, Optional, Sequence
 
 import torch
@@ -32,7 +33,7 @@ class _Cfg(C.Structure):
         ("dtype", C.c_int), ("batch", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int), ("in_chans", C.c_int),
         ("dims", C.c_int * 4), ("conv_depths", C.c_int * 2), ("rope_depths", C.c_int * 2), ("rope_heads", C.c_int * 2),
         ("mlp_hidden", C.c_int * 2), ("n_meta", C.c_int), ("meta_dims", C.c_int * 8), ("only_last_cls", C.c_int),
-        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16),
+        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16), ("inference", C.c_int),
     ]
 
 
@@ -129,6 +130,9 @@ class _PlanFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeats, dlogits):
+        if ctx.st.get("destroyed"):
+            raise L.LnxError("backward() of a forward whose plan was evicted from the plan cache (more than "
+                             "`max_cached_plans` distinct batch shapes were used in between); raise model.max_cached_plans")
         if ctx.st["fwd_id"] != ctx.fwd_id:
             raise L.LnxError("backward() of a forward whose saved activations were overwritten by a later forward of the same "
                              "(batch, image-size) plan; run backward before the next forward")
@@ -240,8 +244,12 @@ class mFormerV1(nn.Module):
         self._hidden = [int(rdims[s] * rratio[s]) for s in range(2)]
         self._in_chans = in_chans
         self._dtype_code = _DTYPES[str(kwargs.get("compute_dtype", os.environ.get("LNX_DTYPE", M.get("LNX_DTYPE", "bf16")))).lower()]
-        self.grad_mode = "autograd"  # or "direct": gradients are written straight into .grad views of one flat arena
-        self._plans: Dict[Any, Dict[str, Any]] = {}
+        # "direct" (default): parameter gradients are written straight into .grad views of one flat fp32 arena (what
+        # loss.backward() + optimizer.step() callers such as the reference's train.py need; zero-copy).  "autograd": the
+        # autograd Function returns copies, for torch.autograd.grad() callers (GradNorm-style code).
+        self.grad_mode = "direct"
+        self.max_cached_plans = 3     # LRU bound of native plans (each owns a workspace proportional to the batch size)
+        self._plans: "OrderedDict[Any, Dict[str, Any]]" = OrderedDict()
         self._active = None
         self._inject_drop = None      # tests: list of per-call [B] multipliers (None entries = no drop)
         self._segment_hook = None     # DataParallel: called after each backward segment is enqueued
@@ -290,6 +298,25 @@ class mFormerV1(nn.Module):
     def set_compute_dtype(self, name: str) -> None:
         """'bf16' (production: bf16 operands, fp32 accumulate/residual) or 'fp32' (strict parity)."""
         self._dtype_code = _DTYPES[name.lower()]
+        self.release_plans()
+
+    def _destroy_plan(self, st) -> None:
+        if st.get("destroyed"):
+            return
+        st["destroyed"] = True
+        try:
+            L.lib().lnx_plan_destroy(st["handle"])  # synchronises and destroys the plan's side stream and events
+        finally:
+            st["handle"] = None
+            st["ws"] = None       # the workspace goes back to the caching allocator
+            st["saved_inputs"] = None
+
+    def release_plans(self) -> None:
+        """Destroy every cached native plan and free its workspace (e.g. before an AutoBatch probe or after validation)."""
+        if torch.cuda.is_available() and self._plans:
+            torch.cuda.synchronize()
+        for st in list(self._plans.values()):
+            self._destroy_plan(st)
         self._plans.clear()
         self._active = None
 
@@ -314,12 +341,24 @@ class mFormerV1(nn.Module):
             return lin.weight if kind == "weight" else lin.bias
         return self.get_parameter(plan_name)
 
-    def _get_plan(self, B: int, H: int, W: int) -> Dict[str, Any]:
-        key = (B, H, W, self._dtype_code)
+    def _get_plan(self, B: int, H: int, W: int, train: bool = True) -> Dict[str, Any]:
+        """Native plan for one (batch, image size, dtype, train/inference) combination.  Inference plans (no_grad /
+        frozen model) carry no backward scratch and share activation buffers between blocks.  The cache is a small
+        LRU: an evicted plan is destroyed and its workspace freed."""
+        key = (B, H, W, self._dtype_code, bool(train))
         st = self._plans.get(key)
         lib = L.lib()
+        if st is not None:
+            self._plans.move_to_end(key)
         if st is None:
+            while len(self._plans) >= max(1, int(self.max_cached_plans)):
+                _, old = self._plans.popitem(last=False)
+                if old is self._active:
+                    self._active = None
+                torch.cuda.current_stream().synchronize()
+                self._destroy_plan(old)
             cfg = _Cfg()
+            cfg.inference = 0 if train else 1
             cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
             cfg.dims[:] = self._dims
             cfg.conv_depths[:] = self._depths[:2]
@@ -359,7 +398,7 @@ class mFormerV1(nn.Module):
             st = dict(handle=handle, names=names, params=params, ws=ws, ptrs=None, n=n, seg_of=seg_of,
                       ndrop=lib.lnx_plan_num_drop_calls(handle), logits_numel=lib.lnx_plan_logits_numel(handle),
                       logit_off=[lib.lnx_plan_logits_offset(handle, i) for i in range(len(tasks))],
-                      logit_ld=[lib.lnx_plan_logits_ld(handle, i) for i in range(len(tasks))], tasks=tasks, B=B, fwd_id=0)
+                      logit_ld=[lib.lnx_plan_logits_ld(handle, i) for i in range(len(tasks))], tasks=tasks, B=B, fwd_id=0, train=bool(train))
             self._plans[key] = st
         self._ensure_bound(st)
         return st
@@ -394,13 +433,14 @@ class mFormerV1(nn.Module):
         for p_ in params:
             if p_.dtype != torch.float32 or not p_.is_contiguous():
                 raise L.LnxError("parameters must be contiguous fp32 (master weights); the bf16 operand copies are made by the plan")
-        self._ensure_grad_arena(st)
+        if st["train"]:
+            self._ensure_grad_arena(st)
         ptrs = tuple(p_.data_ptr() for p_ in params)
         if st["ptrs"] == ptrs:
             return
         n = st["n"]
         parr = (C.c_void_p * n)(*ptrs)
-        garr = (C.c_void_p * n)(*[v.data_ptr() for v in self._grad_views])
+        garr = (C.c_void_p * n)(*[v.data_ptr() for v in self._grad_views]) if st["train"] else None
         wsp = (st["ws"].data_ptr() + 255) // 256 * 256
         L.check(L.lib().lnx_plan_bind(st["handle"], parr, garr, C.c_void_p(wsp)), "lnx_plan_bind")
         st["ptrs"] = ptrs
@@ -432,7 +472,8 @@ class mFormerV1(nn.Module):
             keep = torch.tensor([1.0 - p for p in probs], device=dev).unsqueeze(1)
             cache = st["drop_keep"] = (tuple(probs), keep, bytes(int(p > 0.0) for p in probs))
         _, keep, mask = cache
-        scales = torch.floor(keep + torch.rand(len(probs), B, device=dev)) / keep
+        # floor(keep + U) is Bernoulli(keep): one RNG launch + one divide instead of rand/add/floor/div
+        scales = torch.bernoulli(keep.expand(len(probs), B)).div_(keep)
         st["drop_mask"] = mask
         return scales
 
@@ -440,7 +481,7 @@ class mFormerV1(nn.Module):
         st = self._active
         B = x.shape[0]
         feats = torch.empty(B, self._dims[3], device=x.device, dtype=torch.float32)
-        logits = torch.zeros(max(st["logits_numel"], 1), device=x.device, dtype=torch.float32)
+        logits = torch.empty(max(st["logits_numel"], 1), device=x.device, dtype=torch.float32)  # every exposed element is written by the head GEMMs
         mask = st.get("drop_mask") if drop is not None else None
         L.check(L.lib().lnx_plan_forward(
             st["handle"], C.c_void_p(x.data_ptr()), C.c_void_p(meta.data_ptr()) if meta is not None else None,
@@ -453,8 +494,20 @@ class mFormerV1(nn.Module):
     def _plan_backward(self, st, dfeats, dlogits):
         direct = self.grad_mode == "direct"
         params = st["params"]
-        fresh = (not direct) or any(p_.grad is None for p_ in params)
-        if fresh:
+        views = self._grad_views
+        # The kernels ACCUMULATE into the arena.  A slice may keep its contents only if the parameter's .grad IS that
+        # slice (gradient accumulation in direct mode); every other slice (grad None, or a foreign tensor such as a clone
+        # left by autograd mode / zero_grad(set_to_none=False)) must start from zero.
+        if direct:
+            alias = [p_.grad is not None and p_.grad.data_ptr() == v.data_ptr() for p_, v in zip(params, views)]
+            if not any(alias):
+                self._grad_arena.zero_()
+            elif not all(alias):
+                for a, v in zip(alias, views):
+                    if not a:
+                        v.zero_()
+        else:
+            alias = None
             self._grad_arena.zero_()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         dl = dlogits.contiguous() if dlogits is not None else None
@@ -471,14 +524,14 @@ class mFormerV1(nn.Module):
                                               C.c_void_p(df.data_ptr()) if df is not None else None, seg, stream), "lnx_plan_backward")
                 self._segment_hook(seg)
         if direct:
-            for p_, v in zip(params, self._grad_views):
+            for p_, v, a in zip(params, views, alias):
                 if p_.grad is None:
                     p_.grad = v
-                elif p_.grad.data_ptr() != v.data_ptr():
+                elif not a:
                     p_.grad.add_(v)
             return [None] * len(params)
-        # autograd mode: hand out copies, so .grad never aliases the arena the next backward zeroes
-        return [v.clone() for v in self._grad_views]
+        # autograd mode: hand out copies, so nothing a caller holds ever aliases the arena the next backward zeroes
+        return [v.clone() for v in views]
 
     # ------------------------------------------------------------------ public forward
     def _run(self, x: torch.Tensor, meta: Optional[torch.Tensor]):
@@ -497,10 +550,11 @@ class mFormerV1(nn.Module):
             meta = meta.float().contiguous()
         else:
             meta = None
-        st = self._get_plan(B, H, W)
+        train = torch.is_grad_enabled() and any(p_.requires_grad for p_ in self.parameters())
+        st = self._get_plan(B, H, W, train)
         self._active = st
         drop = self._draw_drop_scales(st, B, x.device)
-        if torch.is_grad_enabled() and any(p_.requires_grad for p_ in st["params"]):
+        if train:
             feats, logits = _PlanFn.apply(self, x, meta, drop, *st["params"])
         else:
             feats, logits = self._plan_forward(x, meta, drop)
@@ -514,18 +568,20 @@ class mFormerV1(nn.Module):
     def forward(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         st, feats, logits = self._run(x, meta)
         B = x.shape[0]
+        acast = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
         out = {}
         for i, t in enumerate(st["tasks"]):
             ld = st["logit_ld"][i]
             nc = self.head[t].effective_linear.out_features
             out[t] = logits[st["logit_off"][i]: st["logit_off"][i] + B * ld].view(B, ld)[:, :nc]
+            if acast is not None:
+                out[t] = out[t].to(acast)  # the reference returns logits in the autocast dtype (SURVEY 8b "Tensor conventions")
         self._last_feats = feats
         return out
 
     def __del__(self):
         try:
-            lib = L.lib()
             for st in self._plans.values():
-                lib.lnx_plan_destroy(st["handle"])
+                self._destroy_plan(st)
         except Exception:
             pass

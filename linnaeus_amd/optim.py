@@ -34,7 +34,7 @@ class FusedAdamW(torch.optim.Optimizer):
         lib = L.lib()
         arr = (L.AdamWDesc * len(items))()
         blk = 0
-        for i, (gi, p) in enumerate(items):
+        for i, (gi, p) in enumerate(items):  # gi: hyper-parameter slot = (param group, step count) combination
             st = self.state[p]
             arr[i].p, arr[i].m, arr[i].v, arr[i].g = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.grad.data_ptr()
             arr[i].n, arr[i].group, arr[i].block_start = p.numel(), gi, blk
@@ -66,21 +66,27 @@ class FusedAdamW(torch.optim.Optimizer):
                 items.append((gi, p))
         if not items:
             return loss
-        key = tuple((gi, p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for gi, p in items)
+        # torch.optim.AdamW bias-corrects PER PARAMETER (its own step count).  Parameters of one group normally share a
+        # step count, but one that was frozen for a while, had no gradient on some steps or came from a checkpoint with
+        # mixed steps does not: every distinct (group, step) pair gets its own hyper-parameter slot.
+        slots = {}
+        for gi, p in items:
+            slots.setdefault((gi, int(self.state[p]["step"])), len(slots))
+        if len(slots) > L.ADAMW_MAX_GROUPS:
+            raise L.LnxError(f"FusedAdamW: {len(slots)} distinct (parameter group, step count) combinations, at most {L.ADAMW_MAX_GROUPS} are supported")
+        items = [(slots[(gi, int(self.state[p]["step"]))], p) for gi, p in items]
+        key = tuple((si, p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for si, p in items)
         if key != self._key:
             self._build(items)
             self._key = key
         h = L.AdamWHyper()
-        h.ngroups = len(self.param_groups)
-        steps = {}
-        for gi, p in items:
-            steps.setdefault(gi, float(self.state[p]["step"]))
-        for gi, group in enumerate(self.param_groups):
+        h.ngroups = len(slots)
+        for (gi, t), si in slots.items():
+            group = self.param_groups[gi]
             b1, b2 = group["betas"]
-            t = steps.get(gi, 1.0)
-            h.lr[gi], h.beta1[gi], h.beta2[gi], h.eps[gi], h.weight_decay[gi] = group["lr"], b1, b2, group["eps"], group["weight_decay"]
-            h.bias_c1[gi], h.bias_c2[gi] = 1.0 - b1 ** t, 1.0 - b2 ** t
-            h.omb1[gi], h.omb2[gi] = 1.0 - b1, 1.0 - b2
+            h.lr[si], h.beta1[si], h.beta2[si], h.eps[si], h.weight_decay[si] = group["lr"], b1, b2, group["eps"], group["weight_decay"]
+            h.bias_c1[si], h.bias_c2[si] = 1.0 - b1 ** float(t), 1.0 - b2 ** float(t)
+            h.omb1[si], h.omb2[si] = 1.0 - b1, 1.0 - b2
         table, n, blocks = self._table
         lib = L.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

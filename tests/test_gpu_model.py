@@ -303,3 +303,206 @@ def test_odd_batches_plan_reuse_and_eval(dtype, golden_dir):
             tot_err += (p_.grad.float().cpu() - ref).double().pow(2).sum().item()
             tot_ref += ref.double().pow(2).sum().item()
         assert (tot_err / tot_ref) ** 0.5 <= gtol, (B, (tot_err / tot_ref) ** 0.5)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Round-2 additions: the TIMED configuration's kernel dispatch under the oracle
+# ----------------------------------------------------------------------------------------------------
+def _drop_scales(spec, B, seed):
+    """Per-call, per-sample DropPath multipliers floor(keep + U)/keep (blocks/drop_path.py:29-33), None where p == 0."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for p_ in O.drop_call_probs(spec):
+        if p_ == 0.0:
+            out.append(None)
+        else:
+            keep = 1.0 - p_
+            out.append(torch.floor(keep + torch.rand(B, generator=g)) / keep)
+    return out
+
+
+def _grad_errors(model, osd):
+    tot_err = tot_ref = 0.0
+    worst = ("", 0.0)
+    for k, p_ in model.named_parameters():
+        parts = k.split(".")
+        ck = f"head.{parts[3]}.fc.{parts[4]}" if (parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers") else k
+        ref = osd[ck].grad
+        e = (p_.grad.float().cpu() - ref).double().pow(2).sum().item()
+        r = ref.double().pow(2).sum().item()
+        tot_err += e
+        tot_ref += r
+        rel = (e / max(r, 1e-30)) ** 0.5
+        if r > 1e-12 and rel > worst[1]:
+            worst = (k, rel)
+    return (tot_err / tot_ref) ** 0.5, worst
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sm_b24_production_dispatch_matches_oracle(dtype):
+    """mFormerV1_sm @224, B = 24 with DropPath multipliers injected: RoPE M = 4,776 / 1,248 >= 1024 and conv M = 75,264 / 18,816,
+    so the pipelined gemm_nt_v2/v4, gemm_tn_v2 + reduce, the resident C=96 / streamed C=192 fused conv-MLP kernels, the
+    fused weight-gradient kernels and the side stream all run INSIDE the plan exactly as in bench.py's B = 256 step
+    (same dispatch thresholds), against O.forward + probe_loss on the CPU.  Tolerances as stated at the top of this file."""
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)), drop_path_rate=0.2)
+    B = 24
+    sd = O.seeded_state_dict(O.param_shapes(spec), 777)
+    x, meta = O.seeded_inputs(spec, B, 224, 778)
+    drops = _drop_scales(spec, B, 779)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta, drops)
+    O.probe_loss(oout).backward()
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    out = run(model, x, meta, drops, train=True)
+    worst = 0.0
+    for t, _ in spec.heads:
+        ref = oout[t].detach()
+        got = out[t].float().cpu()
+        err = (got - ref).abs().max().item()
+        worst = max(worst, err)
+        scale = max(1.0, ref.abs().max().item())
+        if dtype == "fp32":
+            torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * scale, msg=t)
+            assert (got.argmax(-1) == ref.argmax(-1)).all(), t
+        else:
+            assert err <= 0.04 * scale, (t, err, scale)
+            srt = ref.sort(-1).values
+            safe = (srt[:, -1] - srt[:, -2]) > 4 * err
+            assert (got.argmax(-1)[safe] == ref.argmax(-1)[safe]).all(), t
+    O.probe_loss(out).backward()
+    glob, wk = _grad_errors(model, osd)
+    print(f"[sm B=24/{dtype}] max-abs logit error {worst:.5f}; global relative gradient error {glob:.2e}; worst tensor {wk[0]} {wk[1]:.2e}")
+    assert glob <= (1e-3 if dtype == "fp32" else 5e-2), (glob, wk)
+    if dtype == "fp32":
+        assert wk[1] <= 5e-3, wk
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config1_sm_b1_forward(dtype, golden_dir):
+    """BASELINE config 1, literally: mFormerV1_sm forward, batch = 1, 3x224x224 + 5-wide metadata through build_model()
+    (fixture-seeded weights, first sample of the sm fixture -> the reference's own logits are the expected values)."""
+    spec, z, sd, x, meta, _ = load_case("sm", golden_dir)
+    model = build("sm", spec, sd, dtype)
+    with torch.no_grad():
+        out = run(model, x[:1], meta[:1], None, train=False)
+    for task, _ in spec.heads:
+        ref = z["logits_" + task][:1]
+        got = out[task].float().cpu().numpy()
+        assert got.shape == ref.shape
+        if dtype == "fp32":
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=5e-5, err_msg=task)
+            assert (got.argmax(-1) == ref.argmax(-1)).all()
+        else:
+            assert np.abs(got - ref).max() <= 0.04 * max(1.0, np.abs(ref).max())
+
+
+def test_config4_lg384_hierarchical_heads_taxonomy_loss():
+    """BASELINE config 4 on one GPU: mFormerV1_lg @384, ConditionalClassifier heads on a 3-level taxonomy (SURVEY F3:
+    effective shared Linear per task) and linnaeus_amd.loss.TaxonomyAwareLabelSmoothingCE per task (soft-label matrices,
+    ignore_index 0, class weights), weighted sum of the per-task batch means -> backward.  Loss value, logits and
+    every parameter gradient against the CPU oracle (O.forward + O.soft_label_ce)."""
+    from linnaeus_amd.loss import TaxonomyAwareLabelSmoothingCE
+
+    heads = (("taxa_L10", 48), ("taxa_L20", 12), ("taxa_L30", 4))
+    spec = O.Spec(conv_dims=(192, 384, 768, 1536), rope_depths=(10, 2), rope_heads=(12, 24), meta=(("TEMPORAL", 2), ("SPATIAL", 3), ("ELEVATION", 10)),
+                  heads=heads)
+    B = 2
+    sd = O.seeded_state_dict(O.param_shapes(spec), 4321)
+    x, meta = O.seeded_inputs(spec, B, 384, 98)
+    g = torch.Generator().manual_seed(5)
+    soft, cw, tg, tw = {}, {}, {}, {"taxa_L10": 1.0, "taxa_L20": 0.5, "taxa_L30": 0.25}
+    for t, c in heads:
+        m = torch.rand(c, c, generator=g) * 0.1 + 0.9 * torch.eye(c)
+        soft[t] = m / m.sum(1, keepdim=True)
+        cw[t] = 0.5 + torch.rand(c, generator=g)
+        tg[t] = torch.randint(0, c, (B,), generator=g)  # index 0 = null, ignored
+    tg["taxa_L30"][0] = 0
+
+    def total(out, dev):
+        tot = 0.0
+        for t, _ in heads:
+            if dev == "cpu":
+                per = O.soft_label_ce(out[t], tg[t], soft[t], cw[t], 0)
+            else:
+                crit = TaxonomyAwareLabelSmoothingCE(soft[t], weight=cw[t], apply_class_weights=True, ignore_index=0).cuda()
+                per = crit(out[t], tg[t].cuda())
+            tot = tot + tw[t] * per.mean()
+        return tot
+
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta)
+    oloss = total(oout, "cpu")
+    oloss.backward()
+    tree = TinyTree({"taxa_L10": {i: i // 4 for i in range(48)}, "taxa_L20": {i: i // 3 for i in range(12)}}, [t for t, _ in heads], dict(heads))
+    model = build_model(make_config(spec, 384, "ConditionalClassifier"), num_classes=dict(heads), taxonomy_tree=tree)
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    for dtype, ltol, ftol, gtol in (("fp32", 2e-4, 2e-4, 2e-3), ("bf16", 3e-2, 0.1, 0.1)):
+        model.set_compute_dtype(dtype)
+        model.train()
+        model.zero_grad(set_to_none=True)
+        out = model(x.cuda(), meta.cuda())
+        for t, _ in heads:
+            ref = oout[t].detach()
+            err = (out[t].float().cpu() - ref).abs().max().item()
+            assert err <= ftol * max(1.0, ref.abs().max().item()), (dtype, t, err)
+        loss = total(out, "cuda")
+        assert abs(loss.item() - oloss.item()) <= ltol * max(1.0, abs(oloss.item())), (dtype, loss.item(), oloss.item())
+        loss.backward()
+        glob, wk = _grad_errors(model, osd)
+        print(f"[lg@384 hierarchical+taxonomic/{dtype}] loss {loss.item():.5f} vs {oloss.item():.5f}; global relative gradient error {glob:.2e}")
+        assert glob <= gtol, (dtype, glob, wk)
+
+
+def test_plan_cache_is_bounded_and_released():
+    """every distinct batch size used to pin another workspace forever.  The plan cache is an LRU of
+    `max_cached_plans`; evicted plans are destroyed and their workspaces freed; no_grad forwards use an inference plan
+    without backward scratch."""
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 3)
+    model = build("tiny_a", spec, sd, "bf16")
+    model.max_cached_plans = 2
+    model.eval()
+    torch.cuda.synchronize()
+    base = None
+    peak = 0
+    with torch.no_grad():
+        for B in (1, 2, 3, 4, 5, 6, 7, 8, 3, 9, 2):
+            x, meta = O.seeded_inputs(spec, B, 64, 50 + B)
+            model(x.cuda(), meta.cuda())
+            torch.cuda.synchronize()
+            assert len(model._plans) <= 2
+            if base is None:
+                base = torch.cuda.memory_allocated()
+            peak = max(peak, torch.cuda.memory_allocated())
+    # workspace grows ~linearly in B: bounded by (two largest plans) rather than the sum over all 9 sizes
+    assert peak - base < 20 * base + (64 << 20)
+    model.train()
+    x, meta = O.seeded_inputs(spec, 2, 64, 1)
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()  # a training plan after inference plans of the same shape
+    assert all(p_.grad is not None for p_ in model.parameters())
+    model.release_plans()
+    assert len(model._plans) == 0
+
+
+def test_switch_autograd_to_direct_grad_mode():
+    """after an autograd-mode step + zero_grad(set_to_none=False), direct mode must not accumulate onto a
+    stale arena."""
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 1)
+    model = build("tiny_a", spec, sd, "fp32")
+    x, meta = O.seeded_inputs(spec, 2, 64, 5)
+    model.train()
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()  # autograd mode: .grad are clones
+    want = {k: p_.grad.clone() for k, p_ in model.named_parameters()}
+    model.zero_grad(set_to_none=False)
+    model.grad_mode = "direct"
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()
+    for k, p_ in model.named_parameters():
+        torch.testing.assert_close(p_.grad, want[k], rtol=1e-4, atol=1e-6, msg=k)
+    O.probe_loss(model(x.cuda(), meta.cuda())).backward()  # now accumulates (grads alias the arena)
+    for k, p_ in model.named_parameters():
+        torch.testing.assert_close(p_.grad, 2 * want[k], rtol=1e-4, atol=1e-6, msg=k)

@@ -69,3 +69,26 @@ def test_fused_step_on_reference_train_fixture(golden_dir):
         d = (got[k].detach() - before[k]).double().norm().item()
         floor = 0.05 * float(z["lr"]) * int(z["steps"]) * got[k].numel() ** 0.5
         assert abs(d - z["delta_norms"][i]) <= 5e-2 * z["delta_norms"][i] + floor, (k, d, z["delta_norms"][i])
+
+
+def test_fused_adamw_per_parameter_step_counts():
+    """torch.optim.AdamW bias-corrects per parameter.  One parameter of a group skips a step (grad None),
+    so its step count lags the others': the fused optimizer must still match torch exactly."""
+    from linnaeus_amd.optim import FusedAdamW
+
+    g = torch.Generator().manual_seed(3)
+    pa = [torch.randn(257, generator=g).cuda().requires_grad_(True) for _ in range(3)]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa, ob = FusedAdamW(pa, lr=1e-2, weight_decay=0.01), torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01)
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 1 and step in (1, 2):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+    assert oa.state[pa[1]]["step"] == 3 and oa.state[pa[0]]["step"] == 5
