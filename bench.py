@@ -254,7 +254,7 @@ def main():
 
         lib = L.lib()
         st = model._active
-        NC = 8
+        NC = 9
         L.check(lib.lnx_plan_profile_begin(st["handle"]), "profile_begin")
         hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
         for _ in range(args.profile_steps):
@@ -266,7 +266,7 @@ def main():
         work = (C.c_double * NC)()
         cnt = (C.c_int * NC)()
         L.check(lib.lnx_plan_profile_end(st["handle"], ms, work, cnt), "profile_end")
-        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
+        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd", "convmlp_wgrad"]
         for i, nm in enumerate(names):
             if cnt[i] == 0:
                 continue

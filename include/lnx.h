@@ -371,13 +371,35 @@ typedef struct lnx_convmlp_bwd_args {
     const float* gamma;
     const float* rowscale;
     int rows_per_sample;
-    void* act;             /* out [M, 4C] bf16  GELU(h)   (operand of the pwconv2 weight gradient) */
-    void* dh;              /* out [M, 4C] bf16  dL/dh     (operand of the pwconv1 weight gradient) */
+    void* act;             /* out [M, 4C] bf16  GELU(h)   (operand of the pwconv2 weight gradient), or NULL with dh NULL: */
+    void* dh;              /* out [M, 4C] bf16  dL/dh     (operand of the pwconv1 weight gradient)   not materialised  */
     void* dz;              /* out [M, C]  bf16  rowscale*gamma*g */
     void* dln;             /* out [M, C]  bf16  gradient wrt the LayerNorm output */
     float* dgamma;         /* [C] += */
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
+
+/* Weight and bias gradients of the same branch WITHOUT materialising the 4C-wide hidden tensors (round 2):
+ *   dW1[4C,C] += dH^T . ln,  db1 += colsum(dH),  dW2[C,4C] += dz^T . act,  db2 += colsum(dz)
+ * act = GELU(ln . W1^T + b1) and dH = (dz . W2) * GELU'(.) are recomputed per 32-row tile on chip (autograd's weight
+ * gradients of pwconv1 / pwconv2, blocks/convnext.py:60-64).  With this entry lnx_convmlp_bwd is called with
+ * act = dh = NULL.  Row ranges are summed through `ws` in a fixed order (bit-reproducible; no float atomics). */
+typedef struct lnx_convmlp_wgrad_args {
+    int dtype, M, C;
+    const void* ln;   /* [M, C] bf16 */
+    const void* dz;   /* [M, C] bf16 (output of lnx_convmlp_bwd) */
+    const void* w1;   /* [4C, C] bf16 pwconv1.weight */
+    const void* w2t;  /* [4C, C] bf16 pwconv2.weight^T */
+    const float* b1;  /* [4C] */
+    float* dw1;       /* [4C, C] fp32, += */
+    float* db1;       /* [4C], += */
+    float* dw2;       /* [C, 4C] fp32 (torch layout), += */
+    float* db2;       /* [C], += */
+    float* ws;        /* workspace of lnx_convmlp_wgrad_ws_floats(C, M) floats */
+    int64_t ws_floats;
+} lnx_convmlp_wgrad_args;
+int64_t lnx_convmlp_wgrad_ws_floats(int C, int M);
+int lnx_convmlp_wgrad(const lnx_convmlp_wgrad_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Whole-model plan: mFormerV1 forward and backward as one native call each.
@@ -437,8 +459,9 @@ int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, in
  * roofline line; adds event records around the timed launches, so never leave it on in a timed
  * region).  Classes: 0 gemm_nt, 1 gemm_tn, 2 attention fwd, 3 attention bwd (both kernels),
  * 4 depthwise conv fwd / data-grad, 5 depthwise conv weight-grad, 6 fused conv-MLP forward,
- * 7 fused conv-MLP backward.  work = FLOPs for 0-3 and 6-7, algorithmic HBM bytes for 4-5. */
-#define LNX_PROFILE_CLASSES 8
+ * 7 fused conv-MLP backward (data side), 8 fused conv-MLP weight gradients.  work = FLOPs for 0-3 and 6-8,
+ * algorithmic HBM bytes for 4-5. */
+#define LNX_PROFILE_CLASSES 9 /* class 8: fused conv-MLP weight gradients (lnx_convmlp_wgrad), work = FLOPs */
 int lnx_plan_profile_begin(lnx_plan* p);
 int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
 /* indices of the parameters whose gradient is final after `segment`; returns their count */

@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
 // ------------------------------------------------------------------------------------
 // backward (data side): act, dH, dz, dln, dgamma
 // ------------------------------------------------------------------------------------
-template <int NK, int MT, int NW>
+// ST: also store act = GELU(h) and dH ([M, 4C] each) for separate weight-gradient GEMMs (round-1 path, kept for A/B);
+// the plan now calls with ST = false and lnx_convmlp_wgrad recomputes them on chip.
+template <int NK, int MT, int NW, bool ST>
 __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             pd[mt][1] = pack8(da[2][mt], da[3][mt]);
             // packed element j of k-step ks2 <-> hidden n = 64 j_chunk + 32 ks2 + 8 g + j : 16 contiguous bytes per row
             const int m = m_base + mt * 16 + s;
-            if (m < p.M) {
+            if (ST && m < p.M) {
                 const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
                 st16(p.act + off, pa[mt][0]);
                 st16(p.act + off + 64, pa[mt][1]);
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     }
 }
 
-template <int NK, int MT>
+template <int NK, int MT, bool ST>
 __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 pd[mt][0] = pack8(da[0][mt], da[1][mt]);
                 pd[mt][1] = pack8(da[2][mt], da[3][mt]);
                 const int m = m_base + mt * 16 + s;
-                if (m < p.M) {
+                if (ST && m < p.M) {
                     const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
                     st16(p.act + off, pa0);
                     st16(p.act + off + 64, pa1);
@@ -838,18 +840,22 @@ int launch_fwd_res(const CmP& p, hipStream_t st) {
     hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
     return 0;
 }
-template <int NK, int MT>
-int launch_bwd_res(const CmP& p, hipStream_t st) {
+template <int NK, int MT, bool ST>
+int launch_bwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int grid = cdiv(cdiv(p.M, 16 * MT), 8);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST>), dim3(grid), dim3(512), lds, st, p);
     return 0;
+}
+template <int NK, int MT>
+int launch_bwd_res(const CmP& p, hipStream_t st) {
+    return p.act ? launch_bwd_res_t<NK, MT, true>(p, st) : launch_bwd_res_t<NK, MT, false>(p, st);
 }
 
 template <int NK, int MT, int NW>
@@ -864,16 +870,20 @@ int launch_fwd(const CmP& p, hipStream_t st) {
     return 0;
 }
 
-template <int NK, int MT, int NW>
-int launch_bwd(const CmP& p, hipStream_t st) {
+template <int NK, int MT, int NW, bool ST>
+int launch_bwd_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * 3 * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
     return 0;
+}
+template <int NK, int MT, int NW>
+int launch_bwd(const CmP& p, hipStream_t st) {
+    return p.act ? launch_bwd_t<NK, MT, NW, true>(p, st) : launch_bwd_t<NK, MT, NW, false>(p, st);
 }
 
 // waves per workgroup of the streamed-weight kernels: 8 (two per SIMD share one weight stream) unless LNX_CM_NW=4
@@ -905,8 +915,9 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
 }
 
 extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
-    LNX_CHECK(a && a->g && a->ln && a->z && a->w1 && a->w2t && a->w1t && a->b1 && a->gamma && a->act && a->dh && a->dz && a->dln && a->dgamma,
+    LNX_CHECK(a && a->g && a->ln && a->z && a->w1 && a->w2t && a->w1t && a->b1 && a->gamma && a->dz && a->dln && a->dgamma,
               "lnx_convmlp_bwd: null operand");
+    LNX_CHECK((a->act == nullptr) == (a->dh == nullptr), "lnx_convmlp_bwd: act and dh must both be given or both be NULL");
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_bwd: unsupported dtype %d / C %d", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_bwd: empty");
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_convmlp_bwd: rowscale needs rows_per_sample");
