@@ -379,7 +379,9 @@ typedef struct lnx_convmlp_bwd_args {
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
 
-/* Weight and bias gradients of the same branch WITHOUT materialising the 4C-wide hidden tensors (round 2):
+/* Weight and bias gradients of the same branch WITHOUT materialising the 4C-wide hidden tensors (round 2; the plan
+ * uses it only under LNX_CONVMLP_FUSED_WGRAD=1: it removes 16 B/element of HBM traffic but the GELU recompute makes it
+ * VALU-bound and slower than the two weight-gradient GEMMs on MI355X):
  *   dW1[4C,C] += dH^T . ln,  db1 += colsum(dH),  dW2[C,4C] += dz^T . act,  db2 += colsum(dz)
  * act = GELU(ln . W1^T + b1) and dH = (dz . W2) * GELU'(.) are recomputed per 32-row tile on chip (autograd's weight
  * gradients of pwconv1 / pwconv2, blocks/convnext.py:60-64).  With this entry lnx_convmlp_bwd is called with

@@ -150,6 +150,91 @@ __device__ __forceinline__ void gelu_lean_grad2(f32x2_t v, f32x2_t& act, f32x2_t
     act = v * cdf;
     dgelu = (v * splat2(0.39894228040143267794f)) * e + cdf;
 }
+// ---- N chains in lockstep ------------------------------------------------------------------------------------------
+// hipcc emits each Horner chain of the forms above back to back, with an s_nop between every dependent v_pk_fma_f32
+// (packed-fp32 result hazard): 11 serial packed ops per element pair, the VALU idling on its own latency.  The _n forms
+// advance N independent pairs one polynomial step at a time, so in-order issue always has N-1 independent packed
+// operations between two dependent ones.  Same arithmetic per element, bit-identical results.
+template <int N>
+__device__ __forceinline__ void erf_sqrt2_poly2_n(const f32x2_t (&x)[N], f32x2_t (&r)[N]) {
+    constexpr float K[9] = {1.1254853916e-10f, -1.0744679894e-08f, 4.5368678889e-07f, -1.1292854487e-05f, 1.8718494423e-04f,
+                            -2.2188186466e-03f, 1.9636284401e-02f, -1.3269389935e-01f, 7.9780627149e-01f};
+    f32x2_t xc[N], t[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        xc[i].x = __builtin_amdgcn_fmed3f(x[i].x, -4.2426405f, 4.2426405f);
+        xc[i].y = __builtin_amdgcn_fmed3f(x[i].y, -4.2426405f, 4.2426405f);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = xc[i] * xc[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = splat2(K[0]) * t[i] + splat2(K[1]);
+#pragma unroll
+    for (int k = 2; k < 9; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = p[i] * t[i] + splat2(K[k]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = p[i] * xc[i];
+}
+template <int N>
+__device__ __forceinline__ void gelu_lean2_n(const f32x2_t (&v)[N], f32x2_t (&act)[N]) {
+    f32x2_t e[N];
+    erf_sqrt2_poly2_n<N>(v, e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const f32x2_t hv = v[i] * splat2(0.5f);
+        act[i] = hv * e[i] + hv;
+    }
+}
+template <int N>
+__device__ __forceinline__ void gelu_lean_grad2_n(const f32x2_t (&v)[N], f32x2_t (&act)[N], f32x2_t (&dgelu)[N]) {
+    constexpr float K = 0.84932180028801904272f;  // sqrt(log2(e) / 2)
+    f32x2_t e[N], ex[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const f32x2_t u = v[i] * splat2(K);
+        const f32x2_t nuu = -(u * u);
+        ex[i].x = __builtin_amdgcn_exp2f(nuu.x);  // transcendental issued first: its latency runs under the polynomial
+        ex[i].y = __builtin_amdgcn_exp2f(nuu.y);
+    }
+    erf_sqrt2_poly2_n<N>(v, e);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const f32x2_t cdf = e[i] * splat2(0.5f) + splat2(0.5f);
+        act[i] = v[i] * cdf;
+        dgelu[i] = (v[i] * splat2(0.39894228040143267794f)) * ex[i] + cdf;
+    }
+}
+// K accumulator vectors at once: h[k] = GELU(h[k] + b[k])
+template <int K>
+__device__ __forceinline__ void gelu4_bias_n(f32x4_t* h, const f32x4_t* b) {
+    f32x2_t v[2 * K], a[2 * K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[2 * k] = f32x2_t{h[k][0] + b[k][0], h[k][1] + b[k][1]};
+        v[2 * k + 1] = f32x2_t{h[k][2] + b[k][2], h[k][3] + b[k][3]};
+    }
+    gelu_lean2_n<2 * K>(v, a);
+#pragma unroll
+    for (int k = 0; k < K; ++k) h[k] = f32x4_t{a[2 * k].x, a[2 * k].y, a[2 * k + 1].x, a[2 * k + 1].y};
+}
+// h[k] = GELU(h[k] + b[k]),  da[k] *= GELU'(h[k] + b[k])
+template <int K>
+__device__ __forceinline__ void gelu4_bias_grad_n(f32x4_t* h, const f32x4_t* b, f32x4_t* da) {
+    f32x2_t v[2 * K], a[2 * K], d[2 * K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        v[2 * k] = f32x2_t{h[k][0] + b[k][0], h[k][1] + b[k][1]};
+        v[2 * k + 1] = f32x2_t{h[k][2] + b[k][2], h[k][3] + b[k][3]};
+    }
+    gelu_lean_grad2_n<2 * K>(v, a, d);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        h[k] = f32x4_t{a[2 * k].x, a[2 * k].y, a[2 * k + 1].x, a[2 * k + 1].y};
+        da[k] = f32x4_t{da[k][0] * d[2 * k].x, da[k][1] * d[2 * k].y, da[k][2] * d[2 * k + 1].x, da[k][3] * d[2 * k + 1].y};
+    }
+}
+
 // in-place helpers on the 4-element accumulator vectors of the MFMA kernels: h = GELU(h + b) / (act, da *= GELU'(h + b))
 __device__ __forceinline__ void gelu4_bias(f32x4_t& h, const f32x4_t& b) {
     const f32x2_t lo = gelu_lean2(f32x2_t{h[0] + b[0], h[1] + b[1]}), hi = gelu_lean2(f32x2_t{h[2] + b[2], h[3] + b[3]});
@@ -179,19 +264,30 @@ template <typename T> struct Gelu {
 template <> struct Gelu<bf16_t> {
     static __device__ __forceinline__ void fwd16(float (&v)[16]) {
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const f32x2_t r = gelu_lean2(f32x2_t{v[j], v[j + 1]});
-            v[j] = r.x;
-            v[j + 1] = r.y;
+        for (int g = 0; g < 16; g += 8) {  // four pairs in lockstep
+            f32x2_t x[4], a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = f32x2_t{v[g + 2 * i], v[g + 2 * i + 1]};
+            gelu_lean2_n<4>(x, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[g + 2 * i] = a[i].x;
+                v[g + 2 * i + 1] = a[i].y;
+            }
         }
     }
     static __device__ __forceinline__ void mulgrad16(float (&v)[16], const float (&x)[16]) {
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            f32x2_t a, d;
-            gelu_lean_grad2(f32x2_t{x[j], x[j + 1]}, a, d);
-            v[j] *= d.x;
-            v[j + 1] *= d.y;
+        for (int g = 0; g < 16; g += 8) {
+            f32x2_t xx[4], a[4], d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xx[i] = f32x2_t{x[g + 2 * i], x[g + 2 * i + 1]};
+            gelu_lean_grad2_n<4>(xx, a, d);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[g + 2 * i] *= d[i].x;
+                v[g + 2 * i + 1] *= d[i].y;
+            }
         }
     }
     static __device__ __forceinline__ float fwd(float x) { return gelu_lean(x); }

@@ -304,10 +304,14 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    gelu4_bias(h[nt][mt], bv[nt]);
+                for (int n2 = 0; n2 < 4; n2 += 2) {  // four element pairs in lockstep (common.hpp "_n" forms)
+                    f32x4_t hv[2] = {h[n2][mt], h[n2 + 1][mt]};
+                    gelu4_bias_n<2>(hv, &bv[n2]);
+                    h[n2][mt] = hv[0];
+                    h[n2 + 1][mt] = hv[1];
+                }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 pf[mt][0] = pack8(h[0][mt], h[1][mt]);
@@ -459,10 +463,16 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                gelu4_bias_grad(h[nt][mt], bv[nt], da[nt][mt]);  // h = act = GELU(h + b), dH = dA * GELU'(h + b)
+            for (int n2 = 0; n2 < 4; n2 += 2) {  // h = act = GELU(h + b), dH = dA * GELU'(h + b); four element pairs in lockstep
+                f32x4_t hv[2] = {h[n2][mt], h[n2 + 1][mt]}, dv[2] = {da[n2][mt], da[n2 + 1][mt]};
+                gelu4_bias_grad_n<2>(hv, &bv[n2], dv);
+                h[n2][mt] = hv[0];
+                h[n2 + 1][mt] = hv[1];
+                da[n2][mt] = dv[0];
+                da[n2 + 1][mt] = dv[1];
+            }
         uint4 pa[MT][2], pd[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -641,11 +651,20 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             CM_DS_READ128(bv[3], ba, 144);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // element pairs in lockstep (common.hpp "_n" forms): four at a time, two at C = 96 where the two-tile accumulators
+            // leave no room for more temporaries (four spilled)
+            constexpr int GK = NK == 3 ? 1 : 2;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    gelu4_bias(h[nt][mt], bv[nt]);
+                for (int n2 = 0; n2 < 4; n2 += GK) {
+                    f32x4_t hv[GK];
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) hv[k] = h[n2 + k][mt];
+                    gelu4_bias_n<GK>(hv, &bv[n2]);
+#pragma unroll
+                    for (int k = 0; k < GK; ++k) h[n2 + k][mt] = hv[k];
+                }
             uint4 pf[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -776,10 +795,16 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    gelu4_bias_grad(h[nt][mt], bv[nt], da[nt][mt]);
+                for (int n2 = 0; n2 < 4; n2 += 2) {  // four element pairs in lockstep
+                    f32x4_t hv[2] = {h[n2][mt], h[n2 + 1][mt]}, dv[2] = {da[n2][mt], da[n2 + 1][mt]};
+                    gelu4_bias_grad_n<2>(hv, &bv[n2], dv);
+                    h[n2][mt] = hv[0];
+                    h[n2 + 1][mt] = hv[1];
+                    da[n2][mt] = dv[0];
+                    da[n2 + 1][mt] = dv[1];
+                }
             uint4 pd[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

@@ -605,9 +605,11 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_lnws = cv.take(p->lnws_floats * 4);
         p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
         p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
-        // fused conv-MLP blocks recompute act / dH inside lnx_convmlp_wgrad: no [M, 4C] scratch pair for them
-        // (LNX_CONVMLP_STORE_HIDDEN=1 restores round 1's materialise + two weight-gradient GEMMs for A/B runs)
-        const bool store_hidden = getenv("LNX_CONVMLP_STORE_HIDDEN") != nullptr;
+        // Fused conv-MLP blocks: the backward materialises act / dH ([M, 4C] each) for two weight-gradient GEMMs.
+        // LNX_CONVMLP_FUSED_WGRAD=1 switches to lnx_convmlp_wgrad, which recomputes them on chip instead (11 GB/step
+        // less HBM traffic and 1.2 GB less workspace at sm / B = 256) -- measured SLOWER on MI355X (the GELU recompute
+        // makes it VALU-bound: 530 vs 317 us per block at C = 96), so it is opt-in.
+        const bool store_hidden = getenv("LNX_CONVMLP_FUSED_WGRAD") == nullptr;
         p->o_sA = cv.take(maxM4C * esz);
         if (any_fused && store_hidden) p->o_sB = cv.take(maxM4C * esz);
         if (any_fused && !store_hidden) {
