@@ -157,6 +157,14 @@ typedef struct lnx_ln_bwd_args {
     int relu_mask;      /* 1: x is a ReLU output feeding this LN; dx *= (x > 0) */
     float* ws;          /* optional scratch for the dw/db column partials (avoids contended atomics) */
     int64_t ws_floats;  /* its capacity in floats; 2048*2*C is the most that is used */
+    /* optional second output: dx2[m, :] = dx2_rowscale[m / dx2_rows_per_sample] * dx[m, :] in dx2_dtype, identity rows,
+     * leading dimension lddx2.  It is the operand the NEXT branch's GEMMs read (DropPath-scaled gradient in storage
+     * type, rope_2d_mhsa.py:630,643 backward), so no separate cast pass re-reads dx.  May alias dy (same dtype/ld). */
+    void* dx2;
+    int dx2_dtype;
+    int64_t lddx2;
+    const float* dx2_rowscale;
+    int dx2_rows_per_sample;
 } lnx_ln_bwd_args;
 int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
 

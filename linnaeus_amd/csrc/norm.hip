@@ -169,6 +169,10 @@ struct LnBwdP {
     int M, C;
     int relu_mask;
     float* part;      // optional workspace [gridDim.x][2][C]: per-workgroup column partials (no atomics)
+    void* dx2;        // optional second output: rs2[m / rps2] * dx, identity rows, ld = lddx2, bf16 or fp32
+    const float* rs2;
+    int64_t lddx2;
+    int rps2, dx2_f32;
 };
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd
@@ -262,6 +266,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
                 }
                 if constexpr (PAIR == 2) store4x2<TDX>(ox + 4 * c4, ov[0], ov[1]);
                 else store4<TDX>(ox + 4 * c4, ov[0]);
+                if (p.dx2) {  // DropPath-scaled copy in storage type for the next branch's GEMMs (wave-uniform branch)
+                    const float sc = p.rs2 ? p.rs2[m / p.rps2] : 1.0f;
+#pragma unroll
+                    for (int q = 0; q < PAIR; ++q) ov[q] = make_float4(ov[q].x * sc, ov[q].y * sc, ov[q].z * sc, ov[q].w * sc);
+                    if (p.dx2_f32) {
+                        float* o2 = reinterpret_cast<float*>(p.dx2) + (int64_t)m * p.lddx2 + 4 * c4;
+#pragma unroll
+                        for (int q = 0; q < PAIR; ++q) store4<float>(o2 + 4 * q, ov[q]);
+                    } else {
+                        bf16_t* o2 = reinterpret_cast<bf16_t*>(p.dx2) + (int64_t)m * p.lddx2 + 4 * c4;
+                        if constexpr (PAIR == 2) store4x2<bf16_t>(o2, ov[0], ov[1]);
+                        else store4<bf16_t>(o2, ov[0]);
+                    }
+                }
             }
         }
     }
@@ -464,6 +482,13 @@ extern "C" int lnx_layernorm_bwd(const lnx_ln_bwd_args* a, void* stream) {
     p.dymap = RowMap{a->dy_map.group, a->dy_map.pad, a->dy_map.off};
     p.xmap = RowMap{a->x_map.group, a->x_map.pad, a->x_map.off};
     p.M = a->M; p.C = a->C; p.relu_mask = a->relu_mask;
+    p.dx2 = a->dx2; p.rs2 = a->dx2_rowscale; p.lddx2 = a->lddx2; p.rps2 = a->dx2_rows_per_sample > 0 ? a->dx2_rows_per_sample : 1;
+    p.dx2_f32 = a->dx2_dtype == LNX_F32 ? 1 : 0;
+    if (a->dx2) {
+        LNX_CHECK(a->lddx2 % 4 == 0 && (a->dx2_dtype == LNX_F32 || a->dx2_dtype == LNX_BF16), "lnx_layernorm_bwd: bad dx2 layout");
+        LNX_CHECK(a->dx2_dtype == LNX_F32 || ((uintptr_t)a->dx2 % 16 == 0 && (a->lddx2 * 2) % 16 == 0), "lnx_layernorm_bwd: dx2 must be 16-byte aligned");
+        if (a->dx2_rowscale) LNX_CHECK(a->dx2_rows_per_sample > 0, "lnx_layernorm_bwd: dx2_rowscale needs dx2_rows_per_sample");
+    }
     p.part = a->ws;
     const int64_t wsf = a->ws ? a->ws_floats : 0;
     hipStream_t st = (hipStream_t)stream;

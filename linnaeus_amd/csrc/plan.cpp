@@ -833,10 +833,17 @@ int ln_fwd(const Ctx& c, int M, int C, float eps, const void* x, int xdt, int64_
     return lnx_layernorm_fwd(&a, c.st);
 }
 
+// dx2 (optional): DropPath-scaled copy of dx in storage type = the dY operand of the next branch's GEMMs
+struct Dx2 {
+    void* p = nullptr;
+    const float* rowscale = nullptr;
+    int rps = 0;
+};
 int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, lnx_rowmap dym, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi,
-           int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu) {
+           int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu, Dx2 d2 = Dx2()) {
     lnx_ln_bwd_args a;
     memset(&a, 0, sizeof a);
+    a.dx2 = d2.p; a.dx2_dtype = c.dt; a.lddx2 = C; a.dx2_rowscale = d2.rowscale; a.dx2_rows_per_sample = d2.rps;
     a.M = M; a.C = C;
     a.dy = dy; a.dy_dtype = dydt; a.lddy = lddy; a.dy_map = dym;
     a.x = x; a.x_dtype = xdt; a.ldx = ldx; a.x_map = xm;
@@ -1117,7 +1124,9 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
 // ------------------------------------------------------------------------------------
 namespace {
 
-int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
+// have_dy: the caller's last LayerNorm backward already left this block's MLP-branch dY (DropPath-scaled g in storage
+// type) in sC; on return sC holds the same for block i-1 (written by this block's norm1 backward), if there is one
+int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     lnx_plan* p = c.p;
     RopeBlk& k = p->rope[s][i];
     const int B = p->c.batch, C = p->c.dims[2 + s], heads = p->c.rope_heads[s], hid = p->c.mlp_hidden[s];
@@ -1126,7 +1135,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
     // ---- MLP branch ----
-    RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
+    if (!have_dy) RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
     RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = hid;
@@ -1134,9 +1143,11 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
     RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C));
     a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
     RUN(gemm_nt_t(c, &a));
-    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false));
+    // norm2 backward adds into g and, in the same pass, writes the attention branch's dY (DropPath-scaled g in storage type)
+    Dx2 d2;
+    d2.p = sC; d2.rowscale = p->drop_ptr(p->drop_attn[s][i]); d2.rps = N;
+    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
-    RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_attn[s][i]), N, sC, c.dt, C, M, C, c.st));
     RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
     RUN(gemm_nt_t(c, &a));
@@ -1153,7 +1164,13 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g) {
     RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C));
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
     RUN(gemm_nt_t(c, &a));
-    RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false));
+    // norm1 backward: g is final for this block; block i-1's MLP-branch dY goes into sC in place of this LN's dy (row-wise
+    // in-place is safe: a row's dy is consumed before its statistics are known, its dx2 written after)
+    Dx2 d1;
+    if (i > 0) {
+        d1.p = sC; d1.rowscale = p->drop_ptr(p->drop_mlp[s][i - 1]); d1.rps = N;
+    }
+    RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false, d1));
     return 0;
 }
 
@@ -1355,7 +1372,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         const lnx_rowmap clsrow = {1, p->N3 - 1, 0};
         RUN(ln_bwd(c, B, C, dc2n, LNX_F32, C, IDM, c.at<float>(p->o_stage_out[3]), LNX_F32, C, clsrow, p->norm_w[1], p->norm_b[1], c.at<float>(p->o_n2_mean),
                    c.at<float>(p->o_n2_rstd), nullptr, g3, LNX_F32, C, false));
-        for (int i = cf.rope_depths[1] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 1, i, g3));
+        for (int i = cf.rope_depths[1] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 1, i, g3, i != cf.rope_depths[1] - 1));
         RUN(tokens_bwd(c, 1, g3));
         // downsample 3 backward into d(norm_1 output); meta/CLS rows of dt1 start at zero
         const int C2 = D[2];
@@ -1379,22 +1396,29 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
             RUN(gemm_nt_t(c, &a));
         }
         float* g2 = c.at<float>(p->o_g[2]);
+        // norm_1 backward also leaves the last stage-3 block's MLP-branch dY in sC (consumed first thing in segment 1)
+        Dx2 dn;
+        dn.p = c.at<void>(p->o_sC); dn.rowscale = p->drop_ptr(p->drop_mlp[0][cf.rope_depths[0] - 1]); dn.rps = p->N2;
         RUN(ln_bwd(c, B * p->N2, C2, dt1, cf.dtype, C2, IDM, c.at<float>(p->o_stage_out[2]), LNX_F32, C2, IDM, p->norm_w[0], p->norm_b[0], c.at<float>(p->o_t1_mean),
-                   c.at<float>(p->o_t1_rstd), nullptr, g2, LNX_F32, C2, false));
-        RUN(join_side(c, 1));
+                   c.at<float>(p->o_t1_rstd), nullptr, g2, LNX_F32, C2, false, dn));
+        // the stage-4 metadata-head backward (side stream, ~10 small fp32 GEMMs) is joined at the END OF SEGMENT 1: it only
+        // produces parameter gradients, and joining here exposed most of its ~0.7 ms behind the three downsample kernels
+        if (!all) RUN(join_side(c, 1));  // segment-wise callers may stop after any segment: keep every segment self-contained
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);
-        for (int i = cf.rope_depths[0] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 0, i, g2));
+        for (int i = cf.rope_depths[0] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 0, i, g2, true));
         RUN(tokens_bwd(c, 0, g2));
         const lnx_rowmap gm = {p->HW[2], p->E, p->E};
         RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
-        RUN(join_side(c, 0));
+        if (all) RUN(join_side(c, 1));
+        else RUN(join_side(c, 0));
     }
     if (all || segment == 2) {
         float* g1 = c.at<float>(p->o_g[1]);
         for (int i = cf.conv_depths[1] - 1; i >= 0; --i) RUN(conv_block_bwd(c, 1, i, g1));
         RUN(downsample_bwd(c, 0, g1, D[1], IDM, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, c.at<float>(p->o_g[0]), LNX_F32, D[0]));
+        if (all) RUN(join_side(c, 0));  // stage-3 metadata heads: hidden behind the whole ConvNeXt stage-2 backward
     }
     if (all || segment == 3) {
         float* g0 = c.at<float>(p->o_g[0]);
