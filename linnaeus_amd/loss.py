@@ -151,3 +151,207 @@ def multitask_cross_entropy(outputs: Dict[str, torch.Tensor], targets: Dict[str,
     ws = [1.0 if task_weights is None else float(task_weights[t]) for t in tasks]
     tg = [targets[t].to(outputs[t].device, torch.long).contiguous() for t in tasks]
     return _MultiCE.apply(ws, tg, float(label_smoothing), *[outputs[t] for t in tasks])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The whole loss path of the train step on device (SURVEY 8f-1, remainder): weighted_hierarchical_loss with null
+# masking, class weighting and static task weighting, plus the taxonomy smoothing-matrix builder.
+#   build_taxonomy_smoothing_matrix <- loss/taxonomy_label_smoothing.py:30-130
+#   compute_core_loss               <- loss/core_loss.py:19-100
+#   apply_null_masking / apply_class_weighting / apply_loss_masking <- loss/masking.py:19-465, 469-518, 521-700
+#   GradientWeighting (static mode) <- loss/gradient_weighting.py:178-365
+#   weighted_hierarchical_loss      <- loss/hierarchical_loss.py:24-406
+# The per-sample criterion runs in the HIP kernel (lnx_softce); everything after it is arithmetic on [B]-sized device
+# vectors.  What changes against the reference is HOW, not WHAT: its per-sample Python loops with .item() (a host sync
+# per sample, loss/masking.py:501-503, gradient_weighting.py:338-342) become one gather from a class-weight vector, and
+# the valid-sample counts stay on the device.  Finding F13 is reproduced, not fixed: class weights enter three times on
+# the scheduled-masking path, twice on the PHASE1 / validation paths, and the mean divides by count(loss != 0).
+# ----------------------------------------------------------------------------------------------------------------------
+def build_taxonomy_smoothing_matrix(num_classes: int, distances: torch.Tensor, alpha: float = 0.1, beta: float = 1.0,
+                                    uniform_roots: bool = True, root_class_ids=None) -> torch.Tensor:
+    """[C, C] soft-label matrix: row i = (1 - alpha) on the diagonal, alpha spread over the other classes in proportion
+    to exp(-beta * distance) (uniformly for root classes, and for rows whose neighbours are all disconnected)."""
+    if not (0.0 <= alpha <= 1.0):
+        raise ValueError(f"alpha must be in [0, 1], got {alpha}")
+    if beta < 0:
+        raise ValueError(f"beta must be non-negative, got {beta}")
+    if num_classes <= 0:
+        raise ValueError("num_classes must be positive.")
+    if distances.shape != (num_classes, num_classes):
+        raise ValueError(f"distances must be shape ({num_classes},{num_classes}), got {distances.shape}")
+    C_ = num_classes
+    d = distances.float()
+    w = torch.exp(-beta * d)
+    w = torch.where(torch.isinf(d), torch.zeros_like(w), w)
+    eye = torch.eye(C_, dtype=torch.bool, device=d.device)
+    w = w.masked_fill(eye, 0.0)
+    if uniform_roots and root_class_ids and C_ > 1:
+        roots = torch.as_tensor(list(root_class_ids), dtype=torch.long, device=d.device)
+        w[roots] = torch.full((C_,), 1.0 / (C_ - 1), device=d.device)
+        w = w.masked_fill(eye, 0.0)
+    elif uniform_roots and root_class_ids and C_ == 1:
+        w.zero_()
+    rs = w.sum(1, keepdim=True)
+    if C_ > 1:
+        fallback = torch.full((C_, C_), alpha / (C_ - 1), device=d.device).masked_fill(eye, 0.0)
+        probs = torch.where(rs > 1e-9, w * (alpha / rs.clamp_min(1e-30)), fallback)
+    else:
+        probs = torch.zeros_like(w)
+    probs = probs.masked_fill(eye, 1.0 - alpha)
+    tot = probs.sum(1, keepdim=True)
+    return torch.where((tot - 1.0).abs() > 1e-6, probs / tot, probs)
+
+
+def _is_null(target: torch.Tensor) -> torch.Tensor:
+    return target == 0 if target.dim() == 1 else target[:, 0] > 0.5
+
+
+def _sorted_tasks(d):
+    return sorted(d.keys(), key=lambda k: int(k.split("_L")[-1]))
+
+
+def compute_core_loss(outputs, targets, criteria, config=None):
+    """{task: per-sample loss [B]} in rank order; each criterion returns a [B] vector."""
+    return {t: criteria[t](outputs[t], targets[t]) for t in _sorted_tasks(outputs)}
+
+
+def _class_weight_vector(cw_dict, num_classes: int, device) -> torch.Tensor:
+    v = torch.ones(num_classes, dtype=torch.float32)
+    for i, w in cw_dict.items():
+        if 0 <= int(i) < num_classes:
+            v[int(i)] = float(w)
+    return v.to(device)
+
+
+def _sample_weights(cw_dict, target: torch.Tensor, cache: Optional[dict] = None, key=None) -> torch.Tensor:
+    """per-sample class weight: cw[label] for hard labels, <soft target, cw> for [B, C] targets; missing classes weigh 1"""
+    if target.dim() == 1:
+        n = max(int(max(cw_dict.keys(), default=0)) + 1, 1)
+        ck = (key, n, str(target.device))
+        vec = cache.get(ck) if cache is not None else None
+        if vec is None:
+            vec = _class_weight_vector(cw_dict, n, target.device)
+            if cache is not None:
+                cache[ck] = vec
+        idx = target.clamp(0, n - 1)
+        return torch.where(target < n, vec[idx], torch.ones((), device=target.device))
+    vec = _class_weight_vector(cw_dict, target.size(1), target.device)
+    return (target.float() * vec.unsqueeze(0)).sum(1)
+
+
+def apply_class_weighting(per_task_losses, targets, class_weights=None, _cache=None):
+    if class_weights is None:
+        return per_task_losses
+    out = {}
+    for t, vec in per_task_losses.items():
+        out[t] = vec * _sample_weights(class_weights[t], targets[t], _cache, t).to(vec.dtype) if t in class_weights else vec
+    return out
+
+
+def apply_null_masking(per_task_losses, targets, null_mask_prob: float, logger=None, config=None, _coin=None):
+    """Zero the loss of null-labelled samples (label 0) except for a random `null_mask_prob` fraction of them.
+    Statistics are device scalars (the reference calls .item() on each).  `_coin`: {task: [B] uniform draws} for tests."""
+    masked, stats = {}, {"null_mask_prob": null_mask_prob}
+    tot = inc = None
+    for t, vec in per_task_losses.items():
+        null = _is_null(targets[t])
+        if null_mask_prob < 1.0:
+            u = _coin[t].to(vec.device) if _coin is not None else torch.rand(vec.shape[0], device=vec.device)
+            keep = (~null) | (u < null_mask_prob)
+        else:
+            keep = torch.ones_like(null)
+        masked[t] = torch.where(keep, vec, torch.zeros((), dtype=vec.dtype, device=vec.device))
+        n, k = null.sum(), (null & keep).sum()
+        tot, inc = (n, k) if tot is None else (tot + n, inc + k)
+    stats["null_samples_total"], stats["null_samples_included"] = tot, inc
+    stats["inclusion_percentage"] = inc.float() * 100.0 / tot.float().clamp_min(1.0) if tot is not None else 0.0
+    return masked, stats
+
+
+def apply_loss_masking(per_task_losses, targets, ops_schedule, current_step, class_weights=None, is_validation=False, logger=None, config=None,
+                       _coin=None, _cache=None):
+    if is_validation:
+        prob = 1.0
+    elif config is not None and getattr(config.TRAIN, "PHASE1_MASK_NULL_LOSS", False):
+        prob = 0.0
+    else:
+        prob = float(ops_schedule.get_null_mask_prob(current_step))
+    masked, stats = apply_null_masking(per_task_losses, targets, prob, logger, config, _coin)
+    stats["num_valid_samples_per_task"] = {t: (v != 0).sum() for t, v in masked.items()}  # device scalars
+    if class_weights is not None:
+        return apply_class_weighting(masked, targets, class_weights, _cache), stats
+    return masked, stats
+
+
+class GradientWeighting(nn.Module):
+    """Task weighting of the multi-task loss, static mode (the reference's default for fixed weights).  GradNorm (a
+    second backward through the backbone per task) is outside the hot path and not provided."""
+
+    def __init__(self, task_keys, config=None, task_weighting_type: str = "static", init_weights=None, class_weights=None,
+                 use_subset_weights: bool = False, **kwargs):
+        super().__init__()
+        if task_weighting_type != "static":
+            raise NotImplementedError("linnaeus_amd.loss.GradientWeighting implements static task weights; GradNorm is out of scope")
+        self.task_keys = list(task_keys)
+        self.config = config
+        self.task_weighting_type = task_weighting_type
+        if isinstance(init_weights, dict):
+            init_weights = [init_weights.get(k, 1.0) for k in self.task_keys]
+        self.task_weights = torch.tensor(init_weights or [1.0] * len(self.task_keys), dtype=torch.float32)
+        self.gradnorm = None
+        self.class_weights = class_weights
+        self.use_subset_weights = use_subset_weights
+        self._cache: dict = {}
+
+    def _normalize_weights(self, w):
+        return w
+
+    def forward(self, per_task_losses, targets, subset_ids=None, mixed_subset_ids=None, num_valid_samples_per_task=None):
+        first = next(iter(per_task_losses.values()))
+        norm_w = self._normalize_weights(self.task_weights)
+        weighted = {}
+        for i, t in enumerate(self.task_keys):
+            vec = per_task_losses[t]
+            nv = vec.shape[0]
+            if num_valid_samples_per_task is not None:
+                nv = num_valid_samples_per_task.get(t, vec.shape[0])
+            if self.class_weights and t in self.class_weights:
+                vec = vec * _sample_weights(self.class_weights[t], targets[t], self._cache, t).to(vec.dtype)
+            denom = nv.to(vec.dtype).clamp_min(1e-6) if isinstance(nv, torch.Tensor) else max(float(nv), 1e-6)
+            weighted[t] = vec.sum() / denom * float(norm_w[i])
+        return weighted, dict(zip(self.task_keys, norm_w.tolist()))
+
+
+def weighted_hierarchical_loss(outputs, targets, criteria, task_weighting, ops_schedule, current_step: int, subset_ids=None, mixed_subset_ids=None,
+                               is_validation: bool = False, logger=None, config=None, *, sync_components: bool = True, _coin=None):
+    """(total_loss, loss_components, task_weights) of the reference's train / validation step.  With
+    `sync_components=False` the logging values stay device scalars (no host sync in the step)."""
+    keys = _sorted_tasks(outputs)
+    if not isinstance(targets, dict):
+        targets = dict(zip(keys, targets))
+    per = compute_core_loss(outputs, targets, criteria, config)
+    raw = {k: v.detach().clone() for k, v in per.items()}
+    phase1 = bool(config is not None and getattr(config.TRAIN, "PHASE1_MASK_NULL_LOSS", False))
+    cache = getattr(task_weighting, "_cache", None)
+    if phase1 and not is_validation:
+        masked = {t: v * (~_is_null(targets[t])).to(v.dtype) for t, v in per.items()}
+        zero = torch.zeros((), device=next(iter(per.values())).device)
+        stats = {"null_samples_total": zero, "null_samples_included": zero, "inclusion_percentage": 0.0, "null_mask_prob": 0.0}
+    else:
+        masked, stats = apply_loss_masking(per, targets, ops_schedule, current_step, task_weighting.class_weights, is_validation, logger, config,
+                                           _coin=_coin, _cache=cache)
+    stats["phase1_active"] = phase1 and not is_validation
+    after_cw = masked
+    if task_weighting.class_weights:
+        try:
+            apply_cw = config.LOSS.GRAD_WEIGHTING.CLASS.TRAIN if not is_validation else config.LOSS.GRAD_WEIGHTING.CLASS.VAL
+        except Exception:
+            apply_cw = True
+        if apply_cw:
+            after_cw = apply_class_weighting(masked, targets, task_weighting.class_weights, cache)
+    weighted, task_weights = task_weighting(after_cw, targets, num_valid_samples_per_task=stats.get("num_valid_samples_per_task", {}))
+    total = sum(weighted.values())
+    val = (lambda x: x.item()) if sync_components else (lambda x: x.detach())
+    comps = {"total": val(total), "tasks": {t: val(per[t].mean()) for t in keys}, "masked_tasks": {t: val(after_cw[t].mean()) for t in keys},
+             "weighted_tasks": {t: val(weighted[t]) for t in keys}, "raw_per_sample_losses": raw, "null_masking": stats}
+    return total, comps, task_weights

@@ -504,3 +504,65 @@ def soft_label_ce(logits: Tensor, target: Tensor, soft: Tensor, class_weight: Op
     if class_weight is not None:
         loss = loss * class_weight[target]
     return loss
+
+
+def taxonomy_smoothing_matrix(num_classes: int, distances: Tensor, alpha: float = 0.1, beta: float = 1.0, uniform_roots: bool = True,
+                              root_class_ids: Optional[Sequence[int]] = None) -> Tensor:
+    """Row-by-row restatement of build_taxonomy_smoothing_matrix (loss/taxonomy_label_smoothing.py:30-130)."""
+    roots = set(root_class_ids or [])
+    out = torch.zeros(num_classes, num_classes)
+    w = torch.exp(-beta * distances.float())
+    w[torch.isinf(distances)] = 0.0
+    for i in range(num_classes):
+        row = w[i].clone()
+        row[i] = 0.0
+        if uniform_roots and i in roots:
+            row = torch.full_like(row, 1.0 / (num_classes - 1)) if num_classes > 1 else torch.zeros_like(row)
+            row[i] = 0.0
+        s = row.sum()
+        if s > 1e-9:
+            sm = row * (alpha / s)
+        elif num_classes > 1:
+            sm = torch.full_like(row, alpha / (num_classes - 1))
+            sm[i] = 0.0
+        else:
+            sm = torch.zeros_like(row)
+        out[i] = sm
+        out[i, i] = 1.0 - alpha
+        t = out[i].sum()
+        if abs(t - 1.0) > 1e-6:
+            out[i] /= t
+    return out
+
+
+def hierarchical_loss(logits: Dict[str, Tensor], targets: Dict[str, Tensor], soft: Dict[str, Tensor], task_weights: Dict[str, float],
+                      class_weights: Optional[Dict[str, Tensor]], null_mask_prob: float, phase1: bool, is_validation: bool,
+                      apply_cw_train: bool = True, apply_cw_val: bool = False):
+    """Per-sample restatement of weighted_hierarchical_loss (loss/hierarchical_loss.py:24-406) for the DETERMINISTIC
+    masking modes (null_mask_prob in {0, 1}, PHASE1, validation): core loss -> null masking (loss/masking.py:19-465)
+    -> class weighting -> GradientWeighting.forward, static weights (loss/gradient_weighting.py:301-358).  Finding F13:
+    the class weight multiplies a sample once per stage that applies it (three stages on the scheduled path)."""
+    assert null_mask_prob in (0.0, 1.0)
+    weighted = {}
+    for t in sorted(logits, key=lambda k: int(k.split("_L")[-1])):
+        per = soft_label_ce(logits[t], targets[t], soft[t])
+        B = per.shape[0]
+        null = targets[t] == 0
+        if phase1 and not is_validation:
+            masked = [per[b] * (0.0 if null[b] else 1.0) for b in range(B)]
+            num_valid, stages = float(B), 0
+        else:
+            p = 1.0 if is_validation else null_mask_prob
+            masked = [per[b] if (not null[b] or p >= 1.0) else per[b] * 0.0 for b in range(B)]
+            num_valid = float(sum(1 for b in range(B) if masked[b].item() != 0.0))
+            stages = 1 if class_weights is not None else 0                      # inside apply_loss_masking
+        if class_weights is not None:
+            if (apply_cw_val if is_validation else apply_cw_train):
+                stages += 1                                                     # weighted_hierarchical_loss
+            stages += 1                                                         # GradientWeighting.forward
+        tot = 0.0
+        for b in range(B):
+            w = float(class_weights[t][int(targets[t][b])]) ** stages if class_weights is not None else 1.0
+            tot = tot + masked[b] * w
+        weighted[t] = tot / max(num_valid, 1e-6) * task_weights[t]
+    return sum(weighted.values()), weighted

@@ -21,6 +21,7 @@ Cases:
 plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate) and
   soft_ce     the reference's TaxonomyAwareLabelSmoothingCE (per-sample losses + logits gradient)
   train_step  two optimizer steps of tiny_a (CE loss, clip_grad_norm_, AdamW): losses, grad norms, deltas.
+  hier_loss   weighted_hierarchical_loss (null masking, class weights, task weights) + build_taxonomy_smoothing_matrix.
 """
 import os
 import sys
@@ -294,6 +295,85 @@ def soft_ce_known_answers():
     np.savez_compressed(os.path.join(OUT, "soft_ce.npz"), **rec)
 
 
+def hier_loss_known_answers():
+    """The reference's whole loss path on seeded logits (loss/hierarchical_loss.py:24-406 with loss/masking.py,
+    loss/gradient_weighting.py:301-358 and loss/taxonomy_label_smoothing.py:30-130): total loss, per-task weighted
+    losses and the gradient wrt every task's logits, for the deterministic masking modes (scheduled with inclusion
+    probability 1 and 0, PHASE1_MASK_NULL_LOSS, validation), with and without class weights (finding F13: the weights
+    enter three times on the scheduled path, twice on the PHASE1 path).  Also build_taxonomy_smoothing_matrix known
+    answers (root rows, disconnected classes, beta)."""
+    from linnaeus.loss.gradient_weighting import GradientWeighting
+    from linnaeus.loss.hierarchical_loss import weighted_hierarchical_loss
+    from linnaeus.loss.taxonomy_label_smoothing import TaxonomyAwareLabelSmoothingCE, build_taxonomy_smoothing_matrix
+
+    g = torch.Generator().manual_seed(SEED + 11)
+    tasks = (("taxa_L10", 23), ("taxa_L20", 9), ("taxa_L30", 4))
+    B = 16
+    rec = {"tasks": np.array([t for t, _ in tasks]), "classes": np.array([c for _, c in tasks])}
+    # smoothing matrices from synthetic tree distances (every rank: a distance matrix with some inf entries)
+    soft = {}
+    for t, c in tasks:
+        d = torch.randint(1, 5, (c, c), generator=g).float() * 2.0
+        d = torch.minimum(d, d.t())
+        d.fill_diagonal_(0.0)
+        if c > 5:
+            d[2, 5] = d[5, 2] = float("inf")
+            d[c - 1, :] = float("inf")  # a class disconnected from everything: uniform fallback row
+            d[:, c - 1] = float("inf")
+            d[c - 1, c - 1] = 0.0
+        roots = [0, 3] if c > 3 else [0]
+        for beta, ur in ((1.0, True), (0.5, False)):
+            m = build_taxonomy_smoothing_matrix(c, d, alpha=0.15, beta=beta, uniform_roots=ur, root_class_ids=roots)
+            rec[f"smooth_{t}_b{beta}_u{int(ur)}"] = m.numpy()
+        rec[f"dist_{t}"] = d.numpy()
+        rec[f"roots_{t}"] = np.array(roots)
+        soft[t] = build_taxonomy_smoothing_matrix(c, d, alpha=0.15, beta=1.0, uniform_roots=True, root_class_ids=roots)
+    logits = {t: (torch.randn(B, c, generator=g) * 2).requires_grad_(True) for t, c in tasks}
+    targets = {t: torch.randint(0, c, (B,), generator=g) for t, c in tasks}
+    targets["taxa_L10"][:3] = 0
+    targets["taxa_L20"][2:7] = 0
+    cw = {t: {i: float(0.5 + torch.rand(1, generator=g).item()) for i in range(0, c, 2)} for t, c in tasks}  # sparse dict: missing -> 1.0
+    tw = {"taxa_L10": 1.0, "taxa_L20": 0.6, "taxa_L30": 0.3}
+    for t, c in tasks:
+        rec[f"logits_{t}"] = logits[t].detach().numpy()
+        rec[f"target_{t}"] = targets[t].numpy()
+        rec[f"soft_{t}"] = soft[t].numpy()
+        v = np.ones(c, dtype=np.float32)
+        for i, w in cw[t].items():
+            v[i] = w
+        rec[f"cw_{t}"] = v
+    rec["task_weights"] = np.array([tw[t] for t, _ in tasks], dtype=np.float32)
+
+    class Sched:  # the one method the loss path calls (ops_schedule/ops_schedule.py:655)
+        def __init__(self, p):
+            self.p = p
+
+        def get_null_mask_prob(self, step):
+            return self.p
+
+    criteria = {t: TaxonomyAwareLabelSmoothingCE(soft[t]) for t, _ in tasks}
+    keys = [t for t, _ in tasks]
+    for mode, prob, phase1, val, use_cw in (("sched1", 1.0, False, False, True), ("sched0", 0.0, False, False, True), ("phase1", 1.0, True, False, True),
+                                            ("val", 0.0, False, True, True), ("sched0_nocw", 0.0, False, False, False)):
+        cfg = get_default_config()
+        cfg.defrost()
+        cfg.TRAIN.PHASE1_MASK_NULL_LOSS = phase1
+        gw = GradientWeighting(keys, cfg, "static", init_weights=tw, class_weights=cw if use_cw else None)
+        for t in keys:
+            logits[t].grad = None
+        total, comps, weights = weighted_hierarchical_loss({t: logits[t] for t in keys}, targets, criteria, gw, Sched(prob), 10,
+                                                           is_validation=val, config=cfg)
+        total.backward()
+        rec[f"{mode}_total"] = np.float64(total.item())
+        rec[f"{mode}_weighted"] = np.array([comps["weighted_tasks"][t] for t in keys])
+        rec[f"{mode}_masked_mean"] = np.array([comps["masked_tasks"][t] for t in keys])
+        rec[f"{mode}_raw_mean"] = np.array([comps["tasks"][t] for t in keys])
+        for t in keys:
+            rec[f"{mode}_grad_{t}"] = logits[t].grad.numpy().copy()
+        print(f"[hier_loss/{mode}] total {total.item():.6f} weighted {rec[f'{mode}_weighted']}")
+    np.savez_compressed(os.path.join(OUT, "hier_loss.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -387,6 +467,8 @@ def main():
         soft_ce_known_answers()
     if want("train_step"):
         run_train_step("train_step", tiny_a, 64, 4)
+    if want("hier_loss"):
+        hier_loss_known_answers()
 
 
 if __name__ == "__main__":

@@ -126,3 +126,41 @@ def test_train_step_matches_reference(golden_dir):
             continue  # a constant shift in front of final_norm: its gradient is exactly zero in real arithmetic, and Adam turns the rounding noise into +-lr
         floor = 0.05 * float(z["lr"]) * int(z["steps"]) * sd[k].numel() ** 0.5
         assert abs(d - z["delta_norms"][i]) <= 2e-2 * z["delta_norms"][i] + floor, (k, d, z["delta_norms"][i])
+
+
+HIER_MODES = {"sched1": (1.0, False, False, True), "sched0": (0.0, False, False, True), "phase1": (1.0, True, False, True), "val": (0.0, False, True, True),
+              "sched0_nocw": (0.0, False, False, False)}
+
+
+def _hier_fixture(golden_dir):
+    z = np.load(f"{golden_dir}/hier_loss.npz")
+    tasks = [str(t) for t in z["tasks"]]
+    return z, tasks, [int(c) for c in z["classes"]]
+
+
+def test_oracle_smoothing_matrix_matches_reference(golden_dir):
+    z, tasks, classes = _hier_fixture(golden_dir)
+    for t, c in zip(tasks, classes):
+        for beta, ur in ((1.0, 1), (0.5, 0)):
+            m = O.taxonomy_smoothing_matrix(c, torch.from_numpy(z[f"dist_{t}"]), alpha=0.15, beta=beta, uniform_roots=bool(ur), root_class_ids=list(z[f"roots_{t}"]))
+            np.testing.assert_allclose(m.numpy(), z[f"smooth_{t}_b{beta}_u{ur}"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(m.sum(1).numpy(), 1.0, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", list(HIER_MODES))
+def test_oracle_hierarchical_loss_matches_reference(mode, golden_dir):
+    """weighted_hierarchical_loss of the reference (fixture made by tests/golden/gen/make_golden.py hier_loss) vs the
+    oracle restatement: total, per-task weighted losses and the logits gradients of every masking mode (F13 included)."""
+    z, tasks, classes = _hier_fixture(golden_dir)
+    prob, phase1, val, use_cw = HIER_MODES[mode]
+    lg = {t: torch.from_numpy(z[f"logits_{t}"]).clone().requires_grad_(True) for t in tasks}
+    tg = {t: torch.from_numpy(z[f"target_{t}"]) for t in tasks}
+    soft = {t: torch.from_numpy(z[f"soft_{t}"]) for t in tasks}
+    cw = {t: torch.from_numpy(z[f"cw_{t}"]) for t in tasks} if use_cw else None
+    tw = {t: float(w) for t, w in zip(tasks, z["task_weights"])}
+    total, weighted = O.hierarchical_loss(lg, tg, soft, tw, cw, prob, phase1, val)
+    total.backward()
+    assert abs(total.item() - float(z[f"{mode}_total"])) <= 2e-5 * abs(float(z[f"{mode}_total"]))
+    np.testing.assert_allclose([weighted[t].item() for t in tasks], z[f"{mode}_weighted"], rtol=2e-5)
+    for t in tasks:
+        np.testing.assert_allclose(lg[t].grad.numpy(), z[f"{mode}_grad_{t}"], rtol=1e-4, atol=1e-6)
