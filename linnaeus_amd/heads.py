@@ -189,3 +189,26 @@ def configure_classification_heads(heads_config, in_features: int, num_classes_d
             kw["temperature"] = hc.get("TEMPERATURE", hc.get("temperature", 1.0))
         heads[task] = create_head(htype, **kw)
     return heads
+
+
+def refine_logits_top_down(base: Dict[str, torch.Tensor], heads: nn.ModuleDict, task_keys: List[str]) -> Dict[str, torch.Tensor]:
+    """OPT-IN "intended" hierarchical refinement: what heads/conditional_classifier_head.py:176-204
+    was written to do and never does (finding F3: the matrix names never match; F4: it would raise if they did).
+    Coarsest rank first, every finer rank adds the log prior its parent's routing probabilities induce:
+
+        refined[child] = base[child] + log( softmax(refined[parent] / T) . M[parent -> child] + 1e-10 )
+
+    with M = the tree's hmatrix_{parent}_{child} ([n_parent, n_child] 0/1 membership, utils/taxonomy/taxonomy_tree.py:384).
+    Off by default: with it on, outputs intentionally differ from the reference.  The product is lnx_gemm_nt (fp32)."""
+    refined = dict(base)
+    for i in range(len(task_keys) - 2, -1, -1):
+        child, parent = task_keys[i], task_keys[i + 1]
+        head = heads[child] if child in heads else None
+        name = f"hmatrix_{parent}_{child}"
+        if head is None or not hasattr(head, name) or parent not in refined:
+            continue
+        temp = float(getattr(head, "temperature", 1.0))
+        probs = torch.softmax(refined[parent].float() / temp, dim=1)
+        prior = _LinearFn.apply(probs, getattr(head, name).t().contiguous().float(), None)  # probs . M
+        refined[child] = base[child] + torch.log(prior + 1e-10).to(base[child].dtype)
+    return refined

@@ -257,6 +257,9 @@ class mFormerV1(nn.Module):
         self._grad_views: Optional[List[torch.Tensor]] = None
         self._arena_layout = None
         self.use_checkpoint = False   # probed by the reference's train loop; activations are always kept (no recompute path)
+        # opt-in: the refinement the hierarchical heads were meant to apply (heads.refine_logits_top_down); the reference's
+        # effective behaviour -- and the default here -- is the plain shared Linear per task (finding F3)
+        self.hierarchical_refinement = bool(M.CLASSIFICATION.get("HIERARCHICAL_REFINEMENT", False)) if hasattr(M, "CLASSIFICATION") else False
 
     # reference: mFormerV1._init_weights (mFormerV1.py:351-359)
     @staticmethod
@@ -341,6 +344,41 @@ class mFormerV1(nn.Module):
             return lin.weight if kind == "weight" else lin.bias
         return self.get_parameter(plan_name)
 
+    def _make_cfg(self, B: int, H: int, W: int, train: bool) -> "_Cfg":
+        cfg = _Cfg()
+        cfg.inference = 0 if train else 1
+        cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
+        cfg.dims[:] = self._dims
+        cfg.conv_depths[:] = self._depths[:2]
+        cfg.rope_depths[:] = self._rdepths
+        cfg.rope_heads[:] = self._rheads
+        cfg.mlp_hidden[:] = self._hidden
+        cfg.n_meta = len(self.meta_dims)
+        for i, d in enumerate(self.meta_dims):
+            cfg.meta_dims[i] = d
+        cfg.only_last_cls = int(bool(self.only_last_cls))
+        tasks = self._task_list()
+        cfg.n_tasks = len(tasks)
+        for i, t in enumerate(tasks):
+            cfg.task_classes[i] = self.head[t].effective_linear.out_features
+        return cfg
+
+    def workspace_bytes(self, batch: int, img_h: Optional[int] = None, img_w: Optional[int] = None, train: bool = True) -> int:
+        """Bytes of plan workspace (saved activations + operand arena + scratch) a forward[/backward] of this batch shape
+        needs -- computed by the native planner WITHOUT allocating anything, which is what lets AutoBatch size a batch
+        for 288 GB analytically instead of by out-of-memory trials (utils/autobatch.py:111-265)."""
+        lib = L.lib()
+        lib.lnx_plan_workspace_bytes.restype = C.c_int64
+        H = img_h or self.img_size[0]
+        W = img_w or img_h or self.img_size[1]
+        cfg = self._make_cfg(int(batch), int(H), int(W), train)
+        handle = C.c_void_p()
+        L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
+        try:
+            return int(lib.lnx_plan_workspace_bytes(handle)) + 256
+        finally:
+            lib.lnx_plan_destroy(handle)
+
     def _get_plan(self, B: int, H: int, W: int, train: bool = True) -> Dict[str, Any]:
         """Native plan for one (batch, image size, dtype, train/inference) combination.  Inference plans (no_grad /
         frozen model) carry no backward scratch and share activation buffers between blocks.  The cache is a small
@@ -357,22 +395,8 @@ class mFormerV1(nn.Module):
                     self._active = None
                 torch.cuda.current_stream().synchronize()
                 self._destroy_plan(old)
-            cfg = _Cfg()
-            cfg.inference = 0 if train else 1
-            cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
-            cfg.dims[:] = self._dims
-            cfg.conv_depths[:] = self._depths[:2]
-            cfg.rope_depths[:] = self._rdepths
-            cfg.rope_heads[:] = self._rheads
-            cfg.mlp_hidden[:] = self._hidden
-            cfg.n_meta = len(self.meta_dims)
-            for i, d in enumerate(self.meta_dims):
-                cfg.meta_dims[i] = d
-            cfg.only_last_cls = int(bool(self.only_last_cls))
+            cfg = self._make_cfg(B, H, W, train)
             tasks = self._task_list()
-            cfg.n_tasks = len(tasks)
-            for i, t in enumerate(tasks):
-                cfg.task_classes[i] = self.head[t].effective_linear.out_features
             handle = C.c_void_p()
             L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
             lib.lnx_plan_workspace_bytes.restype = C.c_int64
@@ -577,6 +601,10 @@ class mFormerV1(nn.Module):
             if acast is not None:
                 out[t] = out[t].to(acast)  # the reference returns logits in the autocast dtype (SURVEY 8b "Tensor conventions")
         self._last_feats = feats
+        if self.hierarchical_refinement:
+            from .heads import refine_logits_top_down
+
+            out = refine_logits_top_down(out, self.head, self.task_keys)
         return out
 
     def __del__(self):

@@ -102,3 +102,91 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._sumsq is None or self.max_grad_norm is None:
             return None
         return self._sumsq.sqrt()[0]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Muon: SGD-momentum whose 2-D update is orthogonalised by five Newton-Schulz iterations in bf16
+# (optimizers/muon.py:27-65, 67-160).  The 15 matrix products per parameter run on lnx_gemm_nt (bf16 MFMA, fp32
+# accumulate): A = X X^T, B = c A A + b A and X' = B X + a X are each ONE launch (the affine terms ride in the GEMM
+# epilogue as the per-column scale and the fp32 residual), where the reference issues a matmul plus elementwise
+# bf16 passes per term.  Same constructor, param_groups and state ('momentum_buffer') as the reference's Muon.
+# ----------------------------------------------------------------------------------------------------------------------
+def zeropower_via_newtonschulz5(G: torch.Tensor, steps: int = 5) -> torch.Tensor:
+    """Orthogonalise a 2-D gradient (quintic Newton-Schulz, coefficients of optimizers/muon.py:41).  bf16 in / out."""
+    from . import ops
+
+    assert G.ndim == 2, "2-D matrices (4-D conv weights are flattened by the optimizer)"
+    if not G.is_cuda:
+        raise L.LnxError("linnaeus_amd.optim.Muon runs on the HIP GEMM kernels: parameters must be on the GPU")
+    a, b, c = 3.4445, -4.7750, 2.0315
+    X = G.bfloat16()
+    tall = G.size(0) > G.size(1)
+    if tall:
+        X = X.t()
+    m, n = X.shape
+    mp, npad = (m + 7) // 8 * 8, (n + 7) // 8 * 8   # GEMM K granularity; zero rows / columns do not change any product
+    X = X / (X.float().norm() + 1e-7).to(torch.bfloat16)
+    if (mp, npad) != (m, n):
+        X = torch.nn.functional.pad(X, (0, npad - n, 0, mp - m))
+    X = X.contiguous()
+    dev = X.device
+    cvec = torch.full((mp,), c, device=dev, dtype=torch.float32)
+    ones = None
+    A = torch.empty(mp, mp, device=dev, dtype=torch.bfloat16)
+    Bm = torch.empty(mp, mp, device=dev, dtype=torch.bfloat16)
+    Xn = torch.empty(mp, npad, device=dev, dtype=torch.bfloat16)
+    for _ in range(steps):
+        XT = X.t().contiguous()                                   # [n, m]: the "W" operand of B . X
+        ops.gemm_nt(X, X, A)                                      # A = X X^T
+        ops.gemm_nt(A, A, Bm, gamma=cvec, res=A.float() * b)      # B = c A A + b A   (A symmetric: A A^T = A A)
+        ops.gemm_nt(Bm, XT, Xn, res=X.float() * a)                # X' = B X + a X
+        X, Xn = Xn, X
+    X = X[:m, :n]
+    return (X.t() if tall else X).contiguous()
+
+
+class Muon(torch.optim.Optimizer):
+    """optimizers/muon.py:67-160 on the HIP kernels (2-D parameters, or 4-D conv weights flattened to [out, -1])."""
+
+    def __init__(self, params, lr=0.02, weight_decay=0.01, momentum=0.95, nesterov=True, ns_steps=5, strict=False):
+        if not 0.0 <= lr:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not 0.0 <= momentum < 1.0:
+            raise ValueError(f"Invalid momentum value: {momentum}")
+        if not 0.0 <= weight_decay:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        params = list(params)
+        if strict:
+            for p in (q for g in params for q in (g["params"] if isinstance(g, dict) else [g])):
+                if p.dim() not in (2, 4):
+                    raise ValueError(f"Muon optimizer requires 2D or 4D parameters, got shape {p.shape}")
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay, momentum=momentum, nesterov=nesterov, ns_steps=ns_steps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            lr, wd, mom = group["lr"], group["weight_decay"], group["momentum"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if wd != 0:
+                    p.mul_(1 - lr * wd)
+                st = self.state[p]
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(g)
+                buf = st["momentum_buffer"]
+                buf.lerp_(g, 1 - mom)
+                g = g.lerp_(buf, mom) if group["nesterov"] else buf.clone()
+                g2 = g.view(g.size(0), -1) if g.ndim == 4 else g
+                o = zeropower_via_newtonschulz5(g2, steps=group["ns_steps"])
+                if p.dim() == 4:
+                    scaling = max(1, p.size(0) / (p.size(1) * p.size(2) * p.size(3))) ** 0.5
+                else:
+                    scaling = max(1, p.size(-2) / p.size(-1)) ** 0.5
+                p.add_(o.view_as(p).to(p.dtype), alpha=-lr * scaling)
+        return loss

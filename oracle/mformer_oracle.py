@@ -566,3 +566,33 @@ def hierarchical_loss(logits: Dict[str, Tensor], targets: Dict[str, Tensor], sof
             tot = tot + masked[b] * w
         weighted[t] = tot / max(num_valid, 1e-6) * task_weights[t]
     return sum(weighted.values()), weighted
+
+
+def newton_schulz5(G: Tensor, steps: int = 5) -> Tensor:
+    """zeropower_via_newtonschulz5 (optimizers/muon.py:27-65): quintic Newton-Schulz orthogonalisation with every
+    product and affine step rounded to bf16, as the reference runs it."""
+    a, b, c = 3.4445, -4.7750, 2.0315
+    X = G.bfloat16()
+    tall = G.size(-2) > G.size(-1)
+    if tall:
+        X = X.mT
+    X = X / (X.norm(dim=(-2, -1), keepdim=True) + 1e-7)
+    for _ in range(steps):
+        A = X @ X.mT
+        B = b * A + c * A @ A
+        X = a * X + B @ X
+    return (X.mT if tall else X).bfloat16()
+
+
+def newton_schulz5_exact(G: Tensor, steps: int = 5) -> Tensor:
+    """the same iteration in fp64 (what both the reference's bf16 run and the HIP run approximate)"""
+    a, b, c = 3.4445, -4.7750, 2.0315
+    X = G.double()
+    tall = G.size(-2) > G.size(-1)
+    if tall:
+        X = X.mT
+    X = X / (X.norm() + 1e-7)
+    for _ in range(steps):
+        A = X @ X.mT
+        X = a * X + (b * A + c * A @ A) @ X
+    return X.mT if tall else X

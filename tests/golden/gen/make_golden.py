@@ -374,6 +374,34 @@ def hier_loss_known_answers():
     np.savez_compressed(os.path.join(OUT, "hier_loss.npz"), **rec)
 
 
+def muon_known_answers():
+    """The reference's Muon (optimizers/muon.py): Newton-Schulz orthogonalisation of seeded matrices (wide, tall, a
+    conv-shaped one) and two optimizer steps on three parameters."""
+    from linnaeus.optimizers.muon import Muon, zeropower_via_newtonschulz5
+
+    g = torch.Generator().manual_seed(SEED + 13)
+    rec = {}
+    for name, shape in (("wide", (48, 192)), ("tall", (192, 48)), ("odd", (40, 100)), ("sq", (64, 64))):
+        G = torch.randn(*shape, generator=g)
+        rec[f"ns_in_{name}"] = G.numpy()
+        rec[f"ns_out_{name}"] = zeropower_via_newtonschulz5(G, steps=5).float().numpy()
+    ps = [torch.randn(48, 192, generator=g), torch.randn(192, 48, generator=g), torch.randn(32, 8, 2, 2, generator=g)]
+    params = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = Muon(params, lr=0.02, weight_decay=0.01, momentum=0.95, nesterov=True, ns_steps=5)
+    for i, p in enumerate(ps):
+        rec[f"p{i}_init"] = p.numpy()
+    for step in range(2):
+        for i, p in enumerate(params):
+            gr = torch.randn(p.shape, generator=g)
+            rec[f"p{i}_grad{step}"] = gr.numpy()
+            p.grad = gr.clone()
+        opt.step()
+    for i, p in enumerate(params):
+        rec[f"p{i}_final"] = p.detach().numpy()
+    print("[muon] orthogonality |X X^T - I| (wide):", float((torch.from_numpy(rec["ns_out_wide"]) @ torch.from_numpy(rec["ns_out_wide"]).t() - torch.eye(48)).abs().max()))
+    np.savez_compressed(os.path.join(OUT, "muon.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -469,6 +497,8 @@ def main():
         run_train_step("train_step", tiny_a, 64, 4)
     if want("hier_loss"):
         hier_loss_known_answers()
+    if want("muon"):
+        muon_known_answers()
 
 
 if __name__ == "__main__":

@@ -525,3 +525,54 @@ def test_fused_convmlp_wgrad_path_in_plan(golden_dir, monkeypatch):
             ref = osd[k].grad
             rel = ((p_.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-6)).item()
             assert rel <= 0.05, (k, rel)
+
+
+def test_autobatch_analytic_matches_measured():
+    """AutoBatch (utils/autobatch.py:111-265): the planner's analytic footprint predicts the measured peak of a real
+    training step within a few percent, the search result is the largest batch under the budget, and a tight budget
+    yields a smaller batch than a loose one."""
+    from linnaeus_amd.autobatch import _trial, auto_find_batch_size, predicted_bytes
+
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 9)
+    model = build("tiny_a", spec, sd, "bf16")
+    cfg = make_config(spec, 64)
+    for B in (8, 64):
+        pred = predicted_bytes(model, B, 64, mode="train", optimizer_state_per_param=0)
+        base = torch.cuda.memory_allocated()
+        peak = _trial(model, B, 64, "train", 2, None) - base + 4 * sum(p_.numel() for p_ in model.parameters())
+        assert 0.7 * pred <= peak <= 1.3 * pred + (8 << 20), (B, pred, peak)
+    total = torch.cuda.get_device_properties(0).total_memory
+    per_img = (predicted_bytes(model, 512, 64) - predicted_bytes(model, 256, 64)) / 256
+    frac = (predicted_bytes(model, 300, 64) + 0.5 * per_img) / total
+    bs = auto_find_batch_size(model, cfg, "train", target_memory_fraction=frac, max_batch_size=4096, min_batch_size=1, steps_per_trial=1)
+    assert 280 <= bs <= 300, bs
+    assert predicted_bytes(model, bs, 64) <= frac * total < predicted_bytes(model, bs + 2, 64) + per_img
+    assert auto_find_batch_size(model, cfg, "train", target_memory_fraction=frac / 2, max_batch_size=4096, steps_per_trial=1) < bs
+
+
+def test_opt_in_hierarchical_refinement(golden_dir):
+    """MODEL.CLASSIFICATION.HIERARCHICAL_REFINEMENT (opt-in, off by default): refined[child] = base[child] +
+    log(softmax(refined[parent]) . M + 1e-10), coarsest rank first.  The reference never executes this (F3/F4), so the
+    expected values are the formula itself in fp64 on the base logits -- parity for this flag is unpinned by design."""
+    spec, z, sd, x, meta, drops = load_case("tiny_c", golden_dir)
+    model = build("tiny_c", spec, sd, "fp32")
+    model.eval()
+    with torch.no_grad():
+        base = {k: v.clone() for k, v in model(x.cuda(), None).items()}
+        model.hierarchical_refinement = True
+        got = model(x.cuda(), None)
+    keys = [t for t, _ in spec.heads]
+    ref = {k: v.double() for k, v in base.items()}
+    for i in range(len(keys) - 2, -1, -1):
+        child, parent = keys[i], keys[i + 1]
+        M = getattr(model.head[child], f"hmatrix_{parent}_{child}").double()
+        ref[child] = base[child].double() + torch.log(torch.softmax(ref[parent], 1) @ M + 1e-10)
+    for k in keys:
+        torch.testing.assert_close(got[k].double(), ref[k], rtol=1e-5, atol=1e-5)
+    assert not torch.allclose(got[keys[0]], base[keys[0]])  # the flag does change the fine ranks
+    torch.testing.assert_close(got[keys[-1]], base[keys[-1]])  # the coarsest rank has no parent
+    model.train()
+    out = model(x.cuda(), None)
+    O.probe_loss(out).backward()  # differentiable through the HIP GEMM of the prior
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in model.parameters())

@@ -92,3 +92,38 @@ def test_fused_adamw_per_parameter_step_counts():
         for a, b in zip(pa, pb):
             torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
     assert oa.state[pa[1]]["step"] == 3 and oa.state[pa[0]]["step"] == 5
+
+
+def test_muon_newton_schulz_and_steps_match_reference(golden_dir):
+    """Muon (optimizers/muon.py) on the HIP GEMMs against the reference's own outputs (tests/golden/muon.npz): the
+    Newton-Schulz orthogonalisation of wide / tall / non-multiple-of-8 / square matrices, and two optimizer steps on a
+    wide, a tall and a conv-shaped parameter.  The reference rounds every product and affine term to bf16; the HIP path
+    rounds once per fused launch, so it is compared both with the reference (bf16-level tolerance) and with the exact
+    fp64 iteration (it must not be further from it than the reference is)."""
+    from linnaeus_amd.optim import Muon, zeropower_via_newtonschulz5
+    from oracle import mformer_oracle as O
+
+    z = np.load(f"{golden_dir}/muon.npz")
+    for name in ("wide", "tall", "odd", "sq"):
+        G = torch.from_numpy(z[f"ns_in_{name}"])
+        ref = torch.from_numpy(z[f"ns_out_{name}"])
+        got = zeropower_via_newtonschulz5(G.cuda(), steps=5).float().cpu()
+        exact = O.newton_schulz5_exact(G).float()
+        assert got.shape == ref.shape
+        e_ref, e_got = (ref - exact).abs().max().item(), (got - exact).abs().max().item()
+        print(f"[muon/{name}] max|ref - exact| {e_ref:.4f}  max|hip - exact| {e_got:.4f}  max|hip - ref| {(got - ref).abs().max().item():.4f}")
+        assert e_got <= 1.5 * e_ref + 2e-3, (name, e_got, e_ref)
+        assert (got - ref).abs().max().item() <= 2.5 * e_ref + 4e-3, name
+    params = [torch.nn.Parameter(torch.from_numpy(z[f"p{i}_init"]).cuda()) for i in range(3)]
+    opt = Muon(params, lr=0.02, weight_decay=0.01, momentum=0.95, nesterov=True, ns_steps=5)
+    for step in range(2):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(z[f"p{i}_grad{step}"]).cuda()
+        opt.step()
+    for i, p in enumerate(params):
+        ref, init = torch.from_numpy(z[f"p{i}_final"]), torch.from_numpy(z[f"p{i}_init"])
+        d_ref, d_got = ref - init, p.detach().cpu() - init
+        rel = ((d_got - d_ref).norm() / d_ref.norm()).item()
+        print(f"[muon/step p{i}] relative update error vs reference {rel:.4f}")
+        assert rel <= 0.05, (i, rel)
+    assert "momentum_buffer" in opt.state[params[0]]

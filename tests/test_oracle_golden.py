@@ -164,3 +164,11 @@ def test_oracle_hierarchical_loss_matches_reference(mode, golden_dir):
     np.testing.assert_allclose([weighted[t].item() for t in tasks], z[f"{mode}_weighted"], rtol=2e-5)
     for t in tasks:
         np.testing.assert_allclose(lg[t].grad.numpy(), z[f"{mode}_grad_{t}"], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_newton_schulz_matches_reference(golden_dir):
+    """Muon's orthogonalisation (optimizers/muon.py:27-65): the oracle's bf16 restatement reproduces the reference bit for bit"""
+    z = np.load(f"{golden_dir}/muon.npz")
+    for name in ("wide", "tall", "odd", "sq"):
+        got = O.newton_schulz5(torch.from_numpy(z[f"ns_in_{name}"]), steps=5).float().numpy()
+        np.testing.assert_array_equal(got, z[f"ns_out_{name}"])
