@@ -314,6 +314,32 @@ typedef struct lnx_softce_args {
 int lnx_softce(const lnx_softce_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * GPU-side batch mixing of the collate step: selective Mixup / CutMix and the metadata chunk pick.
+ * Replaces linnaeus/aug/gpu/selective_mixup.py:140-230,420-560 and selective_cutmix.py:200-260 (fp32 batches).
+ *   mode 0  out[b] = lam x[b] + (1-lam) x[perm[b]]                          (mixup of images / soft targets)
+ *   mode 1  out[b] = x[b] with the box [h0,h1) x [w0,w1) taken from x[perm[b]] where valid[b]      (cutmix images)
+ *   mode 2  out[b] = valid[b] ? lam x[b] + (1-lam) x[perm[b]] : x[b]                               (cutmix targets)
+ * -----------------------------------------------------------------------------------*/
+typedef struct lnx_mix_args {
+    const float* x;             /* [B, row] */
+    const int64_t* perm;        /* [B] partner index (perm[b] == b: unchanged) */
+    const unsigned char* valid; /* [B] or NULL (= all valid) */
+    float* out;                 /* [B, row], must not alias x */
+    int B;
+    int64_t row;                /* elements per sample, multiple of 4; mode 1: C*H*W */
+    int H, W;                   /* mode 1 only */
+    float lam;
+    int h0, h1, w0, w1;         /* mode 1 only */
+    int mode;
+} lnx_mix_args;
+int lnx_mix_rows(const lnx_mix_args* args, void* stream);
+/* metadata [B, D] with validity mask [B, D] (bytes): per chunk (bounds_dev = device int[2*nchunk] of [start, end)) a chunk
+ * with any zero entry counts as absent; both present -> own if pick[b] < 0.5 else the partner's; one present -> it; none ->
+ * zeros and an all-false mask */
+int lnx_mix_meta(const float* aux, const unsigned char* mask, const int64_t* perm, const float* pick, const int* bounds_dev, int nchunk, int B, int D,
+                 float* out_aux, unsigned char* out_mask, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optimizer + step glue: multi-tensor AdamW with the global-norm clip folded in.
  * Replaces torch.optim.AdamW.step as configured by linnaeus/optimizers/build.py:307-686 (per-group lr / weight
  * decay) and the gradient-norm passes of train.py:282-308 (clip_grad_norm_ semantics:

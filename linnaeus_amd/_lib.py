@@ -117,6 +117,7 @@ EXPORTS = [
     "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
+    "lnx_mix_rows", "lnx_mix_meta",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_wgrad", "lnx_convmlp_wgrad_ws_floats",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",
@@ -215,4 +216,12 @@ class ConvMlpWgradArgs(C.Structure):
         ("ln", C.c_void_p), ("dz", C.c_void_p), ("w1", C.c_void_p), ("w2t", C.c_void_p), ("b1", C.c_void_p),
         ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+    ]
+
+
+class MixArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("perm", C.c_void_p), ("valid", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int), ("row", C.c_int64), ("H", C.c_int), ("W", C.c_int), ("lam", C.c_float),
+        ("h0", C.c_int), ("h1", C.c_int), ("w0", C.c_int), ("w1", C.c_int), ("mode", C.c_int),
     ]

@@ -596,3 +596,56 @@ def newton_schulz5_exact(G: Tensor, steps: int = 5) -> Tensor:
         A = X @ X.mT
         X = a * X + (b * A + c * A @ A) @ X
     return X.mT if tall else X
+
+
+# --------------------------------------------------------------------------------------
+# collate-time batch mixing, given the random draws
+# --------------------------------------------------------------------------------------
+def _null_excluded_groups(targets: Dict[str, Tensor], gids: Tensor) -> Tensor:
+    """exclude_null_samples_from_mixup (aug/utils.py:46-180): group -1 for samples null in any task"""
+    g = gids.clone()
+    for t in targets.values():
+        g[(t == 0) if t.dim() == 1 else (t[:, 0] > 0.5)] = -1
+    return g
+
+
+def _mix_meta_chunks(aux: Tensor, masks: Tensor, perm: Tensor, pick: Tensor, bounds) -> Tuple[Tensor, Tensor]:
+    """_enforce_all_or_nothing + _mix_aux_info_chunkwise (aug/gpu/selective_mixup.py:395-560), sample by sample"""
+    a, m = aux.clone(), masks.clone()
+    for s, e in bounds:
+        part = (a[:, s:e] == 0.0).any(1)
+        a[part, s:e] = 0.0
+        m[part, s:e] = False
+    oa, om = torch.zeros_like(a), torch.zeros_like(m)
+    for i in range(a.shape[0]):
+        j = int(perm[i])
+        for s, e in bounds:
+            z1, z2 = bool((a[i, s:e] == 0).all()), bool((a[j, s:e] == 0).all())
+            src = (i if float(pick[i]) < 0.5 else j) if (not z1 and not z2) else (i if not z1 else (j if not z2 else None))
+            if src is not None:
+                oa[i, s:e], om[i, s:e] = a[src, s:e], m[src, s:e]
+    return oa, om
+
+
+def selective_mixup(images, targets, aux, masks, gids, perm, lam, pick, bounds):
+    """GPUSelectiveMixup.__call__ (aug/gpu/selective_mixup.py:72-230) for given draws"""
+    mi = lam * images + (1 - lam) * images[perm]
+    mt = {k: lam * v + (1 - lam) * v[perm] for k, v in targets.items()}
+    ma, mm = _mix_meta_chunks(aux, masks, perm, pick, bounds)
+    return mi, mt, ma, mm
+
+
+def selective_cutmix(images, targets, aux, masks, gids, perm, box, pick, bounds):
+    """GPUSelectiveCutMix.__call__ (aug/gpu/selective_cutmix.py:96-430) for given draws; box = rand_bbox's tuple"""
+    x1, y1, x2, y2 = [int(v) for v in box]
+    H, W = images.shape[2:]
+    lam_adj = 1.0 - ((x2 - x1) * (y2 - y1) / (H * W))
+    g = _null_excluded_groups(targets, gids)
+    valid = (g != -1).nonzero(as_tuple=True)[0]
+    mi = images.clone()
+    mi[valid, :, x1:x2, y1:y2] = images[perm[valid], :, x1:x2, y1:y2]
+    mt = {k: v.clone() for k, v in targets.items()}
+    for k in mt:
+        mt[k][valid] = lam_adj * targets[k][valid] + (1 - lam_adj) * targets[k][perm[valid]]
+    ma, mm = _mix_meta_chunks(aux, masks, perm, pick, bounds)
+    return mi, mt, ma, mm

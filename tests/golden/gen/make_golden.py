@@ -402,6 +402,87 @@ def muon_known_answers():
     np.savez_compressed(os.path.join(OUT, "muon.npz"), **rec)
 
 
+def collate_known_answers():
+    """The reference's GPU augmentations on a seeded batch (they are device-agnostic torch code): GPUSelectiveMixup and
+    GPUSelectiveCutMix, with the random draws they made (permutation, lambda, box, per-sample pick) recorded so the HIP
+    path can be replayed with the same draws."""
+    import linnaeus.aug.gpu.selective_cutmix as cm
+    from linnaeus.aug.gpu.selective_cutmix import GPUSelectiveCutMix
+    from linnaeus.aug.gpu.selective_mixup import GPUSelectiveMixup
+
+    g = torch.Generator().manual_seed(SEED + 17)
+    B, Cc, H, W, D = 12, 3, 16, 24, 15
+    bounds = [(0, 2), (2, 5), (5, 15)]
+    images = torch.rand(B, Cc, H, W, generator=g)
+    tasks = (("taxa_L10", 9), ("taxa_L20", 4))
+    lab = {t: torch.randint(0, c, (B,), generator=g) for t, c in tasks}
+    lab["taxa_L10"][1] = 0  # a null sample: excluded from mixing
+    targets = {t: torch.nn.functional.one_hot(lab[t], c).float() for t, c in tasks}
+    aux = torch.randn(B, D, generator=g)
+    aux[2, 0:2] = 0.0       # absent chunk
+    aux[3, 3] = 0.0         # partially zero chunk -> treated as absent
+    aux[5, 5:15] = 0.0
+    aux[7] = 0.0
+    masks = aux != 0.0
+    gids = torch.tensor([0, 0, 0, 1, 1, 1, 1, 2, 3, 3, -1, 0])
+    rec = {"images": images.numpy(), "aux": aux.numpy(), "masks": masks.numpy(), "gids": gids.numpy(), "bounds": np.array(bounds)}
+    for t, _ in tasks:
+        rec[f"target_{t}"] = targets[t].numpy()
+    draws = {}
+    orig_rand, orig_beta = torch.rand, torch.distributions.beta.Beta.sample
+
+    def rand_spy(*a, **k):
+        r = orig_rand(*a, **k)
+        if r.numel() == B:
+            draws["pick"] = r.clone()
+        return r
+
+    def beta_spy(self, *a, **k):
+        r = orig_beta(self, *a, **k)
+        draws["lam"] = float(r)
+        return r
+
+    orig_bbox = cm.rand_bbox
+
+    def bbox_spy(size, lam):
+        r = orig_bbox(size, lam)
+        draws["box"] = r
+        return r
+
+    torch.rand, torch.distributions.beta.Beta.sample, cm.rand_bbox = rand_spy, beta_spy, bbox_spy
+    try:
+        for name, cls, cfgd in (("mixup", GPUSelectiveMixup, {"PROB": 1.0, "ALPHA": 0.4, "meta_chunk_bounds_list": bounds}),
+                                ("cutmix", GPUSelectiveCutMix, {"PROB": 1.0, "ALPHA": 1.0, "meta_chunk_bounds_list": bounds})):
+            torch.manual_seed(SEED + (3 if name == "mixup" else 5))
+            import random as _r
+            _r.seed(SEED)
+            op = cls(cfgd, config=None)
+            perm_holder = {}
+            orig_perm = op._get_ingroup_permutation
+
+            def perm_spy(gi, _o=orig_perm, _h=perm_holder):
+                p_ = _o(gi)
+                _h["perm"] = p_.clone()
+                return p_
+
+            op._get_ingroup_permutation = perm_spy
+            out = op((images.clone(), {k: v.clone() for k, v in targets.items()}, aux.clone(), masks.clone(), gids.clone()), exclude_null_samples=True)
+            rec[f"{name}_perm"] = perm_holder["perm"].numpy()
+            rec[f"{name}_lam"] = np.float64(draws["lam"])
+            rec[f"{name}_pick"] = draws["pick"].numpy()
+            if name == "cutmix":
+                rec["cutmix_box"] = np.array(draws["box"])
+            rec[f"{name}_images"] = out[0].numpy()
+            for t, _ in tasks:
+                rec[f"{name}_target_{t}"] = out[1][t].numpy()
+            rec[f"{name}_aux"] = out[2].numpy()
+            rec[f"{name}_masks"] = out[3].numpy()
+            print(f"[collate/{name}] lam {draws['lam']:.4f} perm {perm_holder['perm'].tolist()} box {draws.get('box')}")
+    finally:
+        torch.rand, torch.distributions.beta.Beta.sample, cm.rand_bbox = orig_rand, orig_beta, orig_bbox
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -499,6 +580,8 @@ def main():
         hier_loss_known_answers()
     if want("muon"):
         muon_known_answers()
+    if want("collate"):
+        collate_known_answers()
 
 
 if __name__ == "__main__":
