@@ -15,6 +15,7 @@
 // (thread = (channel lane 0..31, row 0..7)); LDS 14 x 22 x 32 fp32 = 38.5 KiB + 6 KiB taps.
 #include "common.hpp"
 #include "../../include/lnx.h"
+#include "dwconv_mfma.hpp"
 
 namespace {
 
@@ -88,6 +89,15 @@ __device__ __forceinline__ void halo_commit(float* __restrict__ tile, const type
     }
 }
 
+// Diagnostic build only (-DDW_STAMP, tools/build_stamp.sh): per-phase s_memtime sums of wave 0 of workgroup 0
+#ifdef DW_STAMP
+__device__ unsigned long long g_dw_stamp[8];
+#define DW_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                     __builtin_amdgcn_sched_barrier(0); tsum[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define DW_T(i) do { } while (0)
+#endif
+
 template <typename TX, typename TY, bool FLIP>
 __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
     __shared__ __attribute__((aligned(16))) float tile[IH * IW * CB];
@@ -114,10 +124,15 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
     halo_commit<TX>(tile, pre);
     __syncthreads();
 
+#ifdef DW_STAMP
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     for (int t = t_begin; t < t_end; ++t) {
         const TilePos q = tile_pos(t, p.tiles_h, p.tiles_w);
         const bool more = t + 1 < t_end;
         if (more) halo_issue<TX>(pre, xg, tile_pos(t + 1, p.tiles_h, p.tiles_w), c0, p.H, p.W, p.C);
+        DW_T(0);
 
         float acc[TW];
 #pragma unroll
@@ -136,6 +151,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx) acc[j] = fmaf(wv[kx], in[j + kx], acc[j]);
         }
+        DW_T(1);
         const int h = q.h0 + r;
         if (h < p.H) {
             const int64_t off0 = (((int64_t)q.b * p.H + h) * p.W + q.w0) * p.C + c;
@@ -152,13 +168,25 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwP p) {
             for (int j = 0; j < TW; ++j)
                 if (q.w0 + j < p.W) reinterpret_cast<TY*>(p.y)[off0 + (int64_t)j * p.C] = from_f<TY>(acc[j]);
         }
+        DW_T(2);
         __syncthreads();  // every wave is done reading this tile
+        DW_T(3);
         if (more) {
             halo_commit<TX>(tile, pre);
+            DW_T(4);
             __syncthreads();
+            DW_T(5);
         }
     }
+#ifdef DW_STAMP
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_dw_stamp[i] = tsum[i];
+#endif
 }
+
+#ifdef DW_STAMP
+extern "C" int lnx_dbg_dwconv_stamps(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_stamp), 64); }
+#endif
 
 struct DwWgP {
     const void* x;
@@ -278,6 +306,9 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const DwWgP p) {
 extern "C" int lnx_dwconv7_fwd(const lnx_dwconv_args* a, void* stream) {
     LNX_CHECK(a && a->x && a->w49 && a->y, "lnx_dwconv7_fwd: null operand");
     LNX_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->C % CB == 0, "lnx_dwconv7_fwd: bad shape B=%d H=%d W=%d C=%d (C %% 32)", a->B, a->H, a->W, a->C);
+    // bf16 compute: the matrix-core kernels (dwconv_mfma.hip); fp32 (strict-parity mode) stays on the VALU kernels below
+    if (lnx_dwconv_mfma_enabled() && (a->x_dtype == LNX_BF16 || a->y_dtype == LNX_BF16) && !(a->res && a->y_dtype != LNX_F32))
+        return lnx_dwconv7_mfma_fwd(a, (hipStream_t)stream);
     DwP p;
     p.x = a->x; p.w49 = a->w49; p.bias = a->bias; p.res = a->res; p.y = a->y;
     p.B = a->B; p.H = a->H; p.W = a->W; p.C = a->C; p.flip = a->flip;
@@ -312,6 +343,7 @@ extern "C" int lnx_dwconv7_fwd(const lnx_dwconv_args* a, void* stream) {
 extern "C" int lnx_dwconv7_wgrad(const lnx_dwconv_wgrad_args* a, void* stream) {
     LNX_CHECK(a && a->x && a->dy && a->dw, "lnx_dwconv7_wgrad: null operand");
     LNX_CHECK(a->B > 0 && a->H > 0 && a->W > 0 && a->C > 0 && a->C % CB == 0, "lnx_dwconv7_wgrad: bad shape");
+    if (lnx_dwconv_mfma_enabled() && (a->x_dtype == LNX_BF16 || a->dy_dtype == LNX_BF16)) return lnx_dwconv7_mfma_wgrad(a, (hipStream_t)stream);
     DwWgP p;
     p.x = a->x; p.dy = a->dy; p.dw = a->dw; p.db = a->db;
     p.B = a->B; p.H = a->H; p.W = a->W; p.C = a->C;

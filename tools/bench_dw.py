@@ -1,4 +1,4 @@
-"""A/B timing of the depthwise 7x7 kernels at the bench shapes (env LNX_DWCONV_V1 selects round 1's kernel)."""
+"""A/B timing of the depthwise 7x7 kernels at the bench shapes (env LNX_DWCONV_VALU=1 selects the VALU kernels instead of the MFMA ones)."""
 import sys, torch
 sys.path.insert(0, ".")
 from linnaeus_amd import ops
@@ -24,7 +24,8 @@ for (B, H, C) in ((256, 56, 96), (256, 28, 192)):
     g = torch.randn(B, H, H, C, device="cuda")
     dw = torch.zeros(C, 1, 7, 7, device="cuda"); db = torch.zeros(C, device="cuda")
     n = B * H * H * C
-    tf = t(lambda: ops.dwconv7(x, w49(w), b, y))
-    tb = t(lambda: ops.dwconv7(dy, w49(w), None, g, flip=True, res=g))
+    wt = w49(w)
+    tf = t(lambda: ops.dwconv7(x, wt, b, y))
+    tb = t(lambda: ops.dwconv7(dy, wt, None, g, flip=True, res=g))
     tw = t(lambda: ops.dwconv7_wgrad(x, dy, dw, db))
     print(f"B={B} H={H} C={C}: fwd {tf:7.1f} us ({n * 6 / tf / 1e3:6.0f} GB/s)  dgrad {tb:7.1f} us ({n * 10 / tb / 1e3:6.0f} GB/s)  wgrad {tw:7.1f} us ({n * 6 / tw / 1e3:6.0f} GB/s)")
