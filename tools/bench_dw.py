@@ -1,6 +1,7 @@
 """A/B timing of the depthwise 7x7 kernels at the bench shapes (env LNX_DWCONV_VALU=1 selects the VALU kernels instead of the MFMA ones)."""
 import sys, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from linnaeus_amd import ops
 
 def w49(w):

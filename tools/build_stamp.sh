@@ -5,6 +5,7 @@ cd "$(dirname "$0")/../linnaeus_amd/csrc"
 mkdir -p ../../gpurun_out
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DCW_STAMP -c convmlp_wgrad.hip -o /tmp/convmlp_wgrad_stamp.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DDW_STAMP -c dwconv.hip -o /tmp/dwconv_stamp.o
-OBJS=$(ls *.o | grep -v convmlp_wgrad.o | grep -v dwconv.o)
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS /tmp/convmlp_wgrad_stamp.o /tmp/dwconv_stamp.o -o ../../tools/libstamp.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DDW_STAMP -c dwconv_mfma.hip -o /tmp/dwconv_mfma_stamp.o
+OBJS=$(ls *.o | grep -v convmlp_wgrad.o | grep -v dwconv.o | grep -v dwconv_mfma.o)
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS /tmp/convmlp_wgrad_stamp.o /tmp/dwconv_stamp.o /tmp/dwconv_mfma_stamp.o -o ../../tools/libstamp.so
 echo built tools/libstamp.so
