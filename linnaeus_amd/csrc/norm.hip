@@ -87,7 +87,11 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <typename TX, typename TY, int G, int V, int PAIR = 1>
+// FULL: C / 4 == G * V, every slot of every lane is a column (all the model's widths).  The loads are unconditional
+// either way (a slot beyond the row reads column 0 and is zeroed afterwards): a load under a branch whose result is
+// merged with a zero is waited for on the spot (s_waitcnt vmcnt(0) right behind it), which turns the V loads of a row
+// into V serial round trips.  gamma / beta live in registers for the whole kernel for the same reason.
+template <typename TX, typename TY, int G, int V, int PAIR = 1, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
     constexpr int R = 64 / G;  // rows per wave
     const int lane = threadIdx.x & 63;
@@ -95,31 +99,47 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
     const int sub = lane % G, rw = lane / G;
     const int nvec = p.C >> 2;
     const float invC = 1.0f / (float)p.C;
+    int col[V];   // first element of slot i (clamped to 0 beyond the row)
+    bool ok[V];
+    float4 wv[V], bv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c4 = cidx<G, PAIR>(sub, i);
+        ok[i] = FULL || c4 < nvec;
+        col[i] = ok[i] ? 4 * c4 : 0;
+        wv[i] = *reinterpret_cast<const float4*>(p.w + col[i]);
+        bv[i] = *reinterpret_cast<const float4*>(p.b + col[i]);
+    }
     for (int m0 = (blockIdx.x * 4 + wave) * R; m0 < p.M; m0 += gridDim.x * 4 * R) {
         const int m = m0 + rw;
         const bool rv = m < p.M;
         const int mc = rv ? m : p.M - 1;
         const TX* xr = reinterpret_cast<const TX*>(p.x) + map_row(p.xmap, mc) * p.ldx;
-        float4 v[V];
-        float sum = 0.f;
+        float4 v[V], av[V];
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
-            const int c4 = cidx<G, PAIR>(sub, i);
+            if constexpr (PAIR == 2) load4x2<TX>(xr + col[i], v[i], v[i + 1]);
+            else v[i] = load4<TX>(xr + col[i]);
+        }
+        if (p.add) {  // uniform
+            const TX* ar = reinterpret_cast<const TX*>(p.add) + (int64_t)mc * p.ldadd;
 #pragma unroll
-            for (int q = 0; q < PAIR; ++q) v[i + q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c4 < nvec) {
-                if constexpr (PAIR == 2) load4x2<TX>(xr + 4 * c4, v[i], v[i + 1]);
-                else v[i] = load4<TX>(xr + 4 * c4);
-#pragma unroll
-                for (int q = 0; q < PAIR; ++q) sum += (v[i + q].x + v[i + q].y) + (v[i + q].z + v[i + q].w);
+            for (int i = 0; i < V; i += PAIR) {
+                if constexpr (PAIR == 2) load4x2<TX>(ar + col[i], av[i], av[i + 1]);
+                else av[i] = load4<TX>(ar + col[i]);
             }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            if (!ok[i]) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         const float mu = group_sum<G>(sum) * invC;
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c4 = cidx<G, PAIR>(sub, i);
-            if (c4 < nvec) {
+            if (ok[i]) {
                 v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
                 sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
             }
@@ -131,24 +151,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
             if (p.rstd) p.rstd[m] = rs;
         }
         TY* yr = reinterpret_cast<TY*>(p.y) + map_row(p.ymap, m) * p.ldy;
-        const TX* ar = p.add ? reinterpret_cast<const TX*>(p.add) + (int64_t)m * p.ldadd : nullptr;
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
-            const int c4 = cidx<G, PAIR>(sub, i);
-            if (c4 < nvec) {
+            if (ok[i]) {
                 float4 o[PAIR];
 #pragma unroll
                 for (int q = 0; q < PAIR; ++q) {
-                    const float4 w = *reinterpret_cast<const float4*>(p.w + 4 * (c4 + q));
-                    const float4 b = *reinterpret_cast<const float4*>(p.b + 4 * (c4 + q));
+                    const float4 w = wv[i + q], b = bv[i + q];
                     o[q] = make_float4(v[i + q].x * rs * w.x + b.x, v[i + q].y * rs * w.y + b.y, v[i + q].z * rs * w.z + b.z, v[i + q].w * rs * w.w + b.w);
-                    if (ar) {
-                        const float4 a = load4<TX>(ar + 4 * (c4 + q));
-                        o[q].x += a.x; o[q].y += a.y; o[q].z += a.z; o[q].w += a.w;
+                    if (p.add) {
+                        o[q].x += av[i + q].x; o[q].y += av[i + q].y; o[q].z += av[i + q].z; o[q].w += av[i + q].w;
                     }
                 }
-                if constexpr (PAIR == 2) store4x2<TY>(yr + 4 * c4, o[0], o[1]);
-                else store4<TY>(yr + 4 * c4, o[0]);
+                if constexpr (PAIR == 2) store4x2<TY>(yr + col[i], o[0], o[1]);
+                else store4<TY>(yr + col[i], o[0]);
             }
         }
     }
@@ -177,7 +193,7 @@ struct LnBwdP {
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd
 // dw += sum_m dy * xhat,  db += sum_m dy
-template <typename TDY, typename TX, typename TDX, int G, int V, int PAIR = 1>
+template <typename TDY, typename TX, typename TDX, int G, int V, int PAIR = 1, bool FULL = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
     constexpr int R = 64 / G;
     __shared__ float red[4][G * V * 4];
@@ -187,11 +203,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
     const int nvec = p.C >> 2;
     const float invC = 1.0f / (float)p.C;
     float4 adw[V], adb[V], wv[V];
+    int col[V];   // first element of slot i (clamped to 0 beyond the row); loads are unconditional, see ln_fwd_kernel
+    bool ok[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        adw[i] = adb[i] = wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        adw[i] = adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c4 = cidx<G, PAIR>(sub, i);
-        if (c4 < nvec) wv[i] = *reinterpret_cast<const float4*>(p.w + 4 * c4);
+        ok[i] = FULL || c4 < nvec;
+        col[i] = ok[i] ? 4 * c4 : 0;
+        wv[i] = *reinterpret_cast<const float4*>(p.w + col[i]);
     }
 
     for (int m0 = (blockIdx.x * 4 + wave) * R; m0 < p.M; m0 += gridDim.x * 4 * R) {
@@ -205,26 +225,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         float4 xh[V], g[V];
         unsigned pos[V];  // bit j: x element j > 0 (ReLU mask)
         float s1 = 0.f, s2 = 0.f;
-        float4 xraw[V], draw[V];
+        float4 xraw[V], draw[V], gv[V];
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
-            const int c4 = cidx<G, PAIR>(sub, i);
-            if (c4 < nvec) {
-                if constexpr (PAIR == 2) {
-                    load4x2<TX>(xr + 4 * c4, xraw[i], xraw[i + 1]);
-                    load4x2<TDY>(dr + 4 * c4, draw[i], draw[i + 1]);
-                } else {
-                    xraw[i] = load4<TX>(xr + 4 * c4);
-                    draw[i] = load4<TDY>(dr + 4 * c4);
-                }
+            if constexpr (PAIR == 2) {
+                load4x2<TX>(xr + col[i], xraw[i], xraw[i + 1]);
+                load4x2<TDY>(dr + col[i], draw[i], draw[i + 1]);
+            } else {
+                xraw[i] = load4<TX>(xr + col[i]);
+                draw[i] = load4<TDY>(dr + col[i]);
             }
+        }
+        if (p.gin) {  // uniform
+            const float* gi = p.gin + xrow * p.ldgin;
+#pragma unroll
+            for (int i = 0; i < V; ++i) gv[i] = *reinterpret_cast<const float4*>(gi + col[i]);
         }
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            const int c4 = cidx<G, PAIR>(sub, i);
             xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             pos[i] = 0;
-            if (c4 < nvec) {
+            if (ok[i]) {
                 const float4 xv = xraw[i];
                 float4 dv = draw[i];
                 if (!rv) dv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,19 +262,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
         const float m2 = group_sum<G>(s2) * invC;
         if (!rv) continue;
         TDX* ox = reinterpret_cast<TDX*>(p.dx) + xrow * p.lddx;
-        const float* gi = p.gin ? p.gin + xrow * p.ldgin : nullptr;
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
-            const int c4 = cidx<G, PAIR>(sub, i);
-            if (c4 < nvec) {
+            const int c4 = col[i] >> 2;
+            if (ok[i]) {
                 float4 ov[PAIR];
 #pragma unroll
                 for (int q = 0; q < PAIR; ++q) {
                     const int k = i + q;
                     float4 o = make_float4(rs * (g[k].x - m1 - xh[k].x * m2), rs * (g[k].y - m1 - xh[k].y * m2),
                                            rs * (g[k].z - m1 - xh[k].z * m2), rs * (g[k].w - m1 - xh[k].w * m2));
-                    if (gi) {
-                        const float4 a = *reinterpret_cast<const float4*>(gi + 4 * (c4 + q));
+                    if (p.gin) {
+                        const float4 a = gv[k];
                         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
                     }
                     if (p.relu_mask) {
@@ -380,10 +400,10 @@ void launch_fwd(const LnP& p, hipStream_t st) {
             int grid = cdiv(p.M, 4 * (64 / g2));
             if (grid > 4096) grid = 4096;
             const dim3 gg(grid), bb(256);
-            if (g2 == 4) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 4, 6, 2>), gg, bb, 0, st, p);
-            else if (g2 == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 6, 2>), gg, bb, 0, st, p);
-            else if (g2 == 16) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 6, 2>), gg, bb, 0, st, p);
-            else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 6, 2>), gg, bb, 0, st, p);
+            if (g2 == 4) { if (p.C / 4 == 4 * 6) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 4, 6, 2, true>), gg, bb, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 4, 6, 2, false>), gg, bb, 0, st, p); }
+            else if (g2 == 8) { if (p.C / 4 == 8 * 6) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 6, 2, true>), gg, bb, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 6, 2, false>), gg, bb, 0, st, p); }
+            else if (g2 == 16) { if (p.C / 4 == 16 * 6) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 6, 2, true>), gg, bb, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 6, 2, false>), gg, bb, 0, st, p); }
+            else { if (p.C / 4 == 32 * 6) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 6, 2, true>), gg, bb, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 6, 2, false>), gg, bb, 0, st, p); }
             return;
         }
     }
@@ -391,11 +411,11 @@ void launch_fwd(const LnP& p, hipStream_t st) {
     int grid = cdiv(p.M, rows_per_wg);
     if (grid > 4096) grid = 4096;
     const dim3 g(grid), b(256);
-    if (V == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8>), g, b, 0, st, p);
-    else if (G == 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3>), g, b, 0, st, p);
-    else if (G == 16) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3>), g, b, 0, st, p);
-    else if (G == 32) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 3>), g, b, 0, st, p);
+    if (V == 8) { if (p.C / 4 == 64 * 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, false>), g, b, 0, st, p); }
+    else if (G == 8) { if (p.C / 4 == 8 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, false>), g, b, 0, st, p); }
+    else if (G == 16) { if (p.C / 4 == 16 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, false>), g, b, 0, st, p); }
+    else if (G == 32) { if (p.C / 4 == 32 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3, 1, false>), g, b, 0, st, p); }
+    else { if (p.C / 4 == 64 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 3, 1, false>), g, b, 0, st, p); }
 }
 
 constexpr int LN_WS_WGS = 2048;  // workgroups the partial-sum workspace is sized for
@@ -430,19 +450,19 @@ void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats) {
         const int g2 = pick_pair_g(p.C);
         if (g2 && (((uintptr_t)p.x | (uintptr_t)p.dy | (uintptr_t)p.dx) & 15) == 0 && (p.ldx * 2) % 16 == 0 && (p.lddy * 2) % 16 == 0 && (p.lddx * sizeof(TDX)) % 16 == 0) {
             // same grid: the partial-sum workspace is indexed by workgroup, rows are walked grid-stride
-            if (g2 == 4) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 4, 6, 2>), g, b, 0, st, p);
-            else if (g2 == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 6, 2>), g, b, 0, st, p);
-            else if (g2 == 16) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 6, 2>), g, b, 0, st, p);
-            else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 6, 2>), g, b, 0, st, p);
+            if (g2 == 4) { if (p.C / 4 == 4 * 6) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 4, 6, 2, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 4, 6, 2, false>), g, b, 0, st, p); }
+            else if (g2 == 8) { if (p.C / 4 == 8 * 6) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 6, 2, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 6, 2, false>), g, b, 0, st, p); }
+            else if (g2 == 16) { if (p.C / 4 == 16 * 6) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 6, 2, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 6, 2, false>), g, b, 0, st, p); }
+            else { if (p.C / 4 == 32 * 6) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 6, 2, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 6, 2, false>), g, b, 0, st, p); }
             launched = true;
         }
     }
     if (launched) {
-    } else if (V == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8>), g, b, 0, st, p);
-    else if (G == 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3>), g, b, 0, st, p);
-    else if (G == 16) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3>), g, b, 0, st, p);
-    else if (G == 32) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3>), g, b, 0, st, p);
-    else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3>), g, b, 0, st, p);
+    } else if (V == 8) { if (p.C / 4 == 64 * 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8, 1, false>), g, b, 0, st, p); }
+    else if (G == 8) { if (p.C / 4 == 8 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3, 1, false>), g, b, 0, st, p); }
+    else if (G == 16) { if (p.C / 4 == 16 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3, 1, false>), g, b, 0, st, p); }
+    else if (G == 32) { if (p.C / 4 == 32 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3, 1, false>), g, b, 0, st, p); }
+    else { if (p.C / 4 == 64 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3, 1, false>), g, b, 0, st, p); }
     if (p.part) {
         const int slices = grid >= 64 ? 64 : 1;
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * p.C, 256), slices), dim3(256), 0, st, p.part, grid, p.C, p.dw, p.db);
