@@ -58,26 +58,51 @@ __device__ __forceinline__ uint2 tr_read(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-// Load one 16-byte chunk (EPV consecutive head channels starting at d0) of token n for the
-// given operand column base; optionally multiply pairwise by cos and by `scale`.
+// One 16-byte chunk (EPV consecutive head channels starting at d0) of token n for the given operand column base,
+// optionally multiplied pairwise by cos and by `scale`.  Split in two so that a caller can issue every fetch of a
+// batch before the first use: fetch() is unconditional (a row beyond N reads row N - 1, a class token reads the first
+// cos row) -- a load under `if (n < N)` whose result is merged with a zero is waited for on the spot, which turns a
+// staging loop into one memory round trip per chunk.
+template <typename T, bool COS> struct Chunk {
+    uint4 raw;
+    float cf[COS ? TT<T>::EPV / 2 : 1];
+    __device__ __forceinline__ void fetch(const T* __restrict__ base, int64_t ld, int n, int N, int E, int d0, const float* __restrict__ cos_tab, int heads, int head) {
+        const int nc = min(n, N - 1);
+        raw = ld16(base + (int64_t)nc * ld + d0);
+        if constexpr (COS) {
+            const float* cp = cos_tab + ((int64_t)max(nc - E, 0) * heads + head) * 32 + (d0 >> 1);
+            if constexpr (TT<T>::EPV == 8) {
+                const float4 c4 = *reinterpret_cast<const float4*>(cp);
+                cf[0] = c4.x; cf[1] = c4.y; cf[2] = c4.z; cf[3] = c4.w;
+            } else {
+                const float2 c2 = *reinterpret_cast<const float2*>(cp);
+                cf[0] = c2.x; cf[1] = c2.y;
+            }
+        }
+    }
+    __device__ __forceinline__ uint4 value(int n, int N, int E, float scale) const {
+        if (n >= N) return make_uint4(0, 0, 0, 0);
+        Vec16<T> v;
+        v.raw = raw;
+        if constexpr (COS) {
+            constexpr int EPV = TT<T>::EPV;
+            if (n >= E) {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * cf[j >> 1] * scale);
+            } else if (scale != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * scale);
+            }
+        }
+        return v.raw;
+    }
+};
 template <typename T, bool COS>
 __device__ __forceinline__ uint4 load_chunk(const T* __restrict__ base, int64_t ld, int n, int N, int E, int d0, const float* __restrict__ cos_tab,
                                             int heads, int head, float scale) {
-    if (n >= N) return make_uint4(0, 0, 0, 0);
-    Vec16<T> v;
-    v.raw = ld16(base + (int64_t)n * ld + d0);
-    if constexpr (COS) {
-        constexpr int EPV = TT<T>::EPV;
-        if (n >= E) {
-            const float* cp = cos_tab + ((int64_t)(n - E) * heads + head) * 32 + (d0 >> 1);
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * cp[j >> 1] * scale);
-        } else if (scale != 1.0f) {
-#pragma unroll
-            for (int j = 0; j < EPV; ++j) v.set(j, v.get(j) * scale);
-        }
-    }
-    return v.raw;
+    Chunk<T, COS> c;
+    c.fetch(base, ld, n, N, E, d0, cos_tab, heads, head);
+    return c.value(n, N, E, scale);
 }
 
 // Stage a 64-row tile (tokens n0..n0+63) into LDS: swizzled row image (16-byte fragment
@@ -99,8 +124,11 @@ __device__ __forceinline__ void stage_tile(unsigned char* rowimg, unsigned char*
 template <typename T, bool COS>
 __device__ __forceinline__ void load_row_frag(uint4 (&f)[AT<T>::NKK], const T* __restrict__ base, int64_t ld, int n, int N, int E, int g,
                                               const float* __restrict__ cos_tab, int heads, int head, float scale) {
+    Chunk<T, COS> c[AT<T>::NKK];
 #pragma unroll
-    for (int kk = 0; kk < AT<T>::NKK; ++kk) f[kk] = load_chunk<T, COS>(base, ld, n, N, E, (kk * 4 + g) * AT<T>::EPV, cos_tab, heads, head, scale);
+    for (int kk = 0; kk < AT<T>::NKK; ++kk) c[kk].fetch(base, ld, n, N, E, (kk * 4 + g) * AT<T>::EPV, cos_tab, heads, head);
+#pragma unroll
+    for (int kk = 0; kk < AT<T>::NKK; ++kk) f[kk] = c[kk].value(n, N, E, scale);
 }
 
 // acc[t] (t = 0..3, 16 rows each) = Rows(img, row0 + 16 t + s) . frag^T over the 64 channels
@@ -492,11 +520,25 @@ __device__ __forceinline__ void stage_all(unsigned char* rowimg, unsigned char* 
                                           const float* __restrict__ cos_tab, int heads, int head, float scale) {
     constexpr int NCH = AT<T>::NCH;
     constexpr int EPV = AT<T>::EPV;
-    for (int i = threadIdx.x; i < nrows_pad * NCH; i += blockDim.x) {
-        const int r = i / NCH, c = i % NCH;
-        const uint4 v = load_chunk<T, COS>(base, ld, r, N, E, c * EPV, cos_tab, heads, head, scale);
-        if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
-        if constexpr (TRIMG) st16(trimg + r * AT<T>::TRB + c * 16, v);
+    constexpr int UN = 4;  // chunks in flight per thread (N <= 256: the whole operand in one batch of 512 threads)
+    const int total = nrows_pad * NCH;
+    for (int i0 = threadIdx.x; i0 < total; i0 += UN * blockDim.x) {
+        Chunk<T, COS> ch[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = min(i0 + u * (int)blockDim.x, total - 1);
+            ch[u].fetch(base, ld, i / NCH, N, E, (i % NCH) * EPV, cos_tab, heads, head);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < total) {
+                const int r = i / NCH, c = i % NCH;
+                const uint4 v = ch[u].value(r, N, E, scale);
+                if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
+                if constexpr (TRIMG) st16(trimg + r * AT<T>::TRB + c * 16, v);
+            }
+        }
     }
 }
 
