@@ -670,7 +670,8 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
     WgradP p = p0;
     // tile orientation with the least padding waste
     auto waste = [&](int rw, int cw) { return (double)cdiv(p.N, rw) * rw * cdiv(p.K, cw) * cw; };
-    const bool wide_r = waste(256, 128) <= waste(128, 256);
+    static const char* force = getenv("LNX_TN_ORIENT");  // A/B switch: "r" = 256x128 tiles, "c" = 128x256
+    const bool wide_r = force ? force[0] == 'r' : waste(256, 128) <= waste(128, 256);
     const int RW = wide_r ? 256 : 128, CW = wide_r ? 128 : 256;
     p.tiles_n = cdiv(p.N, RW);
     p.tiles_k = cdiv(p.K, CW);
