@@ -38,6 +38,17 @@ def predicted_bytes(model, batch: int, img_size: Optional[int] = None, *, mode: 
     return ws + fixed + io
 
 
+def foreign_bytes(model) -> int:
+    """Device bytes currently allocated that are NOT this model's parameters, gradients or buffers (other models, data
+    loaders, a previous phase's tensors): they count against the memory budget but are not part of predicted_bytes."""
+    m = getattr(model, "module", model)
+    m.release_plans()
+    dev = next(m.parameters()).device
+    own = sum(p.numel() * p.element_size() + (p.grad.numel() * p.grad.element_size() if p.grad is not None else 0) for p in m.parameters())
+    own += sum(b.numel() * b.element_size() for b in m.buffers())
+    return max(0, torch.cuda.memory_allocated(dev) - own)
+
+
 def auto_find_batch_size(model, config, mode: str, *, optimizer_main=None, criteria_train=None, grad_weighting_main=None, scaler_main=None,
                          criteria_val=None, target_memory_fraction: float, max_batch_size: int, min_batch_size: int = 1, steps_per_trial: int = 3,
                          log_level: str = "INFO", step_fn: Optional[Callable[[Any, int], None]] = None) -> int:
@@ -65,11 +76,13 @@ def _search(model, config, mode, frac, hi, lo, steps, log, step_fn) -> int:
         return lo
     total = torch.cuda.get_device_properties(dev).total_memory
     budget = total * frac
+    torch.cuda.empty_cache()
+    other = foreign_bytes(m)  # what everybody else holds on the device counts against the budget too
     img = int(config.MODEL.IMG_SIZE) if config is not None else m.img_size[0]
     best, low, high = lo, lo, hi
     while low <= high:  # analytic binary search: predicted_bytes is monotone in the batch size
         mid = (low + high) // 2
-        need = predicted_bytes(m, mid, img, mode=mode)
+        need = predicted_bytes(m, mid, img, mode=mode) + other
         if need <= budget:
             best, low = mid, mid + 1
         else:
