@@ -68,8 +68,9 @@ struct Stage {
     static constexpr int NPU = (NU + NTHR - 1) / NTHR;
     uint4 p0[NPU], p1[NPU];
     u32 goff[NPU];  // byte offset of the unit's first pixel from the tile's first staged pixel (unsigned: scalar base + 32-bit lane offset addressing)
-    int loff[NPU];  // LDS byte offset of its first channel plane
     int rc[NPU];    // row | first column << 8; -1: idle unit of the last round
+    int cgoff;      // LDS byte offset of this thread's first channel plane (the same for all its units: NTHR % NCG == 0)
+    static_assert(NTHR % NCG == 0, "one channel group per thread");
 
     __device__ __forceinline__ void init(int W, int C) {
 #pragma unroll
@@ -78,7 +79,7 @@ struct Stage {
             const int cg = u % NCG, cp = (u / NCG) % CPAIRS, row = u / (NCG * CPAIRS);
             const bool on = u < NU;
             goff[k] = on ? (u32)((row * W + 2 * cp) * C + cg * CH) * (u32)sizeof(T) : 0u;
-            loff[k] = on ? cg * CH * PLANE + row * PITCH + cp * 4 : 0;
+            cgoff = cg * CH * PLANE;
             rc[k] = on ? (row | (2 * cp) << 8) : -1;
         }
     }
@@ -123,7 +124,7 @@ struct Stage {
 #pragma unroll
         for (int k = 0; k < NPU; ++k) {
             if (NTHR * (k + 1) <= NU || rc[k] >= 0) {
-                char* d = dst + loff[k];
+                char* d = dst + cgoff + (rc[k] & 255) * PITCH + (rc[k] >> 8) * 2;
                 if constexpr (sizeof(T) == 4) {
                     const float* f0 = reinterpret_cast<const float*>(&p0[k]);
                     const float* f1 = reinterpret_cast<const float*>(&p1[k]);
@@ -591,6 +592,7 @@ int lnx_dwconv7_mfma_fwd(const lnx_dwconv_args* a, hipStream_t st) {
     MfP p;
     p.x = a->x; p.w49 = a->w49; p.bias = a->bias; p.res = a->res; p.y = a->y;
     p.B = a->B; p.H = a->H; p.W = a->W; p.C = a->C;
+    const int code = a->x_dtype * 2 + a->y_dtype + (a->flip ? 4 : 0);
     p.tiles_h = cdiv(a->H, MT); p.tiles_w = cdiv(a->W, MT);
     const int64_t ntile = (int64_t)a->B * p.tiles_h * p.tiles_w;
     LNX_CHECK(ntile < (1ll << 31), "lnx_dwconv7_fwd: too many tiles");
@@ -604,7 +606,6 @@ int lnx_dwconv7_mfma_fwd(const lnx_dwconv_args* a, hipStream_t st) {
     p.chunks = cdiv(p.ntile, p.tiles_per_wg);
     const int grid = p.chunks * cblocks;
     LNX_CHECK(!(a->res && a->y_dtype != LNX_F32), "lnx_dwconv7_fwd: a residual needs an fp32 output");
-    const int code = a->x_dtype * 2 + a->y_dtype + (a->flip ? 4 : 0);
     int rc = 0;
     switch (code) {
         case 1: rc = launch_fwd<float, bf16_t, false>(p, grid, st); break;

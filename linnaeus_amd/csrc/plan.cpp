@@ -503,7 +503,9 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.ln = share ? f.ln : cv.take(M * C * esz);
             k.mean = share ? f.mean : cv.take(M * 4);
             k.rstd = share ? f.rstd : cv.take(M * 4);
-            k.fused = lnx_convmlp_supported(c.dtype, (int)C) != 0 && getenv("LNX_NO_FUSED_MLP") == nullptr;
+            // LNX_NO_FUSED_MLP: every conv block on two GEMMs; LNX_FUSED_MLP_MAXC=n: only blocks with C <= n fused (A/B switches)
+            k.fused = lnx_convmlp_supported(c.dtype, (int)C) != 0 && getenv("LNX_NO_FUSED_MLP") == nullptr &&
+                      (getenv("LNX_FUSED_MLP_MAXC") == nullptr || C <= atoi(getenv("LNX_FUSED_MLP_MAXC")));
             any_fused = any_fused || k.fused;
             if (!k.fused) {
                 k.hpre = share ? f.hpre : cv.take(M * 4 * C * esz);
