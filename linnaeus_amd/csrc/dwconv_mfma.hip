@@ -451,7 +451,7 @@ struct MwP {
     float* dw;
     float* db;
     int B, H, W, C;
-    int tiles_h, tiles_w, nwalk, ntile;
+    int tiles_h, tiles_w, nwalk, per, ntile;  // walkers per 32-channel group, tiles per walker
 };
 
 template <typename TX, typename TDY>
@@ -464,9 +464,10 @@ __global__ __launch_bounds__(WT, 4) void dwconv7_mfma_wgrad_kernel(const MwP p) 
     typedef Stage<TDY, WT, WCB, WH, WW / 2, WD_PITCH, WD_PLANE> Sd;
     int pair, half;
     pair_of(pair, half);
-    const int groups = p.C / (2 * WCB), nwalk = p.nwalk;
-    if (pair >= nwalk * groups) return;  // grid padding
+    const int groups = p.C / (2 * WCB);
+    if (pair >= p.nwalk * groups) return;  // grid padding
     const int walker = pair / groups;
+    const int t_begin = walker * p.per, t_end = min(p.ntile, t_begin + p.per);  // a contiguous run of tiles (row-major)
     const int c0 = (2 * (pair % groups) + half) * WCB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 15, g = lane >> 4;
@@ -482,15 +483,18 @@ __global__ __launch_bounds__(WT, 4) void dwconv7_mfma_wgrad_kernel(const MwP p) 
     Sd sd;
     sx.init(p.W, p.C);
     sd.init(p.W, p.C);
+    TileCursor cq;  // the tile being fetched
     {
-        const TileAt q = tile_at(walker, p.tiles_h, p.tiles_w, WH, WW);
-        sx.issue(xg, q.b, q.h0 - 3, q.w0 - 3, p.H, p.W, p.C, walker < p.ntile);
-        sd.issue(dg, q.b, q.h0, q.w0, p.H, p.W, p.C, walker < p.ntile);
+        const TileAt q = tile_at(t_begin, p.tiles_h, p.tiles_w, WH, WW);
+        cq.b = q.b; cq.h0 = q.h0; cq.w0 = q.w0;
+        sx.issue(xg, q.b, q.h0 - 3, q.w0 - 3, p.H, p.W, p.C, t_begin < t_end);
+        sd.issue(dg, q.b, q.h0, q.w0, p.H, p.W, p.C, t_begin < t_end);
+        cq.step(p.H, p.W, WH, WW);
     }
     zero_lds<WT>(smem, WX_BYTES + WD_BYTES);
     if (threadIdx.x < WCB) dbl[threadIdx.x] = 0.f;
     __syncthreads();
-    if (walker < p.ntile) {
+    if (t_begin < t_end) {
         sx.commit(xt);
         sd.commit(dt + 7 * WD_PITCH);
         sd.add_channel_sums(dbs);
@@ -502,22 +506,38 @@ __global__ __launch_bounds__(WT, 4) void dwconv7_mfma_wgrad_kernel(const MwP p) 
     const u32 shift = (kk & 1) * 16;
     const char* xa0 = xt + (CPW * wave + ch) * WX_PLANE + 16 * g + 2 * (kk & ~1);
     const char* db0 = dt + (CPW * wave + ch) * WD_PLANE + (7 - kk) * WD_PITCH + 16 * g;
+    constexpr int NL = Sx::NLOAD + Sd::NLOAD;
+    static_assert(2 * NL <= WXR, "one fetch every other input row");
 
-    for (int t = walker; t < p.ntile; t += nwalk) {
-        const bool more = t + nwalk < p.ntile;
-        {
-            const TileAt qn = tile_at(t + nwalk, p.tiles_h, p.tiles_w, WH, WW);
-            sx.issue(xg, qn.b, qn.h0 - 3, qn.w0 - 3, p.H, p.W, p.C, more);
-            sd.issue(dg, qn.b, qn.h0, qn.w0, p.H, p.W, p.C, more);
-        }
-#pragma unroll 5
-        for (int r = 0; r < WXR; ++r) {
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        // the next tile's fetches are spread over the MFMA loop (one every other input row); operands are read one row
+        // ahead of their MFMA, the fences keep that order
+        const typename Sx::Tile tx = Sx::tile(xg, cq.b, cq.h0 - 3, cq.w0 - 3, p.H, p.W, p.C, more);
+        const typename Sd::Tile td = Sd::tile(dg, cq.b, cq.h0, cq.w0, p.H, p.W, p.C, more);
+        cq.step(p.H, p.W, WH, WW);
+        u32 da[2][5];
+        uint4 bq[2];
+        auto operands = [&](int r) {
             const u32* xa = reinterpret_cast<const u32*>(xa0 + r * WX_PITCH);
-            const u32 d0 = xa[0], d1 = xa[1], d2 = xa[2], d3 = xa[3], d4 = xa[4];
-            const uint4 a = make_uint4(__builtin_amdgcn_alignbit(d1, d0, shift), __builtin_amdgcn_alignbit(d2, d1, shift),
-                                       __builtin_amdgcn_alignbit(d3, d2, shift), __builtin_amdgcn_alignbit(d4, d3, shift));
-            const uint4 bq = *reinterpret_cast<const uint4*>(db0 + r * WD_PITCH);
-            acc = mfma32(a, bq, acc);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) da[r & 1][j] = xa[j];
+            bq[r & 1] = *reinterpret_cast<const uint4*>(db0 + r * WD_PITCH);
+        };
+        operands(0);
+#pragma unroll
+        for (int r = 0; r < WXR; ++r) {
+            if (r + 1 < WXR) operands(r + 1);
+            if ((r & 1) == 0 && r / 2 < NL) {
+                if (r / 2 < Sx::NLOAD) sx.issue_one(tx, r / 2, p.H, p.W, p.C);
+                else sd.issue_one(td, r / 2 - Sx::NLOAD, p.H, p.W, p.C);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32* d = da[r & 1];
+            const uint4 a = make_uint4(__builtin_amdgcn_alignbit(d[1], d[0], shift), __builtin_amdgcn_alignbit(d[2], d[1], shift),
+                                       __builtin_amdgcn_alignbit(d[3], d[2], shift), __builtin_amdgcn_alignbit(d[4], d[3], shift));
+            acc = mfma32(a, bq[r & 1], acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (more) {
@@ -633,7 +653,8 @@ int lnx_dwconv7_mfma_wgrad(const lnx_dwconv_wgrad_args* a, hipStream_t st) {
     int walkers = cus() / groups;  // one resident sibling pair per CU
     if (walkers < 1) walkers = 1;
     if (walkers > p.ntile) walkers = p.ntile;
-    walkers = cdiv(p.ntile, cdiv(p.ntile, walkers));  // same longest walk, no idle walkers
+    p.per = cdiv(p.ntile, walkers);
+    walkers = cdiv(p.ntile, p.per);  // same longest walk, no idle walkers
     p.nwalk = walkers;
     const int grid = 16 * cdiv(walkers * groups, 8);
     const int code = a->x_dtype * 2 + a->dy_dtype;
