@@ -88,11 +88,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
     const int nb = ncol0 + g * 16;  // first n of this lane
     if (nb >= p.N) return;
     const int nvalid = min(16, p.N - nb);
+    // Every load below is unconditional (clamped column / row, uniform branches only): a load under a per-lane branch
+    // whose result is merged with a constant is waited for on the spot, which made this prologue 32 + 4 serial memory
+    // round trips per workgroup.
     float bias[16], gam[16];
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bias[j] = p.bias[min(nb + j, p.N - 1)];
+    }
+    if (p.gamma) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gam[j] = p.gamma[min(nb + j, p.N - 1)];
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        bias[j] = (p.bias && j < nvalid) ? p.bias[nb + j] : 0.f;
-        gam[j] = (p.gamma && j < nvalid) ? p.gamma[nb + j] : 1.f;
+        if (!p.bias || j >= nvalid) bias[j] = 0.f;
+        if (!p.gamma || j >= nvalid) gam[j] = 1.f;
     }
     // Phase 1: every global load of the epilogue (aux, residual, row scale) for all four row slots, before
     // the first store.  C / C2 may alias res or aux as far as the compiler knows, so loads issued between
@@ -101,21 +112,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
     // one staging buffer: aux when the activation needs it, else the residual (a launch with both loads
     // the residual late, in phase 2)
     const bool res_early = p.res && !has_aux;
+    // 16-byte accesses for the staged operand: a kernel-uniform condition (a per-lane one would split the loads)
+    const bool vec_aux = has_aux && p.N % 16 == 0 && (((uintptr_t)p.aux) & 15) == 0 && (p.ldaux * sizeof(T)) % 16 == 0;
+    const bool vec_res = res_early && p.N % 16 == 0 && (((uintptr_t)p.res) & 15) == 0 && (p.ldres * 4) % 16 == 0 && p.c_mode != LNX_ADDR_PATCH2;
     float av[4][16], rs[4];
     int64_t roffs[4];
     int64_t coffs[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-        const int m = mrow0 + (s >> 2) * 16 + mi * 4 + (s & 3);
-        rs[mi] = 1.f;
-        coffs[mi] = 0;
-        roffs[mi] = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) av[mi][j] = 0.f;
-        if (m >= p.M) continue;
+        const int m = min(mrow0 + (s >> 2) * 16 + mi * 4 + (s & 3), p.M - 1);  // rows beyond M are loaded, never stored
+        rs[mi] = p.rowscale ? p.rowscale[m / p.rows_per_sample] : 1.f;
+        if (p.c_mode == LNX_ADDR_PATCH2) {
+            coffs[mi] = patch_base(p.pg, m) + patch_col(p.pg, nb);
+            roffs[mi] = coffs[mi];
+        } else {
+            const int64_t row = map_row(p.cmap, m);
+            coffs[mi] = row * p.ldc + nb;
+            roffs[mi] = row * p.ldres + nb;
+        }
         if (has_aux) {
             const T* ax = reinterpret_cast<const T*>(p.aux) + (int64_t)m * p.ldaux + nb;
-            if (nvalid == 16 && ((((uintptr_t)ax) & 15) == 0)) {
+            if (vec_aux) {
 #pragma unroll
                 for (int h = 0; h < 16 / EPV; ++h) {
                     Vec16<T> t;
@@ -125,21 +142,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) av[mi][j] = j < nvalid ? to_f(ax[j]) : 0.f;
+                for (int j = 0; j < 16; ++j) av[mi][j] = to_f(ax[min(j, nvalid - 1)]);
             }
-        }
-        if (p.rowscale) rs[mi] = p.rowscale[m / p.rows_per_sample];
-        if (p.c_mode == LNX_ADDR_PATCH2) {
-            coffs[mi] = patch_base(p.pg, m) + patch_col(p.pg, nb);
-            roffs[mi] = coffs[mi];
-        } else {
-            const int64_t row = map_row(p.cmap, m);
-            coffs[mi] = row * p.ldc + nb;
-            roffs[mi] = row * p.ldres + nb;
-        }
-        if (res_early) {
+        } else if (res_early) {
             const float* rp = p.res + roffs[mi];
-            if (nvalid == 16 && ((((uintptr_t)rp) & 15) == 0)) {
+            if (vec_res) {
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const float4 t = *reinterpret_cast<const float4*>(rp + 4 * h);
@@ -150,7 +157,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) av[mi][j] = j < nvalid ? rp[j] : 0.f;
+                for (int j = 0; j < 16; ++j) av[mi][j] = rp[min(j, nvalid - 1)];
             }
         }
     }
