@@ -639,24 +639,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int nq16 = (p.N + 15) / 16;
     for (int qt = wave; qt < nq16; qt += 8) {
         const int q = qt * 16 + s;
+        // every fetch of this q tile in one batch (unconditional, clamped rows): q~, dO and O fragments, the raw q values
+        // and cos factors of the epilogue, the row's LSE -- instead of one memory round trip per operand
+        const int qc = min(q, p.N - 1);
         uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
-        load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
-        load_row_frag<T, false>(dof, dob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+        Chunk<T, true> cq[AT<T>::NKK];
+        Chunk<T, false> cdo[AT<T>::NKK], co[AT<T>::NKK];
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            const int d0 = (kk * 4 + g) * AT<T>::EPV;
+            cq[kk].fetch(qb, ld, q, p.N, p.E, d0, p.cos_tab, p.heads, head);
+            cdo[kk].fetch(dob, C, q, p.N, p.E, d0, nullptr, p.heads, head);
+            co[kk].fetch(ob, C, q, p.N, p.E, d0, nullptr, p.heads, head);
+        }
+        const float lse_raw = p.lse[((int64_t)b * p.heads + head) * p.N + qc];
+        const T* qraw = qb + (int64_t)qc * ld;
+        const float* cpr = p.cos_tab + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
+        float qr[4][4], cr[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = dt * 16 + 4 * g;
+            if constexpr (sizeof(T) == 2) {
+                const uint2 r = *reinterpret_cast<const uint2*>(qraw + d0);
+                const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qr[dt][j] = (float)h[j];
+            } else {
+                const float4 r = *reinterpret_cast<const float4*>(qraw + d0);
+                qr[dt][0] = r.x; qr[dt][1] = r.y; qr[dt][2] = r.z; qr[dt][3] = r.w;
+            }
+            const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
+            cr[dt][0] = c2.x; cr[dt][1] = c2.y;
+        }
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            qf[kk] = cq[kk].value(q, p.N, p.E, scale);
+            dof[kk] = cdo[kk].value(q, p.N, p.E, 1.0f);
+        }
         float dl = 0.f;
         {
-            uint4 of[AT<T>::NKK];
-            load_row_frag<T, false>(of, ob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
 #pragma unroll
             for (int kk = 0; kk < AT<T>::NKK; ++kk) {
                 Vec16<T> a, bb;
                 a.raw = dof[kk];
-                bb.raw = of[kk];
+                bb.raw = co[kk].value(q, p.N, p.E, 1.0f);
 #pragma unroll
                 for (int j = 0; j < AT<T>::EPV; ++j) dl += a.get(j) * bb.get(j);
             }
         }
         const float delta = group_sum(dl);
-        const float lse = q < p.N ? p.lse[((int64_t)b * p.heads + head) * p.N + q] : 0.f;
+        const float lse = q < p.N ? lse_raw : 0.f;
         if (q < p.N && g == 0) p.delta[((int64_t)b * p.heads + head) * p.N + q] = delta;
         f32x4_t dq[4];
 #pragma unroll
@@ -679,18 +711,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         if (q < p.N) {
             T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
-            const T* qraw = qb + (int64_t)q * ld;
             const bool img = q >= p.E;
-            const float* cp = img ? p.cos_tab + ((int64_t)(q - p.E) * p.heads + head) * 32 : nullptr;
             float* gq = img ? p.gcos + (((int64_t)b * (p.N - p.E) + (q - p.E)) * p.heads + head) * 32 : nullptr;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
-                const float c0 = img ? cp[d0 >> 1] * scale : scale, c1 = img ? cp[(d0 >> 1) + 1] * scale : scale;
+                const float c0 = img ? cr[dt][0] * scale : scale, c1 = img ? cr[dt][1] * scale : scale;
                 store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
                 if (img) {
-                    gq[d0 >> 1] = scale * (dq[dt][0] * to_f(qraw[d0]) + dq[dt][1] * to_f(qraw[d0 + 1]));
-                    gq[(d0 >> 1) + 1] = scale * (dq[dt][2] * to_f(qraw[d0 + 2]) + dq[dt][3] * to_f(qraw[d0 + 3]));
+                    gq[d0 >> 1] = scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]);
+                    gq[(d0 >> 1) + 1] = scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]);
                 }
             }
         }
@@ -727,9 +757,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int nk16 = (p.N + 15) / 16;
     for (int ktile = wave; ktile < nk16; ktile += 8) {
         const int key = ktile * 16 + s;
+        const int kc = min(key, p.N - 1);
+        // every fetch of this key tile in one batch (see the dq kernel)
         uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
-        load_row_frag<T, true>(kf, kb, ld, key, p.N, p.E, g, p.cos_tab, p.heads, head, 1.0f);
-        load_row_frag<T, false>(vf, vb, ld, key, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
+        Chunk<T, true> ck[AT<T>::NKK];
+        Chunk<T, false> cv[AT<T>::NKK];
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            const int d0 = (kk * 4 + g) * AT<T>::EPV;
+            ck[kk].fetch(kb, ld, key, p.N, p.E, d0, p.cos_tab, p.heads, head);
+            cv[kk].fetch(vb, ld, key, p.N, p.E, d0, nullptr, p.heads, head);
+        }
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) {
+            kf[kk] = ck[kk].value(key, p.N, p.E, 1.0f);
+            vf[kk] = cv[kk].value(key, p.N, p.E, 1.0f);
+        }
         f32x4_t dk[4], dv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -754,22 +797,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             imgT_times_regs<T>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr, nt);
             imgT_times_regs<T>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds, nt);
         }
+        // raw k values and cos factors of the epilogue: one batch of loads here (held across the query loop they spill)
+        const T* kraw = kb + (int64_t)kc * ld;
+        const float* cpr = p.cos_tab + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
+        float kr[4][4], cr[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d0 = dt * 16 + 4 * g;
+            if constexpr (sizeof(T) == 2) {
+                const uint2 r = *reinterpret_cast<const uint2*>(kraw + d0);
+                const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kr[dt][j] = (float)h[j];
+            } else {
+                const float4 r = *reinterpret_cast<const float4*>(kraw + d0);
+                kr[dt][0] = r.x; kr[dt][1] = r.y; kr[dt][2] = r.z; kr[dt][3] = r.w;
+            }
+            const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
+            cr[dt][0] = c2.x; cr[dt][1] = c2.y;
+        }
         if (key < p.N) {
             T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
             T* dvp = dkp + C;
-            const T* kraw = kb + (int64_t)key * ld;
             const bool img = key >= p.E;
-            const float* cp = img ? p.cos_tab + ((int64_t)(key - p.E) * p.heads + head) * 32 : nullptr;
             float* gk = img ? p.gcos + (int64_t)p.B * (p.N - p.E) * p.heads * 32 + (((int64_t)b * (p.N - p.E) + (key - p.E)) * p.heads + head) * 32 : nullptr;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
-                const float c0 = img ? cp[d0 >> 1] : 1.0f, c1 = img ? cp[(d0 >> 1) + 1] : 1.0f;
+                const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
                 store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
                 store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
                 if (img) {
-                    gk[d0 >> 1] = dk[dt][0] * to_f(kraw[d0]) + dk[dt][1] * to_f(kraw[d0 + 1]);
-                    gk[(d0 >> 1) + 1] = dk[dt][2] * to_f(kraw[d0 + 2]) + dk[dt][3] * to_f(kraw[d0 + 3]);
+                    gk[d0 >> 1] = dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1];
+                    gk[(d0 >> 1) + 1] = dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3];
                 }
             }
         }
