@@ -727,9 +727,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// Diagnostic build only (-DATT_STAMP, tools/build_stamp.sh): per-phase s_memtime sums of wave 0 of one workgroup
+#ifdef ATT_STAMP
+__device__ unsigned long long g_att_stamp[8];
+#define ATT_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); tsum[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define ATT_T(i) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dkv_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef ATT_STAMP
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     const int nqt = (p.N + BT - 1) / BT;
     const int npad = (p.N + 31) & ~31;
     unsigned char* qimg = smem;  // padded-pitch images: row fragments AND transposed reads
@@ -749,11 +762,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
     stage_all<T, true, false, true>(nullptr, qimg, qb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, scale);
     stage_all<T, false, false, true>(nullptr, doimg, dob, C, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
-    for (int i = threadIdx.x; i < nqt * BT; i += blockDim.x) {
-        lse_s[i] = i < p.N ? p.lse[statbase + i] : 0.f;
-        del_s[i] = i < p.N ? p.delta[statbase + i] : 0.f;
+    ATT_T(0);
+    for (int i = threadIdx.x; i < nqt * BT; i += blockDim.x) {  // unconditional loads (clamped), zero by select
+        const float l = p.lse[statbase + min(i, p.N - 1)], d = p.delta[statbase + min(i, p.N - 1)];
+        lse_s[i] = i < p.N ? l : 0.f;
+        del_s[i] = i < p.N ? d : 0.f;
     }
     __syncthreads();
+    ATT_T(1);
     const int nk16 = (p.N + 15) / 16;
     for (int ktile = wave; ktile < nk16; ktile += 8) {
         const int key = ktile * 16 + s;
@@ -779,6 +795,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             dk[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             dv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
+        ATT_T(2);
         for (int qt = 0; qt < nqt; ++qt) {
             f32x4_t sacc[4], dpacc[4];
             const int nt = min(4, (p.N - qt * BT + 15) >> 4);  // 16-query groups of this tile that are not padding
@@ -797,6 +814,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             imgT_times_regs<T>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr, nt);
             imgT_times_regs<T>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds, nt);
         }
+        ATT_T(3);
         // raw k values and cos factors of the epilogue: one batch of loads here (held across the query loop they spill)
         const T* kraw = kb + (int64_t)kc * ld;
         const float* cpr = p.cos_tab + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
@@ -833,8 +851,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             }
         }
+        ATT_T(4);
     }
+#ifdef ATT_STAMP
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_att_stamp[i] = tsum[i];
+#endif
 }
+#ifdef ATT_STAMP
+extern "C" int lnx_dbg_attn_stamps(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_att_stamp), 64); }
+#endif
 
 // ---------------------------------------------------------------------------------
 // cos table and its backward to the learnable freqs
