@@ -236,8 +236,21 @@ __device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
+// Diagnostic build only (-DCM_STAMP, tools/build_stamp.sh): per-phase s_memtime sums of wave 0 of one workgroup
+#ifdef CM_STAMP
+__device__ unsigned long long g_cm_stamp[8];
+#define CM_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                     __builtin_amdgcn_sched_barrier(0); tsum[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define CM_T(i) do { } while (0)
+#endif
+
 template <int NK, int MT, int NW>
 __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
+#ifdef CM_STAMP
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr int PART = Geo<NK>::PART;
@@ -279,11 +292,14 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
     dma_cmajor<NK, NW>(smem + PART, p.w2, 0, wave, lane);
     dma_nmajor<NK, NW>(smem + STAGE, p.w1, 64, wave, lane);
     dma_cmajor<NK, NW>(smem + STAGE + PART, p.w2, 64, wave, lane);
+    CM_T(0);
     for (int j = 0; j < NCH; ++j) {
         const int stg = j % 3;
         if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CM_T(1);
         __builtin_amdgcn_s_barrier();
+        CM_T(2);
         if (j + 2 < NCH) {
             unsigned char* nx = smem + ((j + 2) % 3) * STAGE;
             dma_nmajor<NK, NW>(nx, p.w1, 64 * (j + 2), wave, lane);
@@ -291,7 +307,9 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
         }
         const uint32_t st = lds0 + stg * STAGE;
         f32x4_t h[4][MT];
+        CM_T(3);
         prod_nmajor_pipe<NK, MT>(h, st, s, g, xf);
+        CM_T(4);
         // bias + exact-erf GELU on the accumulator; row 4g+r of tile nt <-> hidden n = 64j + 32(nt>>1) + 8g + 4(nt&1) + r
         uint4 pf[MT][2];
         {
@@ -318,7 +336,9 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
                 pf[mt][1] = pack8(h[2][mt], h[3][mt]);
             }
         }
+        CM_T(5);
         prod_cmajor_pipe<NK, MT>(o, st + PART, s, g, pf);
+        CM_T(6);
     }
     // epilogue: lane (s = row m, g) holds channels c = 16 ct + 4 g + r
 #pragma unroll
@@ -351,7 +371,15 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
                 make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
         }
     }
+    CM_T(7);
+#ifdef CM_STAMP
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_cm_stamp[i] = tsum[i];
+#endif
 }
+#ifdef CM_STAMP
+extern "C" int lnx_dbg_convmlp_stamps(unsigned long long* out8) { return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cm_stamp), 64); }
+#endif
 
 // ------------------------------------------------------------------------------------
 // backward (data side): act, dH, dz, dln, dgamma
