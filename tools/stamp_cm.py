@@ -21,7 +21,10 @@ for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 print("convmlp_fwd C=192 us:", e0.elapsed_time(e1) * 100)
 o8 = (C.c_ulonglong * 8)()
-L.lib().lnx_dbg_convmlp_stamps(o8)
+try:
+    L.lib().lnx_dbg_convmlp_stamps(o8)
+except AttributeError:
+    sys.exit(0)  # not a stamp build: timing only
 names = ["prologue", "dma wait", "barrier", "dma issue", "prod1|matrix", "gelu|valu", "prod2", "epilogue"]
 tot = sum(o8)
 print("wave 0: total clk", tot, " ".join(f"{n} {o8[i] / tot * 100:.1f}%" for i, n in enumerate(names)))
