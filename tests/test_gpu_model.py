@@ -230,6 +230,60 @@ def test_large_384_matches_oracle():
         assert glob <= gtol, (dtype, glob)
 
 
+def test_xlarge_224_matches_oracle_and_autobatch():
+    """BASELINE config 5's architecture in bf16 / fp32 (the fp8 MFMA path is not built): mFormerV1_xl (dims 256..2048,
+    rope depths 22/2, heads 16/32) -- conv stages on the plain GEMM path (C = 256 / 512 is beyond the fused conv-MLP),
+    LayerNorm at C = 2048 (full wave, 8 float4 per lane), 24 RoPE blocks.  Logits and gradients against the CPU
+    oracle on the same seeded weights, then AutoBatch (utils/autobatch.py:111-265) sizes the batch for a memory
+    budget from the planner's exact workspace figure."""
+    from linnaeus_amd.autobatch import auto_find_batch_size, foreign_bytes, predicted_bytes
+
+    spec = O.Spec(conv_dims=(256, 512, 1024, 2048), rope_depths=(22, 2), rope_heads=(16, 32), heads=(("taxa_L10", 40), ("taxa_L20", 9)))
+    sd = O.seeded_state_dict(O.param_shapes(spec), 4321)
+    x, meta = O.seeded_inputs(spec, 1, 224, 77)
+    cfg = make_config(spec, 224)
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for v in sd.values())
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta)
+    O.probe_loss(oout).backward()
+    for dtype, ftol, gtol in (("fp32", 3e-4, 3e-3), ("bf16", 0.15, 0.15)):
+        model.set_compute_dtype(dtype)
+        model.train()
+        model.zero_grad()
+        out = model(x.cuda(), meta.cuda())
+        for t, _ in spec.heads:
+            ref = oout[t].detach()
+            err = (out[t].float().cpu() - ref).abs().max().item()
+            assert err <= ftol * max(1.0, ref.abs().max().item()), (dtype, t, err)
+            if dtype == "fp32":
+                assert (out[t].argmax(-1).cpu() == ref.argmax(-1)).all()
+        O.probe_loss(out).backward()
+        tot_err = tot_ref = 0.0
+        for k, p_ in model.named_parameters():
+            ref = osd[k].grad
+            tot_err += (p_.grad.float().cpu() - ref).double().pow(2).sum().item()
+            tot_ref += ref.double().pow(2).sum().item()
+        glob = (tot_err / tot_ref) ** 0.5
+        print(f"[xl@224/{dtype}] global relative gradient error vs oracle: {glob:.2e}")
+        assert glob <= gtol, (dtype, glob)
+    # AutoBatch: analytic footprint is monotone, and the search returns the largest batch under a (small, so that the
+    # verification step is quick) budget; at 0.9 of the 288 GB the same formula gives the production batch
+    model.set_compute_dtype("bf16")
+    model.zero_grad(set_to_none=True)
+    total = torch.cuda.get_device_properties(0).total_memory
+    other = foreign_bytes(model)
+    b8, b9 = predicted_bytes(model, 8, 224), predicted_bytes(model, 9, 224)
+    assert b9 > b8
+    frac = (b8 + 0.5 * (b9 - b8) + other) / total
+    assert auto_find_batch_size(model, cfg, "train", target_memory_fraction=frac, max_batch_size=512, steps_per_trial=1) == 8
+    big = 8 + int((0.9 * total - other - b8) // (b9 - b8))
+    print(f"[xl@224] AutoBatch at 0.9 x {total / 2**30:.0f} GiB: batch {big} per GPU ({(b9 - b8) / 2**20:.0f} MiB per image)")
+    assert big > 256
+
+
 def test_data_parallel_stream_logic_single_rank(golden_dir):
     """DataParallel on one GPU with the collectives forced on (RCCL, world size 1): the per-segment all-reduces on the
     side stream, their events and the final join must leave exactly the gradients of the plain model, for the plain
