@@ -80,6 +80,18 @@ typedef struct lnx_gemm_args {
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 
+/* fp8 operands (BASELINE config 5's "fp8 MFMA path"; the reference has no fp8 code: this is the MI355X form of its
+ * bf16 Linear, mlp.py:46-66 / rope_2d_mhsa.py:432,500).  OCP e4m3fn storage, one dequantisation scale per tensor:
+ *   lnx_amax          amax[0] = max(amax[0], max |x|)            (device scalar, caller zeroes it)
+ *   lnx_quantize_fp8  y = e4m3(x * 448 / amax[0]),  scale_out[0] = amax[0] / 448   (amax 0 -> scale 1)
+ *   lnx_gemm_nt_fp8   C = epilogue( a_scale[0] * w_scale[0] * A8 . W8^T ): `args` as lnx_gemm_nt with dtype = LNX_BF16
+ *                     for C / c2 / aux, but A and W are e4m3 bytes (lda / ldw in bytes), K % 128 == 0, N % 16 == 0, M >= 256, plain
+ *                     addressing and an epilogue the specialised forms cover (bias, GELU + c2, GELU', fp32 residual).
+ * The product runs on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: 2x the bf16 MFMA rate. */
+int lnx_amax(const void* x, int x_dtype, int64_t ldx, int rows, int cols, float* amax, void* stream);
+int lnx_quantize_fp8(const void* x, int x_dtype, int64_t ldx, int rows, int cols, const float* amax, void* y, int64_t ldy, float* scale_out, void* stream);
+int lnx_gemm_nt_fp8(const lnx_gemm_args* args, const float* a_scale, const float* w_scale, void* stream);
+
 /* Weight gradient  dW[N,K] += dY[M,N]^T . A[M,K]  and optionally db[N] += colsum(dY).
  * Split over M across workgroups.  Partial tiles are added to dW/db with fp32 atomics, or, when the
  * caller passes a workspace (ws), stored there and summed into dW/db by a second kernel in a fixed

@@ -32,6 +32,8 @@ struct GemmP {
     int act;
     int rows_per_sample;
     int tiles_m, tiles_n;
+    const float* sa = nullptr;  // fp8 kernels: dequantisation scales of A and W (device scalars)
+    const float* sw = nullptr;
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on

@@ -1,0 +1,274 @@
+// fp8 (OCP e4m3fn) operands for the NT GEMM on gfx950: lnx_amax / lnx_quantize_fp8 / lnx_gemm_nt_fp8 (include/lnx.h).
+//
+// The GEMM is the 256x128-tile LDS-DMA pipeline of gemm2.hip with the same bytes per stage: a 128-byte LDS row is one
+// K slice of 128 e4m3 values instead of 64 bf16, so each K slice does twice the work for the same fill traffic, and
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; the per-tensor scales are applied to the accumulator) retires
+// it at twice the bf16 MFMA rate.  Operand lane map, verified with exact integer data (tools/ubench/mfma_f8_layout.hip):
+// lane l holds A[row l & 15][k = 32 (l >> 4) + j] in byte j of its 8 dwords, B likewise with the column on l & 15; C/D as
+// every 16x16 MFMA.  A lane's 32 bytes are the two 16-byte chunks 2g, 2g+1 of the LDS row (XOR swizzle per chunk).
+#include "gemm_common.hpp"
+
+namespace lnxg {
+
+#define F8_DS_READ4(dst, addr)                                                                           \
+    do {                                                                                                 \
+        const uint32_t a_ = (addr);                                                                      \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(a_) : "memory");                         \
+        asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(dst[1]) : "v"(a_) : "memory");              \
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(dst[2]) : "v"(a_) : "memory");             \
+        asm volatile("ds_read_b128 %0, %1 offset:1536" : "=v"(dst[3]) : "v"(a_) : "memory");             \
+    } while (0)
+
+constexpr int F8_BM = 256, F8_BN = 128, F8_BK = 128;   // BK in elements = bytes
+constexpr int F8_STAGE = (F8_BM + F8_BN) * ROWB;       // 48 KiB
+constexpr int F8_NSTAGE = 3;
+constexpr int F8_LD = (F8_BM + F8_BN) / 8 / 8;         // 1-KiB LDS-DMA instructions per wave per stage = 6
+
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+__device__ __forceinline__ void mfma_f8(f32x4_t& acc, const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi) {
+    const i32x8_t a = {(int)a_lo.x, (int)a_lo.y, (int)a_lo.z, (int)a_lo.w, (int)a_hi.x, (int)a_hi.y, (int)a_hi.z, (int)a_hi.w};
+    const i32x8_t b = {(int)b_lo.x, (int)b_lo.y, (int)b_lo.z, (int)b_lo.w, (int)b_hi.x, (int)b_hi.y, (int)b_hi.z, (int)b_hi.w};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  // e4m3 x e4m3, block scales 2^0
+}
+
+template <bool OUT_F32, int F>
+__global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
+    typedef bf16_t T;  // type of C / c2 / aux
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3][A 256 rows | W 128 rows][128 B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int s = lane & 15, g = lane >> 4;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tn = logical % p.tiles_n;
+    const int tm = logical / p.tiles_n;
+    const int m0 = tm * F8_BM, n0 = tn * F8_BN;
+
+    // LDS-DMA sources as in gemm_nt_v2_kernel (bytes == elements)
+    const unsigned char* src[F8_LD];
+#pragma unroll
+    for (int j = 0; j < F8_LD; ++j) {
+        const int i = wave + 8 * j;
+        const int row = 8 * i + (lane >> 3);
+        const int slot = lane & 7;
+        if (row < F8_BM) {
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            src[j] = p.A + (int64_t)m * p.lda + ((slot ^ row_key(row)) << 4);
+        } else {
+            const int wr = row - F8_BM;
+            int n = n0 + wr;
+            if (n >= p.N) n = p.N - 1;
+            src[j] = p.W + (int64_t)n * p.ldw + ((slot ^ row_key(wr)) << 4);
+        }
+    }
+    auto issue_tile = [&](int kt, int stage) {
+#pragma unroll
+        for (int j = 0; j < F8_LD; ++j) {
+            const int i = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (int64_t)kt * F8_BK),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * F8_STAGE + i * 1024), 16, 0, 0);
+        }
+    };
+
+    const int frag_row = (s >> 2) * 16 + (s & 3);
+    const int frag_key = ((s >> 1) & 1) | ((s >> 2) << 1);
+    const int a_row0 = wm * 64 + frag_row;
+    const int w_row0 = F8_BM + wn * 64 + frag_row;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t ch0 = (uint32_t)(((2 * g) ^ frag_key) << 4), ch1 = (uint32_t)(((2 * g + 1) ^ frag_key) << 4);  // bytes 32g .. 32g+31 of the row
+    const uint32_t a_off0 = a_row0 * ROWB + ch0, a_off1 = a_row0 * ROWB + ch1;
+    const uint32_t w_off0 = w_row0 * ROWB + ch0, w_off1 = w_row0 * ROWB + ch1;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / F8_BK;  // >= 2
+    issue_tile(0, 0);
+    issue_tile(1, 1);
+    // ping-pong wave groups, two barriers per K slice, counted waits: see gemm_nt_v2_kernel
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t st = lds_base + (kt % F8_NSTAGE) * F8_STAGE;
+        uint4 wf0[4], af0[4], wf1[4], af1[4];
+        F8_DS_READ4(wf0, st + w_off0);
+        F8_DS_READ4(af0, st + a_off0);
+        F8_DS_READ4(wf1, st + w_off1);
+        F8_DS_READ4(af1, st + a_off1);
+        if (kt + 2 < nk) {
+            issue_tile(kt + 2, (kt + 2) % F8_NSTAGE);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mfma_f8(acc[ni][mi], wf0[ni], wf1[ni], af0[mi], af1[mi]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp && kt + 1 == nk)) __builtin_amdgcn_s_barrier();
+    }
+    const float alpha = (p.sa ? p.sa[0] : 1.0f) * (p.sw ? p.sw[0] : 1.0f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] *= alpha;
+    gemm_epilogue_fast<T, OUT_F32, F>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// amax / quantise: HBM-bound streaming kernels, 16-byte accesses, grid-stride over rows
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(256) void amax_kernel(const TX* __restrict__ x, int64_t ldx, int rows, int cols, float* __restrict__ amax) {
+    constexpr int EPV = 16 / sizeof(TX);
+    const int cpr = cols / EPV;  // 16-byte chunks per row
+    const int64_t total = (int64_t)rows * cpr;
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr);
+        Vec16<TX> v;
+        v.raw = ld16(x + r * ldx + c * EPV);
+#pragma unroll
+        for (int j = 0; j < EPV; ++j) m = fmaxf(m, fabsf(v.get(j)));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));  // non-negative floats order as their bits
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const TX* __restrict__ x, int64_t ldx, int rows, int cols, const float* __restrict__ amax,
+                                                           unsigned char* __restrict__ y, int64_t ldy, float* __restrict__ scale_out) {
+    // both quotients through fp64, i.e. correctly rounded fp32 values of 448 / amax and amax / 448 (the fp32 division
+    // hipcc emits here was one ulp low, which moves every value that sits just past a rounding tie by one code)
+    const float am = amax[0];
+    const float inv = am > 0.f ? (float)(448.0 / (double)am) : 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && scale_out) scale_out[0] = am > 0.f ? (float)((double)am / 448.0) : 1.0f;
+    const int cpr = cols / 16;  // 16 outputs (16 bytes) per thread step
+    const int64_t total = (int64_t)rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cpr;
+        const int c = (int)(i - r * cpr) * 16;
+        float f[16];
+        if constexpr (sizeof(TX) == 2) {
+            Vec16<TX> a, b;
+            a.raw = ld16(x + r * ldx + c);
+            b.raw = ld16(x + r * ldx + c + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f[j] = a.get(j);
+                f[8 + j] = b.get(j);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float4 t = *reinterpret_cast<const float4*>(x + r * ldx + c + 4 * h);
+                f[4 * h] = t.x; f[4 * h + 1] = t.y; f[4 * h + 2] = t.z; f[4 * h + 3] = t.w;
+            }
+        }
+        uint32_t w[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            // saturating round-to-nearest-even conversion of two floats into one half of a dword (v_cvt_pk_fp8_f32)
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 1] * inv, -448.f), 448.f), 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 3] * inv, -448.f), 448.f), pk, true);
+            w[h] = (uint32_t)pk;
+        }
+        st16(y + r * ldy + c, make_uint4(w[0], w[1], w[2], w[3]));
+    }
+}
+
+}  // namespace lnxg
+using namespace lnxg;
+
+extern "C" int lnx_amax(const void* x, int x_dtype, int64_t ldx, int rows, int cols, float* amax, void* stream) {
+    LNX_CHECK(x && amax && rows > 0 && cols > 0, "lnx_amax: null operand / empty");
+    LNX_CHECK(x_dtype == LNX_F32 || x_dtype == LNX_BF16, "lnx_amax: bad dtype %d", x_dtype);
+    const int epv = x_dtype == LNX_F32 ? 4 : 8;
+    LNX_CHECK(cols % epv == 0 && ldx % epv == 0 && (((uintptr_t)x) & 15) == 0, "lnx_amax: 16-byte aligned rows of whole 16-byte chunks");
+    int grid = (int)(((int64_t)rows * (cols / epv) + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (x_dtype == LNX_F32) hipLaunchKernelGGL(amax_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, rows, cols, amax);
+    else hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, rows, cols, amax);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_quantize_fp8(const void* x, int x_dtype, int64_t ldx, int rows, int cols, const float* amax, void* y, int64_t ldy, float* scale_out, void* stream) {
+    LNX_CHECK(x && amax && y && rows > 0 && cols > 0, "lnx_quantize_fp8: null operand / empty");
+    LNX_CHECK(x_dtype == LNX_F32 || x_dtype == LNX_BF16, "lnx_quantize_fp8: bad dtype %d", x_dtype);
+    LNX_CHECK(cols % 16 == 0 && ldx % 8 == 0 && ldy % 16 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0, "lnx_quantize_fp8: cols %% 16, 16-byte aligned rows");
+    int grid = (int)(((int64_t)rows * (cols / 16) + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (x_dtype == LNX_F32)
+        hipLaunchKernelGGL(quantize_fp8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, rows, cols, amax, (unsigned char*)y, ldy, scale_out);
+    else
+        hipLaunchKernelGGL(quantize_fp8_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, rows, cols, amax, (unsigned char*)y, ldy, scale_out);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_gemm_nt_fp8(const lnx_gemm_args* a, const float* a_scale, const float* w_scale, void* stream) {
+    LNX_CHECK(a != nullptr && a->A && a->W && a->C, "lnx_gemm_nt_fp8: null operand");
+    LNX_CHECK(a->dtype == LNX_BF16, "lnx_gemm_nt_fp8: dtype (of C / c2 / aux) must be LNX_BF16");
+    LNX_CHECK(a->M >= 256 && a->N > 0 && a->K >= 256 && a->K % 128 == 0, "lnx_gemm_nt_fp8: M=%d N=%d K=%d (M >= 256, K %% 128 == 0, K >= 256)", a->M, a->N, a->K);
+    LNX_CHECK(a->lda % 16 == 0 && a->ldw % 16 == 0 && ((((uintptr_t)a->A) | ((uintptr_t)a->W)) & 15) == 0, "lnx_gemm_nt_fp8: A/W rows must be 16-byte aligned");
+    LNX_CHECK(a->a_mode == LNX_ADDR_PLAIN && a->c_mode == LNX_ADDR_PLAIN && a->c_map.group == 0 && a->c_map.pad == 0 && a->c_map.off == 0,
+              "lnx_gemm_nt_fp8: plain addressing only");
+    if (a->act == LNX_ACT_GELU_BWD) LNX_CHECK(a->aux != nullptr, "lnx_gemm_nt_fp8: GELU_BWD needs aux");
+    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_gemm_nt_fp8: rowscale needs rows_per_sample");
+    GemmP p;
+    p.A = (const unsigned char*)a->A; p.W = (const unsigned char*)a->W; p.C = (unsigned char*)a->C; p.C2 = (unsigned char*)a->c2;
+    p.aux = (const unsigned char*)a->aux; p.bias = a->bias; p.gamma = a->gamma; p.rowscale = a->rowscale; p.res = a->res;
+    p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc; p.ldc2 = a->ldc2; p.ldaux = a->ldaux; p.ldres = a->ldres;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.a_mode = a->a_mode; p.c_mode = a->c_mode;
+    p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
+    p.cmap = RowMap{0, 0, 0};
+    p.act = a->act;
+    p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.tiles_m = cdiv(a->M, F8_BM);
+    p.tiles_n = cdiv(a->N, F8_BN);
+    p.sa = a_scale; p.sw = w_scale;
+    const bool out_f32 = a->out_f32 != 0;
+    const int f = fast_epilogue_mask(p, out_f32);
+    LNX_CHECK(f != (int)F_GENERIC && a->gamma == nullptr, "lnx_gemm_nt_fp8: this epilogue needs the generic form, which the fp8 kernel does not carry");
+    const int grid = p.tiles_m * p.tiles_n;
+    const size_t lds = F8_NSTAGE * (size_t)F8_STAGE;
+    hipStream_t st = (hipStream_t)stream;
+#define F8_LAUNCH(O, FF)                                                                                                              \
+    do {                                                                                                                              \
+        static bool attr = false;                                                                                                     \
+        if (!attr) {                                                                                                                  \
+            LNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_fp8_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr = true;                                                                                                              \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_fp8_kernel<O, FF>), dim3(grid), dim3(512), lds, st, p);                                           \
+    } while (0)
+    if (out_f32) {
+        LNX_CHECK(f == (F_BIAS | F_RES), "lnx_gemm_nt_fp8: an fp32 output needs bias + residual (the model's form)");
+        F8_LAUNCH(true, F_BIAS | F_RES);
+    } else if (f == 0) F8_LAUNCH(false, 0);
+    else if (f == F_BIAS) F8_LAUNCH(false, F_BIAS);
+    else if (f == (F_BIAS | F_C2 | F_GELU)) F8_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
+    else if (f == F_GELU_BWD) F8_LAUNCH(false, F_GELU_BWD);
+    else LNX_CHECK(false, "lnx_gemm_nt_fp8: unsupported epilogue feature set %d", f);
+#undef F8_LAUNCH
+    LNX_LAUNCH_CHECK();
+    return 0;
+}

@@ -71,6 +71,38 @@ def gemm_nt(A, W, out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     return out
 
 
+def quantize_fp8(x, *, amax=None):
+    """(x8, scale): x8 = e4m3fn(x * 448 / max|x|) as a torch.float8_e4m3fn tensor, scale = max|x| / 448 (device scalar).
+    `amax`: a device scalar to use instead of this tensor's own maximum (delayed scaling)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if amax is None:
+        amax = torch.zeros(1, device=x.device, dtype=torch.float32)
+        L.check(L.lib().lnx_amax(_p(x2), code_of(x2), C.c_int64(x2.stride(0)), x2.shape[0], x2.shape[1], _p(amax), _stream()), "lnx_amax")
+    y = torch.empty(x2.shape, device=x.device, dtype=torch.uint8)
+    scale = torch.empty(1, device=x.device, dtype=torch.float32)
+    L.check(L.lib().lnx_quantize_fp8(_p(x2), code_of(x2), C.c_int64(x2.stride(0)), x2.shape[0], x2.shape[1], _p(amax), _p(y), C.c_int64(y.stride(0)), _p(scale), _stream()),
+            "lnx_quantize_fp8")
+    return y.view(torch.float8_e4m3fn).reshape(x.shape), scale
+
+
+def gemm_nt_fp8(A8, a_scale, W8, w_scale, out, *, bias=None, act=L.ACT_NONE, aux=None, c2=None, rowscale=None, rows_per_sample=0, res=None):
+    """out = epilogue(a_scale * w_scale * A8 . W8^T) with e4m3 operands; see lnx_gemm_nt_fp8."""
+    a = L.GemmArgs()
+    a.dtype = L.BF16
+    a.M, a.N, a.K = A8.shape[0], W8.shape[0], W8.shape[1]
+    a.A, a.lda = _p(A8), A8.stride(0)
+    a.W, a.ldw = _p(W8), W8.stride(0)
+    a.C, a.ldc = _p(out), out.stride(0)
+    a.out_f32 = int(out.dtype == torch.float32)
+    a.bias = _p(bias)
+    a.c2, a.ldc2 = _p(c2), (c2.stride(0) if c2 is not None else 0)
+    a.act, a.aux, a.ldaux = act, _p(aux), (aux.stride(0) if aux is not None else 0)
+    a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
+    a.res, a.ldres = _p(res), (res.stride(0) if res is not None else 0)
+    L.check(L.lib().lnx_gemm_nt_fp8(C.byref(a), _p(a_scale), _p(w_scale), _stream()), "lnx_gemm_nt_fp8")
+    return out
+
+
 def gemm_tn(dY, A, dW, *, M=None, N=None, K=None, lda=None, lddw=None, db=None, a_patch=None, k_perm_c=0, k_store=0, splits=0, dtype=None):
     a = L.WgradArgs()
     a.dtype = dtype if dtype is not None else code_of(dY)

@@ -366,3 +366,48 @@ def test_convmlp_fused_fwd_bwd(C_, M):
     assert e1.max().item() < 3e-3 and e2.max().item() < 3e-3, (e1.max().item(), e2.max().item())  # fp32 accumulation of bf16 products
     torch.testing.assert_close(db1.double() + 0.25, dh64.sum(0), rtol=2e-3, atol=2e-3 * M**0.5)
     torch.testing.assert_close(db2.double() - 1.0, dz.double().sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
+@pytest.mark.parametrize("xd", [L.BF16, L.F32])
+def test_fp8_quantize_and_gemm(M, N, K, xd):
+    """fp8 path (BASELINE config 5; the reference has no fp8 code, so the expected values are the definition itself):
+    quantisation = torch's own e4m3fn rounding of x * 448 / amax, and the GEMM = the fp64 product of the DEQUANTISED
+    operands, i.e. the only error left is fp32 accumulation order."""
+    gen = g(M + N + K)
+    x = (torch.randn(M, K, generator=gen) * 3).cuda().to(DT[xd])
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda().to(torch.bfloat16)
+    x8, sx = ops.quantize_fp8(x)
+    w8, sw = ops.quantize_fp8(w)
+    amax = x.float().abs().max()
+    assert torch.allclose(sx, (amax / 448).reshape(1), rtol=1e-6)
+    # 448 / amax as the correctly rounded fp32 quotient (torch's own tensor division on the GPU is a reciprocal-multiply
+    # and can be one ulp off, which flips every bf16 input that lands just past a rounding tie); then one fp32 multiply
+    # and torch's round-to-nearest-even e4m3 conversion: byte-exact
+    inv = torch.tensor(448.0 / amax.double().item(), dtype=torch.float32).item()
+    ref8 = (x.float() * inv).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(x8.view(torch.uint8), ref8.view(torch.uint8))
+    xd_ = x8.float().double().cpu() * sx.item()
+    wd_ = w8.float().double().cpu() * sw.item()
+    bias = torch.randn(N, generator=gen).cuda()
+    # plain, bias, bias + GELU (+ pre-activation copy), fp32 output with residual and DropPath row scale
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_fp8(x8, sx, w8, sw, out)
+    ref = xd_ @ wd_.t()
+    tol = 8e-3 * max(1.0, ref.abs().max().item())
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=8e-3, atol=tol)
+    if N % 16 == 0:
+        ops.gemm_nt_fp8(x8, sx, w8, sw, out, bias=bias)
+        torch.testing.assert_close(out.double().cpu(), ref + bias.double().cpu(), rtol=8e-3, atol=tol)
+        pre = torch.empty_like(out)
+        ops.gemm_nt_fp8(x8, sx, w8, sw, out, bias=bias, act=L.ACT_GELU, c2=pre)
+        h = ref + bias.double().cpu()
+        torch.testing.assert_close(pre.double().cpu(), h, rtol=8e-3, atol=tol)
+        torch.testing.assert_close(out.double().cpu(), torch.nn.functional.gelu(h), rtol=8e-3, atol=tol)
+        res = torch.randn(M, N, generator=gen).cuda()
+        rs = (torch.rand(4, generator=gen) + 0.5).cuda()
+        rps = (M + 3) // 4
+        o32 = torch.empty(M, N, device="cuda")
+        ops.gemm_nt_fp8(x8, sx, w8, sw, o32, bias=bias, res=res, rowscale=rs, rows_per_sample=rps)
+        rowf = rs.double().cpu()[torch.arange(M) // rps].reshape(M, 1)
+        torch.testing.assert_close(o32.double().cpu(), res.double().cpu() + rowf * h, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()))
