@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--drop-in", action="store_true",
                     help="time the model the way the reference's train.py:147-176,279-316 drives it: torch cross_entropy per task, "
                          "loss.backward(), clip_grad_norm_, torch.optim.AdamW.step, zero_grad (nothing from linnaeus_amd but the model)")
+    ap.add_argument("--recompute", action="store_true",
+                    help="gradient checkpointing on (TRAIN.GRADIENT_CHECKPOINTING: block inputs kept, activations recomputed in backward); "
+                         "not the headline configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -151,6 +154,7 @@ def main():
     model = model.to(dev)
     model.set_compute_dtype(args.dtype)
     model.train()
+    model.use_checkpoint = bool(args.recompute)
     net = model
     if world > 1 or args.force_dp:
         from linnaeus_amd.ddp import DataParallel
@@ -317,6 +321,9 @@ def main():
     }
     if dp_extra:
         line["data_parallel"] = dp_extra
+    if args.recompute:
+        line["config"]["workload"] = line["config"]["workload"].replace("gradient checkpointing off", "gradient checkpointing ON (recompute plan)")
+        line["workspace_gb"] = round(model._active["ws"].numel() / 1e9, 2)
     if args.drop_in:
         line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
     print(json.dumps(line), flush=True)

@@ -474,6 +474,11 @@ typedef struct lnx_mformer_cfg {
     int task_classes[LNX_MAX_TASKS];
     int inference;             /* 1: forward-only plan (model.eval() under no_grad, validation.py:199): no backward scratch,
                                   blocks share their activation buffers; lnx_plan_backward fails on it */
+    int recompute;             /* 1: activation recompute (gradient checkpointing, blocks/convnext.py:89-100,
+                                  rope_2d_mhsa.py:617-641): only each block's INPUT is kept; the blocks of a stage share one
+                                  set of activation buffers and lnx_plan_backward re-runs a block's forward right before its
+                                  backward.  Same results bit for bit (the recompute is deterministic and reuses the DropPath
+                                  draw of the forward); workspace no longer grows with the depth. */
 } lnx_mformer_cfg;
 
 typedef struct lnx_plan lnx_plan;

@@ -126,6 +126,8 @@ struct lnx_plan {
     const unsigned char* last_mask = nullptr;
     std::vector<unsigned char> mask_host;
     const float* last_meta = nullptr;
+    // recompute plans: index of the block whose activations currently sit in each stage's shared buffer set
+    int resident[4] = {-1, -1, -1, -1};
     // side stream for the tiny M = batch metadata-head chains: they are independent of the image path
     // until token assembly, so they run concurrently with the conv stages (forward) / the downsample
     // backward (backward) instead of serialising ~100 small launches on the main stream
@@ -483,7 +485,10 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     bool any_fused = false;
     // Inference plans: nothing is saved for a backward, so the blocks of a stage share one set of activation buffers
     // and the residual stream ping-pongs between two (the workspace no longer grows with the depth).
+    // Recompute plans (cfg.recompute, training): the same sharing, but every block keeps its own INPUT; the backward
+    // re-runs a block's forward into the shared set before differentiating it.
     const bool inf = c.inference != 0;
+    const bool ck = !inf && c.recompute != 0;
     for (int s = 0; s < 2; ++s) {
         const int64_t M = (int64_t)B * p->HW[s], C = D[s];
         if (M * C > maxMC) maxMC = M * C;
@@ -496,7 +501,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         const size_t nb = p->conv[s].size();
         for (size_t i = 0; i < nb; ++i) {
             ConvBlk& k = p->conv[s][i];
-            const bool share = inf && i > 0;
+            const bool share = (inf || ck) && i > 0;
             const ConvBlk& f = p->conv[s][0];
             k.xin = inf ? pp[i & 1] : cv.take(M * C * 4);
             k.y = share ? f.y : cv.take(M * C * esz);
@@ -534,7 +539,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         }
         for (size_t i = 0; i < p->rope[s].size(); ++i) {
             RopeBlk& k = p->rope[s][i];
-            const bool share = inf && i > 0;
+            const bool share = (inf || ck) && i > 0;
             const RopeBlk& f = p->rope[s][0];
             if (i == 0) k.xin = p->o_tok[s];  // later blocks: output buffer of the previous block (set below)
             k.n1 = share ? f.n1 : cv.take(M * C * esz);
@@ -890,6 +895,7 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
     const int B = p->c.batch, H = p->H[s], W = p->W[s], C = p->c.dims[s];
     const int M = B * H * W;
     (void)xin;
+    p->resident[s] = i;
     lnx_dwconv_args d;
     memset(&d, 0, sizeof d);
     d.B = B; d.H = H; d.W = W; d.C = C;
@@ -964,6 +970,7 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     const int B = p->c.batch, C = p->c.dims[2 + s], heads = p->c.rope_heads[s], hid = p->c.mlp_hidden[s];
     const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
     const float* xin = c.at<float>(k.xin);
+    p->resident[2 + s] = i;
     RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1)));
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
@@ -1311,6 +1318,24 @@ int tokens_bwd(const Ctx& c, int s, const float* g) {
     return 0;
 }
 
+// Recompute plans: bring block i's activations back into the stage's shared buffers (no-op when they are still there,
+// i.e. for the last block of a stage right after the forward).  The block's output buffer is rewritten with the
+// same values.
+int conv_block_restore(const Ctx& c, int s, int i) {
+    lnx_plan* p = c.p;
+    if (!p->c.recompute || p->resident[s] == i) return 0;
+    const int nb = p->c.conv_depths[s];
+    float* xout = i + 1 < nb ? c.at<float>(p->conv[s][i + 1].xin) : c.at<float>(p->o_stage_out[s]);
+    return conv_block_fwd(c, s, i, nullptr, xout);
+}
+int rope_block_restore(const Ctx& c, int s, int i) {
+    lnx_plan* p = c.p;
+    if (!p->c.recompute || p->resident[2 + s] == i) return 0;
+    const int nb = p->c.rope_depths[s];
+    float* xout = i + 1 < nb ? c.at<float>(p->rope[s][i + 1].xin) : c.at<float>(p->o_stage_out[2 + s]);
+    return rope_block_fwd(c, s, i, xout);
+}
+
 int join_side(const Ctx& c, int s) {
     lnx_plan* p = c.p;
     if (p->side && p->c.n_meta > 0) HIPRUN(hipStreamWaitEvent((hipStream_t)c.st, p->ev_bjoin[s], 0));
@@ -1374,7 +1399,10 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         const lnx_rowmap clsrow = {1, p->N3 - 1, 0};
         RUN(ln_bwd(c, B, C, dc2n, LNX_F32, C, IDM, c.at<float>(p->o_stage_out[3]), LNX_F32, C, clsrow, p->norm_w[1], p->norm_b[1], c.at<float>(p->o_n2_mean),
                    c.at<float>(p->o_n2_rstd), nullptr, g3, LNX_F32, C, false));
-        for (int i = cf.rope_depths[1] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 1, i, g3, i != cf.rope_depths[1] - 1));
+        for (int i = cf.rope_depths[1] - 1; i >= 0; --i) {
+            RUN(rope_block_restore(c, 1, i));
+            RUN(rope_block_bwd(c, 1, i, g3, i != cf.rope_depths[1] - 1));
+        }
         RUN(tokens_bwd(c, 1, g3));
         // downsample 3 backward into d(norm_1 output); meta/CLS rows of dt1 start at zero
         const int C2 = D[2];
@@ -1409,7 +1437,10 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);
-        for (int i = cf.rope_depths[0] - 1; i >= 0; --i) RUN(rope_block_bwd(c, 0, i, g2, true));
+        for (int i = cf.rope_depths[0] - 1; i >= 0; --i) {
+            RUN(rope_block_restore(c, 0, i));
+            RUN(rope_block_bwd(c, 0, i, g2, true));
+        }
         RUN(tokens_bwd(c, 0, g2));
         const lnx_rowmap gm = {p->HW[2], p->E, p->E};
         RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
@@ -1418,13 +1449,19 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     }
     if (all || segment == 2) {
         float* g1 = c.at<float>(p->o_g[1]);
-        for (int i = cf.conv_depths[1] - 1; i >= 0; --i) RUN(conv_block_bwd(c, 1, i, g1));
+        for (int i = cf.conv_depths[1] - 1; i >= 0; --i) {
+            RUN(conv_block_restore(c, 1, i));
+            RUN(conv_block_bwd(c, 1, i, g1));
+        }
         RUN(downsample_bwd(c, 0, g1, D[1], IDM, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, c.at<float>(p->o_g[0]), LNX_F32, D[0]));
         if (all) RUN(join_side(c, 0));  // stage-3 metadata heads: hidden behind the whole ConvNeXt stage-2 backward
     }
     if (all || segment == 3) {
         float* g0 = c.at<float>(p->o_g[0]);
-        for (int i = cf.conv_depths[0] - 1; i >= 0; --i) RUN(conv_block_bwd(c, 0, i, g0));
+        for (int i = cf.conv_depths[0] - 1; i >= 0; --i) {
+            RUN(conv_block_restore(c, 0, i));
+            RUN(conv_block_bwd(c, 0, i, g0));
+        }
         const int M0 = B * p->HW[0];
         void* sC = c.at<void>(p->o_sC);
         RUN(ln_bwd(c, M0, D[0], g0, LNX_F32, D[0], IDM, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, c.at<float>(p->o_stem_mean),

@@ -33,7 +33,7 @@ class _Cfg(C.Structure):
         ("dtype", C.c_int), ("batch", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int), ("in_chans", C.c_int),
         ("dims", C.c_int * 4), ("conv_depths", C.c_int * 2), ("rope_depths", C.c_int * 2), ("rope_heads", C.c_int * 2),
         ("mlp_hidden", C.c_int * 2), ("n_meta", C.c_int), ("meta_dims", C.c_int * 8), ("only_last_cls", C.c_int),
-        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16), ("inference", C.c_int),
+        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16), ("inference", C.c_int), ("recompute", C.c_int),
     ]
 
 
@@ -256,7 +256,9 @@ class mFormerV1(nn.Module):
         self._grad_arena = None
         self._grad_views: Optional[List[torch.Tensor]] = None
         self._arena_layout = None
-        self.use_checkpoint = False   # probed by the reference's train loop; activations are always kept (no recompute path)
+        # set by the reference's train loop / AutoBatch (train.py:93-110, utils/autobatch.py:298-300); together with
+        # TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS and forward(force_checkpointing=...) it selects a recompute plan
+        self.use_checkpoint = False
         # opt-in: the refinement the hierarchical heads were meant to apply (heads.refine_logits_top_down); the reference's
         # effective behaviour -- and the default here -- is the plain shared Linear per task (finding F3)
         self.hierarchical_refinement = bool(M.CLASSIFICATION.get("HIERARCHICAL_REFINEMENT", False)) if hasattr(M, "CLASSIFICATION") else False
@@ -344,9 +346,25 @@ class mFormerV1(nn.Module):
             return lin.weight if kind == "weight" else lin.bias
         return self.get_parameter(plan_name)
 
-    def _make_cfg(self, B: int, H: int, W: int, train: bool) -> "_Cfg":
+    def _wants_recompute(self, force_checkpointing: Optional[bool] = None) -> bool:
+        """mFormerV1.py:415-422: `force_checkpointing` wins, else TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS (or the
+        `use_checkpoint` attribute the reference's train loop toggles); the blocks apply it only in training mode
+        (convnext.py:91, rope_2d_mhsa.py:617)."""
+        want = bool(force_checkpointing) if force_checkpointing is not None else self._checkpoint_policy()
+        return want and self.training
+
+    def _checkpoint_policy(self) -> bool:
+        want = bool(self.use_checkpoint)
+        try:
+            want = want or bool(self.config.TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS)
+        except (AttributeError, KeyError):
+            pass
+        return want
+
+    def _make_cfg(self, B: int, H: int, W: int, train: bool, recompute: bool = False) -> "_Cfg":
         cfg = _Cfg()
         cfg.inference = 0 if train else 1
+        cfg.recompute = 1 if (train and recompute) else 0
         cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
         cfg.dims[:] = self._dims
         cfg.conv_depths[:] = self._depths[:2]
@@ -363,7 +381,8 @@ class mFormerV1(nn.Module):
             cfg.task_classes[i] = self.head[t].effective_linear.out_features
         return cfg
 
-    def workspace_bytes(self, batch: int, img_h: Optional[int] = None, img_w: Optional[int] = None, train: bool = True) -> int:
+    def workspace_bytes(self, batch: int, img_h: Optional[int] = None, img_w: Optional[int] = None, train: bool = True,
+                        recompute: Optional[bool] = None) -> int:
         """Bytes of plan workspace (saved activations + operand arena + scratch) a forward[/backward] of this batch shape
         needs -- computed by the native planner WITHOUT allocating anything, which is what lets AutoBatch size a batch
         for 288 GB analytically instead of by out-of-memory trials (utils/autobatch.py:111-265)."""
@@ -371,7 +390,9 @@ class mFormerV1(nn.Module):
         lib.lnx_plan_workspace_bytes.restype = C.c_int64
         H = img_h or self.img_size[0]
         W = img_w or img_h or self.img_size[1]
-        cfg = self._make_cfg(int(batch), int(H), int(W), train)
+        if recompute is None:  # what a training forward would use
+            recompute = self._checkpoint_policy()
+        cfg = self._make_cfg(int(batch), int(H), int(W), train, bool(recompute))
         handle = C.c_void_p()
         L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
         try:
@@ -379,11 +400,12 @@ class mFormerV1(nn.Module):
         finally:
             lib.lnx_plan_destroy(handle)
 
-    def _get_plan(self, B: int, H: int, W: int, train: bool = True) -> Dict[str, Any]:
-        """Native plan for one (batch, image size, dtype, train/inference) combination.  Inference plans (no_grad /
-        frozen model) carry no backward scratch and share activation buffers between blocks.  The cache is a small
-        LRU: an evicted plan is destroyed and its workspace freed."""
-        key = (B, H, W, self._dtype_code, bool(train))
+    def _get_plan(self, B: int, H: int, W: int, train: bool = True, recompute: bool = False) -> Dict[str, Any]:
+        """Native plan for one (batch, image size, dtype, train/inference, recompute) combination.  Inference plans (no_grad /
+        frozen model) carry no backward scratch and share activation buffers between blocks; recompute plans (gradient
+        checkpointing) keep block inputs only.  The cache is a small LRU: an evicted plan is destroyed and its workspace freed."""
+        recompute = bool(train and recompute)
+        key = (B, H, W, self._dtype_code, bool(train), recompute)
         st = self._plans.get(key)
         lib = L.lib()
         if st is not None:
@@ -395,7 +417,7 @@ class mFormerV1(nn.Module):
                     self._active = None
                 torch.cuda.current_stream().synchronize()
                 self._destroy_plan(old)
-            cfg = self._make_cfg(B, H, W, train)
+            cfg = self._make_cfg(B, H, W, train, recompute)
             tasks = self._task_list()
             handle = C.c_void_p()
             L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
@@ -558,7 +580,7 @@ class mFormerV1(nn.Module):
         return [v.clone() for v in views]
 
     # ------------------------------------------------------------------ public forward
-    def _run(self, x: torch.Tensor, meta: Optional[torch.Tensor]):
+    def _run(self, x: torch.Tensor, meta: Optional[torch.Tensor], force_checkpointing: Optional[bool] = None):
         if not x.is_cuda:
             raise L.LnxError("mFormerV1 (linnaeus_amd) has no CPU path: inputs must be on the GPU")
         if x.dim() != 4 or x.shape[1] != self._in_chans:
@@ -575,7 +597,7 @@ class mFormerV1(nn.Module):
         else:
             meta = None
         train = torch.is_grad_enabled() and any(p_.requires_grad for p_ in self.parameters())
-        st = self._get_plan(B, H, W, train)
+        st = self._get_plan(B, H, W, train, self._wants_recompute(force_checkpointing))
         self._active = st
         drop = self._draw_drop_scales(st, B, x.device)
         if train:
@@ -585,12 +607,12 @@ class mFormerV1(nn.Module):
         return st, feats, logits
 
     def forward_features(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> torch.Tensor:
-        """[B, D3] features after final_norm (mFormerV1.py:407-529).  `force_checkpointing` is accepted
-        for interface parity; the plan keeps activations in its workspace instead of recomputing."""
-        return self._run(x, meta)[1]
+        """[B, D3] features after final_norm (mFormerV1.py:407-529).  `force_checkpointing` / the config's
+        GRADIENT_CHECKPOINTING flag select a recompute plan (block inputs kept, activations recomputed in backward)."""
+        return self._run(x, meta, force_checkpointing)[1]
 
     def forward(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> Dict[str, torch.Tensor]:
-        st, feats, logits = self._run(x, meta)
+        st, feats, logits = self._run(x, meta, force_checkpointing)
         B = x.shape[0]
         acast = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
         out = {}

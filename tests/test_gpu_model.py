@@ -637,3 +637,95 @@ def test_opt_in_hierarchical_refinement(golden_dir):
     out = model(x.cuda(), None)
     O.probe_loss(out).backward()  # differentiable through the HIP GEMM of the prior
     assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in model.parameters())
+
+
+# ----------------------------------------------------------------------------------------------------
+# A16: activation recompute (gradient checkpointing) -- convnext.py:89-100, rope_2d_mhsa.py:617-641
+# ----------------------------------------------------------------------------------------------------
+def _grads(model):
+    return {k: p_.grad.detach().clone() for k, p_ in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name,dtype", [("tiny_dp", "fp32"), ("tiny_b", "bf16"), ("tiny_c", "fp32")])
+def test_recompute_plan_equals_kept_activations(name, dtype, golden_dir):
+    """forward(force_checkpointing=True) in training mode runs a recompute plan: same logits bit for bit, same gradients
+    (up to the summation order of the atomically accumulated ones), smaller workspace; it is ignored in eval mode, as in
+    the reference's blocks (`use_checkpoint and self.training`)."""
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    model = build(name, spec, sd, dtype)
+    model.train(True)
+    model._inject_drop = drops
+    xs, ms = x.cuda(), meta.cuda() if meta is not None else None
+    out_a = model(xs, ms)
+    O.probe_loss(out_a).backward()
+    ga = _grads(model)
+    model.zero_grad(set_to_none=True)
+    out_b = model(xs, ms, force_checkpointing=True)
+    assert model._active["handle"] is not None and any(k[-1] for k in model._plans), "no recompute plan was created"
+    for t in out_a:
+        assert torch.equal(out_a[t], out_b[t]), t
+    O.probe_loss(out_b).backward()
+    gb = _grads(model)
+    for k in ga:
+        err = (ga[k] - gb[k]).norm().item()
+        assert err <= 1e-5 * ga[k].norm().item() + 1e-7, (k, err, ga[k].norm().item())
+    B = x.shape[0]
+    deep = max(spec.conv_depths + spec.rope_depths) > 1   # one block per stage: nothing to share
+    w_ck, w_keep = model.workspace_bytes(B, IMG[name], recompute=True), model.workspace_bytes(B, IMG[name], recompute=False)
+    assert w_ck < w_keep if deep else w_ck == w_keep, (w_ck, w_keep)
+    # oracle check of the recompute path itself (fp32 cases)
+    if dtype == "fp32":
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        O.probe_loss(O.forward(osd, spec, x, meta, drops)).backward()
+        glob, wk = _grad_errors(model, osd)
+        assert glob <= 1e-3, (glob, wk)
+    # eval mode: the flag is ignored (no recompute plan for an eval forward under grad)
+    n_plans = len(model._plans)
+    model.train(False)
+    model(xs, ms, force_checkpointing=True)
+    assert not any(k[-1] for k in list(model._plans)[n_plans:])
+
+
+def test_recompute_sm_b24_production_dispatch_and_config_flag():
+    """The recompute plan at the production dispatch (sm@224, B = 24, bf16, DropPath on), selected the way the reference's
+    train loop selects it (TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS / model.use_checkpoint, train.py:93-110),
+    run segment by segment as DataParallel runs it, and backward twice over one forward (the second pass has to restore
+    the last block of each stage as well)."""
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300)), drop_path_rate=0.2)
+    B = 24
+    sd = O.seeded_state_dict(O.param_shapes(spec), 31)
+    x, meta = O.seeded_inputs(spec, B, 224, 32)
+    drops = _drop_scales(spec, B, 33)
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype("bf16")
+    model.train(True)
+    model._inject_drop = drops
+    xs, ms = x.cuda(), meta.cuda()
+    out_a = model(xs, ms)
+    O.probe_loss(out_a).backward()
+    ga = _grads(model)
+    kept_ws = model._active["ws"].numel()
+    model.zero_grad(set_to_none=True)
+
+    model.use_checkpoint = True           # what train.py sets from the config flag
+    seen = []
+    model._segment_hook = seen.append     # segment-wise backward, as under DataParallel
+    out_b = model(xs, ms)
+    assert model._active["ws"].numel() < 0.75 * kept_ws, (model._active["ws"].numel(), kept_ws)
+    for t in out_a:
+        assert torch.equal(out_a[t], out_b[t]), t
+    loss = O.probe_loss(out_b)
+    loss.backward(retain_graph=True)
+    assert seen == [0, 1, 2, 3]
+    gb = _grads(model)
+    for k in ga:
+        err = (ga[k] - gb[k]).norm().item()
+        assert err <= 1e-5 * ga[k].norm().item() + 1e-7, (k, err, ga[k].norm().item())
+    # a second backward over the same forward accumulates the same gradient again
+    model._segment_hook = None
+    loss.backward()
+    for k, p_ in model.named_parameters():
+        err = (p_.grad - 2 * ga[k]).norm().item()
+        assert err <= 2e-5 * ga[k].norm().item() + 2e-7, (k, err)
