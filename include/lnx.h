@@ -92,6 +92,17 @@ int lnx_amax(const void* x, int x_dtype, int64_t ldx, int rows, int cols, float*
 int lnx_quantize_fp8(const void* x, int x_dtype, int64_t ldx, int rows, int cols, const float* amax, void* y, int64_t ldy, float* scale_out, void* stream);
 int lnx_gemm_nt_fp8(const lnx_gemm_args* args, const float* a_scale, const float* w_scale, void* stream);
 
+/* MXFP8 (OCP microscaling): e4m3 elements, one E8M0 (power-of-two) scale per 32 consecutive elements of a row; the block
+ * scales are operands of v_mfma_scale_f32_16x16x128_f8f6f4 itself, so there is no amax pass, no scale state and no
+ * dequantisation step -- the CDNA4-native form of the fp8 path.
+ *   lnx_quantize_mxfp8  per block: e = smallest exponent with amax * 2^-e <= 448, y = e4m3(x * 2^-e) (round to nearest even),
+ *                       scales: bytes [cols/128][rows][4], byte j of (ks, r) = e + 127 of block 4 ks + j of row r
+ *                       (cols % 128 == 0; x fp32 or bf16, 16-byte aligned rows; ldy in bytes)
+ *   lnx_gemm_nt_mxfp8   C = epilogue( dequant(A8) . dequant(W8)^T ): `args` as lnx_gemm_nt_fp8, a_scales [K/128][M][4],
+ *                       w_scales [K/128][N][4] as written by lnx_quantize_mxfp8 */
+int lnx_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* y, int64_t ldy, void* scales, void* stream);
+int lnx_gemm_nt_mxfp8(const lnx_gemm_args* args, const void* a_scales, const void* w_scales, void* stream);
+
 /* Weight gradient  dW[N,K] += dY[M,N]^T . A[M,K]  and optionally db[N] += colsum(dY).
  * Split over M across workgroups.  Partial tiles are added to dW/db with fp32 atomics, or, when the
  * caller passes a workspace (ws), stored there and summed into dW/db by a second kernel in a fixed

@@ -34,6 +34,8 @@ struct GemmP {
     int tiles_m, tiles_n;
     const float* sa = nullptr;  // fp8 kernels: dequantisation scales of A and W (device scalars)
     const float* sw = nullptr;
+    const uint32_t* mxa = nullptr;  // MXFP8 kernels: E8M0 block scales of A / W, [K/128][rows] dwords (byte j = block 4 ks + j)
+    const uint32_t* mxw = nullptr;
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on

@@ -6,6 +6,14 @@
 // it at twice the bf16 MFMA rate.  Operand lane map, verified with exact integer data (tools/ubench/mfma_f8_layout.hip):
 // lane l holds A[row l & 15][k = 32 (l >> 4) + j] in byte j of its 8 dwords, B likewise with the column on l & 15; C/D as
 // every 16x16 MFMA.  A lane's 32 bytes are the two 16-byte chunks 2g, 2g+1 of the LDS row (XOR swizzle per chunk).
+//
+// MXFP8 (lnx_quantize_mxfp8 / lnx_gemm_nt_mxfp8): the same pipeline with the instruction's block scales in use -- one
+// E8M0 (power-of-two) scale per 32 consecutive K elements of a row, applied by the matrix core itself.  What the hardware
+// takes as "k" (tools/ubench/mfma_mx_map.hip, mfma_mx_scale.hip): a lane's dwords 0-3 are k = 16 g .. 16 g + 15, its
+// dwords 4-7 are k = 64 + 16 g .. 64 + 16 g + 15, and the scale of block kb of row r is the selected byte of lane
+// 16 kb + r's scale register.  So the MX kernel reads chunks g and g + 4 of the LDS row, and its scales travel with the
+// tile: one more LDS-DMA instruction per wave and stage brings a dword (the four block scales of this K slice) per tile
+// row from the [K/128][rows] scale array, and each lane picks its byte with ds_read_u8.
 #include "gemm_common.hpp"
 
 namespace lnxg {
@@ -21,19 +29,22 @@ namespace lnxg {
 
 constexpr int F8_BM = 256, F8_BN = 128, F8_BK = 128;   // BK in elements = bytes
 constexpr int F8_STAGE = (F8_BM + F8_BN) * ROWB;       // 48 KiB
+constexpr int F8_SCALES = 8 * 64 * 4;                  // MX: one dword per tile row (384 used), one 256-byte DMA per wave
 constexpr int F8_NSTAGE = 3;
 constexpr int F8_LD = (F8_BM + F8_BN) / 8 / 8;         // 1-KiB LDS-DMA instructions per wave per stage = 6
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
-__device__ __forceinline__ void mfma_f8(f32x4_t& acc, const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi) {
+__device__ __forceinline__ void mfma_f8(f32x4_t& acc, const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi, int sa = 0x7f, int sb = 0x7f) {
     const i32x8_t a = {(int)a_lo.x, (int)a_lo.y, (int)a_lo.z, (int)a_lo.w, (int)a_hi.x, (int)a_hi.y, (int)a_hi.z, (int)a_hi.w};
     const i32x8_t b = {(int)b_lo.x, (int)b_lo.y, (int)b_lo.z, (int)b_lo.w, (int)b_hi.x, (int)b_hi.y, (int)b_hi.z, (int)b_hi.w};
-    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);  // e4m3 x e4m3, block scales 2^0
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 0, 0, 0, sa, 0, sb);  // e4m3 x e4m3; scale = byte 0 of sa / sb (E8M0, 0x7f = 2^0)
 }
 
-template <bool OUT_F32, int F>
+template <bool OUT_F32, int F, bool MX>
 __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
+    constexpr int STAGE = F8_STAGE + (MX ? F8_SCALES : 0);
+    constexpr int NLD = F8_LD + (MX ? 1 : 0);  // VMEM instructions per wave and stage
     typedef bf16_t T;  // type of C / c2 / aux
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3][A 256 rows | W 128 rows][128 B]
     const int tid = threadIdx.x;
@@ -66,13 +77,34 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
             src[j] = p.W + (int64_t)n * p.ldw + ((slot ^ row_key(wr)) << 4);
         }
     }
+    // MX: lane `lane` of wave `wave` fetches the scale dword of tile row 64 wave + lane (A rows 0..255, W rows 256..383,
+    // the last two waves re-fetch the last W row: every wave issues the same number of VMEM instructions)
+    const uint32_t* sc_src = nullptr;
+    int64_t sc_step = 0;
+    if constexpr (MX) {
+        const int row = 64 * wave + lane;
+        if (row < F8_BM) {
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            sc_src = p.mxa + m;
+            sc_step = p.M;
+        } else {
+            int n = n0 + row - F8_BM;
+            if (row >= F8_BM + F8_BN || n >= p.N) n = p.N - 1;
+            sc_src = p.mxw + n;
+            sc_step = p.N;
+        }
+    }
     auto issue_tile = [&](int kt, int stage) {
 #pragma unroll
         for (int j = 0; j < F8_LD; ++j) {
             const int i = wave + 8 * j;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (int64_t)kt * F8_BK),
-                                             (__attribute__((address_space(3))) void*)(smem + stage * F8_STAGE + i * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + i * 1024), 16, 0, 0);
         }
+        if constexpr (MX)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc_src + (int64_t)kt * sc_step),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + F8_STAGE + wave * 256), 4, 0, 0);
     };
 
     const int frag_row = (s >> 2) * 16 + (s & 3);
@@ -80,7 +112,9 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
     const int a_row0 = wm * 64 + frag_row;
     const int w_row0 = F8_BM + wn * 64 + frag_row;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const uint32_t ch0 = (uint32_t)(((2 * g) ^ frag_key) << 4), ch1 = (uint32_t)(((2 * g + 1) ^ frag_key) << 4);  // bytes 32g .. 32g+31 of the row
+    // plain: bytes 32g .. 32g+31 of the row (any k order does, as long as A and W agree); MX: the hardware's own k order
+    const uint32_t ch0 = (uint32_t)(((MX ? g : 2 * g) ^ frag_key) << 4), ch1 = (uint32_t)(((MX ? g + 4 : 2 * g + 1) ^ frag_key) << 4);
+    const uint32_t sc_a0 = F8_STAGE + (wm * 64 + frag_row) * 4 + g, sc_w0 = F8_STAGE + (F8_BM + wn * 64 + frag_row) * 4 + g;
     const uint32_t a_off0 = a_row0 * ROWB + ch0, a_off1 = a_row0 * ROWB + ch1;
     const uint32_t w_off0 = w_row0 * ROWB + ch0, w_off1 = w_row0 * ROWB + ch1;
 
@@ -95,19 +129,32 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
     issue_tile(1, 1);
     // ping-pong wave groups, two barriers per K slice, counted waits: see gemm_nt_v2_kernel
     const int grp = wave >> 2;
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (MX) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t st = lds_base + (kt % F8_NSTAGE) * F8_STAGE;
+        const uint32_t st = lds_base + (kt % F8_NSTAGE) * STAGE;
         uint4 wf0[4], af0[4], wf1[4], af1[4];
         F8_DS_READ4(wf0, st + w_off0);
         F8_DS_READ4(af0, st + a_off0);
         F8_DS_READ4(wf1, st + w_off1);
         F8_DS_READ4(af1, st + a_off1);
+        int scw[4], sca[4];
+        if constexpr (MX) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // fragment i of this lane is tile row frag_row + 4 i: 16 bytes further on
+                asm volatile("ds_read_u8 %0, %1" : "=v"(scw[i]) : "v"(st + sc_w0 + 16 * i) : "memory");
+                asm volatile("ds_read_u8 %0, %1" : "=v"(sca[i]) : "v"(st + sc_a0 + 16 * i) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) scw[i] = sca[i] = 0x7f;
+        }
         if (kt + 2 < nk) {
             issue_tile(kt + 2, (kt + 2) % F8_NSTAGE);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (MX) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -118,16 +165,18 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) mfma_f8(acc[ni][mi], wf0[ni], wf1[ni], af0[mi], af1[mi]);
+            for (int mi = 0; mi < 4; ++mi) mfma_f8(acc[ni][mi], wf0[ni], wf1[ni], af0[mi], af1[mi], scw[ni], sca[mi]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!(grp && kt + 1 == nk)) __builtin_amdgcn_s_barrier();
     }
-    const float alpha = (p.sa ? p.sa[0] : 1.0f) * (p.sw ? p.sw[0] : 1.0f);
+    if constexpr (!MX) {
+        const float alpha = (p.sa ? p.sa[0] : 1.0f) * (p.sw ? p.sw[0] : 1.0f);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] *= alpha;
+            for (int j = 0; j < 4; ++j) acc[i][j] *= alpha;
+    }
     gemm_epilogue_fast<T, OUT_F32, F>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
@@ -194,6 +243,61 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const TX* __restrict_
     }
 }
 
+// MXFP8 (OCP microscaling, e4m3 elements): one thread per 32-element block.  Block scale 2^e with the smallest e such that
+// amax * 2^-e <= 448 (no element saturates), stored as E8M0 (e + 127) in byte (kb & 3) of dword [kb >> 2][row] of the scale
+// array; elements are e4m3(x * 2^-e), round to nearest even.  A zero block gets the smallest scale (E8M0 0).
+__device__ __forceinline__ void mx_block(const float (&f)[32], uint32_t (&w)[8], uint32_t& e8) {
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) am = fmaxf(am, fabsf(f[j]));
+    const uint32_t bits = __float_as_uint(am);
+    // amax = 1.m * 2^E: e = E - 8 if 1.m <= 1.75 (448 = 1.75 * 2^8) else E - 7; biased: (E + 127) - 8 [+ 1]
+    int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+    e = e < 0 ? 0 : (e > 254 ? 254 : e);
+    e8 = (uint32_t)e;
+    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);  // 2^(127 - e), exact
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 1] * inv, -448.f), 448.f), 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(f[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(f[4 * h + 3] * inv, -448.f), 448.f), pk, true);
+        w[h] = (uint32_t)pk;
+    }
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const TX* __restrict__ x, int64_t ldx, int rows, int cols, unsigned char* __restrict__ y,
+                                                             int64_t ldy, unsigned char* __restrict__ scales) {
+    const int bpr = cols / 32;
+    const int64_t total = (int64_t)rows * bpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / bpr;
+        const int kb = (int)(i - r * bpr);
+        const TX* src = x + r * ldx + kb * 32;
+        float f[32];
+        if constexpr (sizeof(TX) == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Vec16<TX> v;
+                v.raw = ld16(src + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[8 * q + j] = v.get(j);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(src + 4 * q);
+                f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+            }
+        }
+        uint32_t w[8], e8;
+        mx_block(f, w, e8);
+        unsigned char* dst = y + r * ldy + kb * 32;
+        st16(dst, make_uint4(w[0], w[1], w[2], w[3]));
+        st16(dst + 16, make_uint4(w[4], w[5], w[6], w[7]));
+        scales[((int64_t)(kb >> 2) * rows + r) * 4 + (kb & 3)] = (unsigned char)e8;
+    }
+}
+
 }  // namespace lnxg
 using namespace lnxg;
 
@@ -224,15 +328,17 @@ extern "C" int lnx_quantize_fp8(const void* x, int x_dtype, int64_t ldx, int row
     return 0;
 }
 
-extern "C" int lnx_gemm_nt_fp8(const lnx_gemm_args* a, const float* a_scale, const float* w_scale, void* stream) {
-    LNX_CHECK(a != nullptr && a->A && a->W && a->C, "lnx_gemm_nt_fp8: null operand");
-    LNX_CHECK(a->dtype == LNX_BF16, "lnx_gemm_nt_fp8: dtype (of C / c2 / aux) must be LNX_BF16");
-    LNX_CHECK(a->M >= 256 && a->N > 0 && a->K >= 256 && a->K % 128 == 0, "lnx_gemm_nt_fp8: M=%d N=%d K=%d (M >= 256, K %% 128 == 0, K >= 256)", a->M, a->N, a->K);
-    LNX_CHECK(a->lda % 16 == 0 && a->ldw % 16 == 0 && ((((uintptr_t)a->A) | ((uintptr_t)a->W)) & 15) == 0, "lnx_gemm_nt_fp8: A/W rows must be 16-byte aligned");
+static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float* w_scale, const void* mxa, const void* mxw, void* stream, const char* who) {
+    LNX_CHECK(a != nullptr && a->A && a->W && a->C, "%s: null operand", who);
+    LNX_CHECK(a->dtype == LNX_BF16, "%s: dtype (of C / c2 / aux) must be LNX_BF16", who);
+    LNX_CHECK(a->M >= 256 && a->N > 0 && a->K >= 256 && a->K % 128 == 0, "%s: M=%d N=%d K=%d (M >= 256, K %% 128 == 0, K >= 256)", who, a->M, a->N, a->K);
+    LNX_CHECK(a->lda % 16 == 0 && a->ldw % 16 == 0 && ((((uintptr_t)a->A) | ((uintptr_t)a->W)) & 15) == 0, "%s: A/W rows must be 16-byte aligned", who);
     LNX_CHECK(a->a_mode == LNX_ADDR_PLAIN && a->c_mode == LNX_ADDR_PLAIN && a->c_map.group == 0 && a->c_map.pad == 0 && a->c_map.off == 0,
-              "lnx_gemm_nt_fp8: plain addressing only");
-    if (a->act == LNX_ACT_GELU_BWD) LNX_CHECK(a->aux != nullptr, "lnx_gemm_nt_fp8: GELU_BWD needs aux");
-    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_gemm_nt_fp8: rowscale needs rows_per_sample");
+              "%s: plain addressing only", who);
+    if (a->act == LNX_ACT_GELU_BWD) LNX_CHECK(a->aux != nullptr, "%s: GELU_BWD needs aux", who);
+    if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "%s: rowscale needs rows_per_sample", who);
+    const bool mx = mxa != nullptr;
+    if (mx) LNX_CHECK(mxw != nullptr && ((((uintptr_t)mxa) | ((uintptr_t)mxw)) & 3) == 0, "%s: block-scale arrays must be 4-byte aligned", who);
     GemmP p;
     p.A = (const unsigned char*)a->A; p.W = (const unsigned char*)a->W; p.C = (unsigned char*)a->C; p.C2 = (unsigned char*)a->c2;
     p.aux = (const unsigned char*)a->aux; p.bias = a->bias; p.gamma = a->gamma; p.rowscale = a->rowscale; p.res = a->res;
@@ -245,30 +351,62 @@ extern "C" int lnx_gemm_nt_fp8(const lnx_gemm_args* a, const float* a_scale, con
     p.tiles_m = cdiv(a->M, F8_BM);
     p.tiles_n = cdiv(a->N, F8_BN);
     p.sa = a_scale; p.sw = w_scale;
+    p.mxa = (const uint32_t*)mxa; p.mxw = (const uint32_t*)mxw;
     const bool out_f32 = a->out_f32 != 0;
     const int f = fast_epilogue_mask(p, out_f32);
-    LNX_CHECK(f != (int)F_GENERIC && a->gamma == nullptr, "lnx_gemm_nt_fp8: this epilogue needs the generic form, which the fp8 kernel does not carry");
+    LNX_CHECK(f != (int)F_GENERIC && a->gamma == nullptr, "%s: this epilogue needs the generic form, which the fp8 kernels do not carry", who);
     const int grid = p.tiles_m * p.tiles_n;
-    const size_t lds = F8_NSTAGE * (size_t)F8_STAGE;
     hipStream_t st = (hipStream_t)stream;
-#define F8_LAUNCH(O, FF)                                                                                                              \
+#define F8_LAUNCH_(O, FF, MXV)                                                                                                        \
     do {                                                                                                                              \
+        const size_t lds = F8_NSTAGE * (size_t)(F8_STAGE + ((MXV) ? F8_SCALES : 0));                                                  \
         static bool attr = false;                                                                                                     \
         if (!attr) {                                                                                                                  \
-            LNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_fp8_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            LNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_fp8_kernel<O, FF, MXV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             attr = true;                                                                                                              \
         }                                                                                                                             \
-        hipLaunchKernelGGL((gemm_nt_fp8_kernel<O, FF>), dim3(grid), dim3(512), lds, st, p);                                           \
+        hipLaunchKernelGGL((gemm_nt_fp8_kernel<O, FF, MXV>), dim3(grid), dim3(512), lds, st, p);                                      \
+    } while (0)
+#define F8_LAUNCH(O, FF)                 \
+    do {                                 \
+        if (mx) F8_LAUNCH_(O, FF, true); \
+        else F8_LAUNCH_(O, FF, false);   \
     } while (0)
     if (out_f32) {
-        LNX_CHECK(f == (F_BIAS | F_RES), "lnx_gemm_nt_fp8: an fp32 output needs bias + residual (the model's form)");
+        LNX_CHECK(f == (F_BIAS | F_RES), "%s: an fp32 output needs bias + residual (the model's form)", who);
         F8_LAUNCH(true, F_BIAS | F_RES);
     } else if (f == 0) F8_LAUNCH(false, 0);
     else if (f == F_BIAS) F8_LAUNCH(false, F_BIAS);
     else if (f == (F_BIAS | F_C2 | F_GELU)) F8_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
     else if (f == F_GELU_BWD) F8_LAUNCH(false, F_GELU_BWD);
-    else LNX_CHECK(false, "lnx_gemm_nt_fp8: unsupported epilogue feature set %d", f);
+    else LNX_CHECK(false, "%s: unsupported epilogue feature set %d", who, f);
 #undef F8_LAUNCH
+#undef F8_LAUNCH_
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_gemm_nt_fp8(const lnx_gemm_args* a, const float* a_scale, const float* w_scale, void* stream) {
+    return launch_fp8(a, a_scale, w_scale, nullptr, nullptr, stream, "lnx_gemm_nt_fp8");
+}
+
+extern "C" int lnx_gemm_nt_mxfp8(const lnx_gemm_args* a, const void* a_scales, const void* w_scales, void* stream) {
+    LNX_CHECK(a_scales != nullptr && w_scales != nullptr, "lnx_gemm_nt_mxfp8: null block-scale array");
+    return launch_fp8(a, nullptr, nullptr, a_scales, w_scales, stream, "lnx_gemm_nt_mxfp8");
+}
+
+extern "C" int lnx_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, int rows, int cols, void* y, int64_t ldy, void* scales, void* stream) {
+    LNX_CHECK(x && y && scales && rows > 0 && cols > 0, "lnx_quantize_mxfp8: null operand / empty");
+    LNX_CHECK(x_dtype == LNX_F32 || x_dtype == LNX_BF16, "lnx_quantize_mxfp8: bad dtype %d", x_dtype);
+    LNX_CHECK(cols % 128 == 0 && ldx % 8 == 0 && ldy % 16 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && (((uintptr_t)scales) & 3) == 0,
+              "lnx_quantize_mxfp8: cols %% 128, 16-byte aligned rows, 4-byte aligned scales");
+    const int64_t blocks = (int64_t)rows * (cols / 32);
+    int grid = (int)((blocks + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (x_dtype == LNX_F32)
+        hipLaunchKernelGGL(quantize_mxfp8_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, rows, cols, (unsigned char*)y, ldy, (unsigned char*)scales);
+    else
+        hipLaunchKernelGGL(quantize_mxfp8_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, rows, cols, (unsigned char*)y, ldy, (unsigned char*)scales);
     LNX_LAUNCH_CHECK();
     return 0;
 }

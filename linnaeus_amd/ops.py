@@ -103,6 +103,45 @@ def gemm_nt_fp8(A8, a_scale, W8, w_scale, out, *, bias=None, act=L.ACT_NONE, aux
     return out
 
 
+def quantize_mxfp8(x):
+    """(x8, scales): OCP MXFP8 -- e4m3fn elements with one power-of-two (E8M0) scale per 32 consecutive elements of a row.
+    x8: torch.float8_e4m3fn [rows, cols]; scales: uint8 [cols/128, rows, 4] (byte j of [ks, r] = block 4 ks + j of row r),
+    the layout lnx_gemm_nt_mxfp8 streams.  See lnx_quantize_mxfp8."""
+    x2 = x.reshape(-1, x.shape[-1])
+    rows, cols = x2.shape
+    y = torch.empty(rows, cols, device=x.device, dtype=torch.uint8)
+    sc = torch.empty(cols // 128, rows, 4, device=x.device, dtype=torch.uint8)
+    L.check(L.lib().lnx_quantize_mxfp8(_p(x2), code_of(x2), C.c_int64(x2.stride(0)), rows, cols, _p(y), C.c_int64(y.stride(0)), _p(sc), _stream()),
+            "lnx_quantize_mxfp8")
+    return y.view(torch.float8_e4m3fn), sc
+
+
+def dequantize_mxfp8(x8, scales):
+    """fp32 tensor an MXFP8 pair stands for (tests, debugging)."""
+    rows, cols = x8.shape
+    e = scales.permute(1, 0, 2).reshape(rows, cols // 32).to(torch.float32) - 127.0
+    return (x8.to(torch.float32).view(rows, cols // 32, 32) * torch.exp2(e).unsqueeze(-1)).view(rows, cols)
+
+
+def gemm_nt_mxfp8(A8, a_scales, W8, w_scales, out, *, bias=None, act=L.ACT_NONE, aux=None, c2=None, rowscale=None, rows_per_sample=0, res=None):
+    """out = epilogue(dequant(A8) . dequant(W8)^T) with MXFP8 operands (block scales applied by the matrix core); see lnx_gemm_nt_mxfp8."""
+    a = L.GemmArgs()
+    a.dtype = L.BF16
+    a.M, a.N, a.K = A8.shape[0], W8.shape[0], W8.shape[1]
+    a.A, a.lda = _p(A8), A8.stride(0)
+    a.W, a.ldw = _p(W8), W8.stride(0)
+    a.C, a.ldc = _p(out), out.stride(0)
+    a.out_f32 = int(out.dtype == torch.float32)
+    a.bias = _p(bias)
+    a.c2, a.ldc2 = _p(c2), (c2.stride(0) if c2 is not None else 0)
+    a.act, a.aux, a.ldaux = act, _p(aux), (aux.stride(0) if aux is not None else 0)
+    a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
+    a.res, a.ldres = _p(res), (res.stride(0) if res is not None else 0)
+    assert tuple(a_scales.shape) == (a.K // 128, a.M, 4) and tuple(w_scales.shape) == (a.K // 128, a.N, 4)
+    L.check(L.lib().lnx_gemm_nt_mxfp8(C.byref(a), _p(a_scales), _p(w_scales), _stream()), "lnx_gemm_nt_mxfp8")
+    return out
+
+
 def gemm_tn(dY, A, dW, *, M=None, N=None, K=None, lda=None, lddw=None, db=None, a_patch=None, k_perm_c=0, k_store=0, splits=0, dtype=None):
     a = L.WgradArgs()
     a.dtype = dtype if dtype is not None else code_of(dY)

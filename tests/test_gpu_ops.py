@@ -411,3 +411,72 @@ def test_fp8_quantize_and_gemm(M, N, K, xd):
         ops.gemm_nt_fp8(x8, sx, w8, sw, o32, bias=bias, res=res, rowscale=rs, rows_per_sample=rps)
         rowf = rs.double().cpu()[torch.arange(M) // rps].reshape(M, 1)
         torch.testing.assert_close(o32.double().cpu(), res.double().cpu() + rowf * h, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()))
+
+
+def _mx_reference(x):
+    """The definition lnx_quantize_mxfp8 implements, restated with torch integer ops: per 32-element block the smallest
+    power of two 2^e with amax * 2^-e <= 448, elements = e4m3fn(x * 2^-e) (torch's round-to-nearest-even conversion)."""
+    M, K = x.shape
+    xb = x.float().view(M, K // 32, 32)
+    bits = xb.abs().amax(-1).contiguous().view(torch.int32)
+    e = ((bits >> 23) & 0xFF) - 8 + ((bits & 0x7FFFFF) > 0x600000).int()
+    e = e.clamp(0, 254)
+    inv = ((254 - e) << 23).view(torch.float32)
+    q = (xb * inv.unsqueeze(-1)).clamp(-448, 448).to(torch.float8_e4m3fn).view(M, K)
+    return q, e.to(torch.uint8)  # e: [M, K/32]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
+@pytest.mark.parametrize("xd", [L.BF16, L.F32])
+def test_mxfp8_quantize_and_gemm(M, N, K, xd):
+    """MXFP8 path (block-scaled e4m3, scales applied inside v_mfma_scale_f32_16x16x128_f8f6f4).  Quantisation is checked
+    byte for byte against the torch restatement above on data whose blocks span ~2^±20 (plus an all-zero block, a tiny
+    block and a block at the top of the fp32/bf16 range); the GEMM against the fp64 product of the DEQUANTISED operands,
+    so the only error left is fp32 accumulation order -- which also proves the scale layout and the instruction's k order."""
+    gen = g(M * 7 + N + K)
+    x = torch.randn(M, K, generator=gen) * torch.exp2(torch.randint(-20, 21, (M, K // 32, 1), generator=gen).float()).expand(M, K // 32, 32).reshape(M, K)
+    x[3, 32:64] = 0.0
+    x[5, 0:32] = 1e-30
+    x[7, 64:96] = 3e38
+    x = x.cuda().to(DT[xd])
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5 * torch.exp2(torch.randint(-3, 4, (N, K // 32, 1), generator=gen).float()).expand(N, K // 32, 32).reshape(N, K))
+    w = w.cuda().to(torch.bfloat16)
+    x8, sx = ops.quantize_mxfp8(x)
+    w8, sw = ops.quantize_mxfp8(w)
+    q, e = _mx_reference(x)
+    assert torch.equal(x8.view(torch.uint8), q.view(torch.uint8))
+    assert torch.equal(sx.permute(1, 0, 2).reshape(M, K // 32), e)
+    # what the format promises: 3 mantissa bits relative to the element, 2^-9 of the block's scale at the bottom
+    xd_ = ops.dequantize_mxfp8(x8, sx)
+    blk_amax = x.float().abs().view(M, K // 32, 32).amax(-1, keepdim=True).expand(M, K // 32, 32).reshape(M, K)
+    assert ((xd_ - x.float()).abs() <= x.float().abs() / 16 + blk_amax / 2 ** 16).all()
+    # GEMM on well-scaled activations (the wide-range x above would overflow a bf16 output)
+    a = (torch.randn(M, K, generator=gen) * torch.exp2(torch.randint(-4, 5, (M, K // 32, 1), generator=gen).float()).expand(M, K // 32, 32).reshape(M, K)).cuda().to(DT[xd])
+    a8, sa = ops.quantize_mxfp8(a)
+    ad = ops.dequantize_mxfp8(a8, sa).double().cpu()
+    wd = ops.dequantize_mxfp8(w8, sw).double().cpu()
+    ref = ad @ wd.t()
+    tol = 8e-3 * max(1.0, ref.abs().max().item())
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out)
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=8e-3, atol=tol)
+    bias = torch.randn(N, generator=gen).cuda()
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out, bias=bias)
+    torch.testing.assert_close(out.double().cpu(), ref + bias.double().cpu(), rtol=8e-3, atol=tol)
+    pre = torch.empty_like(out)
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out, bias=bias, act=L.ACT_GELU, c2=pre)
+    h = ref + bias.double().cpu()
+    torch.testing.assert_close(pre.double().cpu(), h, rtol=8e-3, atol=tol)
+    torch.testing.assert_close(out.double().cpu(), torch.nn.functional.gelu(h), rtol=8e-3, atol=tol)
+    res = torch.randn(M, N, generator=gen).cuda()
+    rs = (torch.rand(4, generator=gen) + 0.5).cuda()
+    rps = (M + 3) // 4
+    o32 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, o32, bias=bias, res=res, rowscale=rs, rows_per_sample=rps)
+    rowf = rs.double().cpu()[torch.arange(M) // rps].reshape(M, 1)
+    torch.testing.assert_close(o32.double().cpu(), res.double().cpu() + rowf * h, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()))
+    # quantisation error of the whole product against the unquantised operands: the number a user cares about
+    full = a.double().cpu() @ w.double().cpu().t()
+    rel = (ref - full).norm() / full.norm()
+    print(f"[mxfp8 M={M} N={N} K={K}] relative error of the MXFP8 product vs the unquantised one: {rel:.3e}")
+    assert rel < 0.05
