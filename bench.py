@@ -67,7 +67,7 @@ def parse():
                          "(config 3: global batch 1024 at 8 GPUs, the point the north-star scaling target is defined at)")
     ap.add_argument("--arch", default="sm")
     ap.add_argument("--img", type=int, default=224)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"], help="fp8: bf16 plus MXFP8 forward products in the RoPE blocks (config 5)")
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
     ap.add_argument("--force-dp", action="store_true", help="single GPU rehearsal of the data-parallel path: RCCL world size 1, collectives issued")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW(fused=True) instead of linnaeus_amd.optim.FusedAdamW")

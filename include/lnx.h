@@ -490,6 +490,11 @@ typedef struct lnx_mformer_cfg {
                                   set of activation buffers and lnx_plan_backward re-runs a block's forward right before its
                                   backward.  Same results bit for bit (the recompute is deterministic and reuses the DropPath
                                   draw of the forward); workspace no longer grows with the depth. */
+    int fp8;                   /* 1 (with dtype = LNX_BF16): the forward products of the RoPE blocks' qkv / fc1 / fc2 Linear layers run
+                                  on the block-scaled fp8 matrix cores (MXFP8: lnx_quantize_mxfp8 + lnx_gemm_nt_mxfp8) -- BASELINE
+                                  config 5's "fp8 MFMA path".  Weights are re-quantised from the fp32 masters every forward,
+                                  activations as they are produced; everything saved for the backward, and the whole backward,
+                                  stay bf16.  Needs RoPE dims and MLP widths that are multiples of 128. */
 } lnx_mformer_cfg;
 
 typedef struct lnx_plan lnx_plan;

@@ -48,6 +48,7 @@ struct OpW {          // a GEMM weight in the T-typed operand arena
     int mode = LNX_PREP_CAST, P = 0;
     bool f32 = false;  // operand kept in fp32 even in bf16 mode (the tiny M = batch meta-head GEMMs)
     int64_t off = 0, off_t = 0;
+    int64_t off8 = 0, off8s = 0;  // fp8 plans: MXFP8 copy [N][K] bytes and its block scales [K/128][N][4] (0: none)
 };
 
 struct ConvBlk {
@@ -122,6 +123,7 @@ struct lnx_plan {
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_cmws = 0, cmws_floats = 0;  // row-range partials of the fused conv-MLP weight gradients
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
+    int64_t o_a8 = 0, o_a8s = 0;  // fp8 plans: MXFP8 copy of the current GEMM's activation operand and its block scales (forward scratch)
     const float* last_drop = nullptr;
     const unsigned char* last_mask = nullptr;
     std::vector<unsigned char> mask_host;
@@ -298,6 +300,12 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     for (int m = 0; m < c.n_meta; ++m)
         if (c.meta_dims[m] <= 0 || c.meta_dims[m] > 16) FAIL("lnx_plan_create: meta dim %d must be in 1..16", c.meta_dims[m]);
 
+    if (c.fp8) {
+        if (c.dtype != LNX_BF16) FAIL("lnx_plan_create: fp8 = 1 needs dtype = LNX_BF16 (fp8 operands, bf16 storage)");
+        for (int s = 0; s < 2; ++s)
+            if (c.dims[2 + s] % 128 != 0 || c.mlp_hidden[s] % 128 != 0)
+                FAIL("lnx_plan_create: fp8 = 1 needs RoPE dims and MLP widths that are multiples of 128 (stage %d: %d / %d)", s + 2, c.dims[2 + s], c.mlp_hidden[s]);
+    }
     lnx_plan* p = new lnx_plan();
     p->c = c;
     p->esz = c.dtype == LNX_BF16 ? 2 : 4;
@@ -473,6 +481,13 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     }
     for (int s = 0; s < 2; ++s)
         for (auto& k : p->conv[s]) k.w49 = cv.take((int64_t)49 * D[s] * 4);
+    if (c.fp8)
+        for (int s = 0; s < 2; ++s)
+            for (auto& k : p->rope[s])
+                for (OpW* w : {&k.qkv, &k.fc1, &k.fc2}) {
+                    w->off8 = cv.take((int64_t)w->N * w->K);
+                    w->off8s = cv.take((int64_t)(w->K / 128) * w->N * 4);
+                }
     const int64_t arena_end = cv.cur;
     (void)arena_end;
 
@@ -605,6 +620,16 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         for (int t = 0; t < c.n_tasks; ++t)
             if (p->logit_ld[t] > maxld) maxld = p->logit_ld[t];
         p->o_dlT = cv.take((int64_t)B * maxld * esz);
+    }
+    if (c.fp8) {
+        int64_t mk = 0;
+        for (int s = 0; s < 2; ++s) {
+            const int64_t M = (int64_t)B * (s == 0 ? p->N2 : p->N3);
+            const int64_t k = c.mlp_hidden[s] > D[2 + s] ? c.mlp_hidden[s] : D[2 + s];
+            if (M * k > mk) mk = M * k;
+        }
+        p->o_a8 = cv.take(mk);
+        p->o_a8s = cv.take(mk / 32);
     }
     p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
     p->lnws_side_floats = (int64_t)256 * 2 * D[3];
@@ -886,6 +911,21 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
 
 const lnx_rowmap IDM = {0, 0, 0};
 
+// A RoPE-block Linear in the forward: on fp8 plans (and M >= 256, the MXFP8 kernel's floor) the bf16 activation `g.A` is
+// quantised into the plan's MXFP8 scratch and the product runs on lnx_gemm_nt_mxfp8 with the weight's MXFP8 copy; the
+// epilogue (bias, GELU + pre-activation copy, fp32 residual with DropPath scale) is the same code either way.
+int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w) {
+    lnx_plan* p = c.p;
+    if (!p->c.fp8 || w.off8s == 0 || g.M < 256) return gemm_nt_t(c, &g);
+    RUN(lnx_quantize_mxfp8(g.A, LNX_BF16, g.lda, g.M, g.K, c.at<void>(p->o_a8), g.K, c.at<void>(p->o_a8s), c.st));
+    g.A = c.at<void>(p->o_a8);
+    g.lda = g.K;
+    g.W = c.at<void>(w.off8);
+    g.ldw = w.K;
+    Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K);
+    return lnx_gemm_nt_mxfp8(&g, c.at<void>(p->o_a8s), c.at<void>(w.off8s), c.st);
+}
+
 
 
 // ------------------------------ forward pieces ------------------------------
@@ -974,7 +1014,7 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1)));
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
-    RUN(gemm_nt_t(c, &g));
+    RUN(linear_fwd(c, g, k.qkv));
     RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), c.st));
     lnx_attn_args a;
     memset(&a, 0, sizeof a);
@@ -990,10 +1030,10 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2)));
     g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
     g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
-    RUN(gemm_nt_t(c, &g));
+    RUN(linear_fwd(c, g, k.fc1));
     g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, xout, C, true);
     g.bias = p->P[k.fc2b]; g.rowscale = p->drop_ptr(p->drop_mlp[s][i]); g.rows_per_sample = N; g.res = c.at<float>(k.xmid); g.ldres = C;
-    RUN(gemm_nt_t(c, &g));
+    RUN(linear_fwd(c, g, k.fc2));
     return 0;
 }
 
@@ -1019,6 +1059,11 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
     RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs), (int)p->n_descs_t, (int)p->prep_blocks, cf.dtype, stream));
     if (p->n_descs_f > 0)
         RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs) + p->n_descs_t, (int)p->n_descs_f, (int)p->prep_blocks_f, LNX_F32, stream));
+    if (cf.fp8)  // MXFP8 copies of the RoPE blocks' forward weights, straight from the fp32 masters
+        for (int s = 0; s < 2; ++s)
+            for (auto& k : p->rope[s])
+                for (const OpW* w : {&k.qkv, &k.fc1, &k.fc2})
+                    RUN(lnx_quantize_mxfp8(p->P[w->param], LNX_F32, w->K, w->N, w->K, c.at<void>(w->off8), w->K, c.at<void>(w->off8s), stream));
 
     // metadata heads of both RoPE stages: forked onto the side stream right after the weight refresh
     int mw_all = 0;

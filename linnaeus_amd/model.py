@@ -33,7 +33,7 @@ class _Cfg(C.Structure):
         ("dtype", C.c_int), ("batch", C.c_int), ("img_h", C.c_int), ("img_w", C.c_int), ("in_chans", C.c_int),
         ("dims", C.c_int * 4), ("conv_depths", C.c_int * 2), ("rope_depths", C.c_int * 2), ("rope_heads", C.c_int * 2),
         ("mlp_hidden", C.c_int * 2), ("n_meta", C.c_int), ("meta_dims", C.c_int * 8), ("only_last_cls", C.c_int),
-        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16), ("inference", C.c_int), ("recompute", C.c_int),
+        ("n_tasks", C.c_int), ("task_classes", C.c_int * 16), ("inference", C.c_int), ("recompute", C.c_int), ("fp8", C.c_int),
     ]
 
 
@@ -243,7 +243,9 @@ class mFormerV1(nn.Module):
         self._dims, self._depths, self._rdepths, self._rheads = dims, depths, rdepths, rheads
         self._hidden = [int(rdims[s] * rratio[s]) for s in range(2)]
         self._in_chans = in_chans
-        self._dtype_code = _DTYPES[str(kwargs.get("compute_dtype", os.environ.get("LNX_DTYPE", M.get("LNX_DTYPE", "bf16")))).lower()]
+        dt_name = str(kwargs.get("compute_dtype", os.environ.get("LNX_DTYPE", M.get("LNX_DTYPE", "bf16")))).lower()
+        self._fp8 = dt_name in ("fp8", "mxfp8")
+        self._dtype_code = L.BF16 if self._fp8 else _DTYPES[dt_name]
         # "direct" (default): parameter gradients are written straight into .grad views of one flat fp32 arena (what
         # loss.backward() + optimizer.step() callers such as the reference's train.py need; zero-copy).  "autograd": the
         # autograd Function returns copies, for torch.autograd.grad() callers (GradNorm-style code).
@@ -301,8 +303,11 @@ class mFormerV1(nn.Module):
 
     # ------------------------------------------------------------------ plan plumbing
     def set_compute_dtype(self, name: str) -> None:
-        """'bf16' (production: bf16 operands, fp32 accumulate/residual) or 'fp32' (strict parity)."""
-        self._dtype_code = _DTYPES[name.lower()]
+        """'bf16' (production: bf16 operands, fp32 accumulate/residual), 'fp32' (strict parity) or 'fp8' (bf16 plus MXFP8
+        forward products in the RoPE blocks' qkv / fc1 / fc2 layers: `lnx_mformer_cfg.fp8`)."""
+        name = name.lower()
+        self._fp8 = name in ("fp8", "mxfp8")
+        self._dtype_code = L.BF16 if self._fp8 else _DTYPES[name]
         self.release_plans()
 
     def _destroy_plan(self, st) -> None:
@@ -327,7 +332,7 @@ class mFormerV1(nn.Module):
 
     @property
     def compute_dtype(self) -> str:
-        return "bf16" if self._dtype_code == L.BF16 else "fp32"
+        return "fp8" if self._fp8 else ("bf16" if self._dtype_code == L.BF16 else "fp32")
 
     def _task_list(self) -> List[str]:
         return list(self.head.keys())
@@ -365,6 +370,7 @@ class mFormerV1(nn.Module):
         cfg = _Cfg()
         cfg.inference = 0 if train else 1
         cfg.recompute = 1 if (train and recompute) else 0
+        cfg.fp8 = 1 if self._fp8 else 0
         cfg.dtype, cfg.batch, cfg.img_h, cfg.img_w, cfg.in_chans = self._dtype_code, B, H, W, self._in_chans
         cfg.dims[:] = self._dims
         cfg.conv_depths[:] = self._depths[:2]
@@ -405,7 +411,7 @@ class mFormerV1(nn.Module):
         frozen model) carry no backward scratch and share activation buffers between blocks; recompute plans (gradient
         checkpointing) keep block inputs only.  The cache is a small LRU: an evicted plan is destroyed and its workspace freed."""
         recompute = bool(train and recompute)
-        key = (B, H, W, self._dtype_code, bool(train), recompute)
+        key = (B, H, W, self._dtype_code, self._fp8, bool(train), recompute)
         st = self._plans.get(key)
         lib = L.lib()
         if st is not None:

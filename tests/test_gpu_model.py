@@ -729,3 +729,72 @@ def test_recompute_sm_b24_production_dispatch_and_config_flag():
     for k, p_ in model.named_parameters():
         err = (p_.grad - 2 * ga[k]).norm().item()
         assert err <= 2e-5 * ga[k].norm().item() + 2e-7, (k, err)
+
+
+# ----------------------------------------------------------------------------------------------------
+# (f-4) / config 5: the fp8 MFMA path at the model level (MXFP8 forward products in the RoPE blocks)
+# ----------------------------------------------------------------------------------------------------
+def test_fp8_mode_sm_b24_against_oracle_and_bf16():
+    """compute dtype 'fp8' = bf16 plan + MXFP8 (block-scaled e4m3) qkv / fc1 / fc2 forward products.  Stated tolerance against
+    the fp32 oracle (the reference has no fp8 code): logits within 0.12 x their scale (bf16 mode: 0.04), arg-max equal
+    wherever the oracle's margin exceeds 4x the error, global relative gradient error <= 12 % (bf16 mode: 5 %) -- the
+    gradients are bf16 products evaluated at the fp8 forward's activations.  Also: the fp8 plan really runs the fp8
+    kernels (its logits differ from the bf16 plan's), and eval / recompute plans work in this mode."""
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)), drop_path_rate=0.2)
+    B = 24
+    sd = O.seeded_state_dict(O.param_shapes(spec), 777)
+    x, meta = O.seeded_inputs(spec, B, 224, 778)
+    drops = _drop_scales(spec, B, 779)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta, drops)
+    O.probe_loss(oout).backward()
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype("bf16")
+    out_bf = {t: v.detach().clone() for t, v in run(model, x, meta, drops, train=True).items()}
+    model.set_compute_dtype("fp8")
+    assert model.compute_dtype == "fp8"
+    out = run(model, x, meta, drops, train=True)
+    worst = 0.0
+    for t, _ in spec.heads:
+        ref = oout[t].detach()
+        got = out[t].float().cpu()
+        err = (got - ref).abs().max().item()
+        scale = max(1.0, ref.abs().max().item())
+        worst = max(worst, err / scale)
+        assert err <= 0.12 * scale, (t, err, scale)
+        srt = ref.sort(-1).values
+        safe = (srt[:, -1] - srt[:, -2]) > 4 * err
+        assert (got.argmax(-1)[safe] == ref.argmax(-1)[safe]).all(), t
+        assert not torch.equal(out[t], out_bf[t]), "the fp8 plan produced the bf16 plan's logits: fp8 kernels not in use"
+    O.probe_loss(out).backward()
+    glob, wk = _grad_errors(model, osd)
+    print(f"[sm B=24/fp8] max logit error / scale {worst:.4f}; global relative gradient error {glob:.3e}; worst tensor {wk[0]} {wk[1]:.2e}")
+    assert glob <= 0.12, (glob, wk)
+    # eval (inference plan) and recompute plan in fp8 mode
+    model.zero_grad(set_to_none=True)
+    ev = run(model, x, meta, None, train=False)
+    model.train(True)
+    model._inject_drop = [None] * len(drops)
+    tr = model(x.cuda(), meta.cuda(), force_checkpointing=True)
+    for t in ev:
+        assert torch.equal(ev[t], tr[t]), t
+    O.probe_loss(tr).backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in model.parameters())
+
+
+def test_fp8_mode_rejects_unsupported_widths(golden_dir):
+    """MXFP8 blocks are 32 wide and a K slice of the kernel 128: the planner refuses other widths loudly (no silent bf16)."""
+    import ctypes as C
+    from linnaeus_amd import _lib as L
+
+    spec, z, sd, x, meta, drops = load_case("tiny_a", golden_dir)
+    model = build("tiny_a", spec, sd, "bf16")
+    model.set_compute_dtype("fp8")
+    cfg = model._make_cfg(2, 64, 64, True)
+    assert cfg.fp8 == 1
+    cfg.mlp_hidden[0] = 192
+    handle = C.c_void_p()
+    with pytest.raises(L.LnxError, match="multiples of 128"):
+        L.check(L.lib().lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")

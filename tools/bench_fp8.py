@@ -1,4 +1,4 @@
-"""fp8 vs bf16 NT GEMM at the model's shapes (sm RoPE stages, xl RoPE stage 2, a 4k cube)."""
+"""fp8 (per-tensor scale) and MXFP8 (block scales in the MFMA) vs bf16 NT GEMM at the model's shapes (sm RoPE stages, xl RoPE stage 2, two cubes)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -24,5 +24,10 @@ for name, M, N, K in shapes:
     tb = t(lambda: ops.gemm_nt(a, w, out))
     t8 = t(lambda: ops.gemm_nt_fp8(a8, sa, w8, sw, out))
     tq = t(lambda: ops.quantize_fp8(a))
+    am, sam = ops.quantize_mxfp8(a)
+    wm, swm = ops.quantize_mxfp8(w)
+    tm = t(lambda: ops.gemm_nt_mxfp8(am, sam, wm, swm, out))
+    tqm = t(lambda: ops.quantize_mxfp8(a))
     fl = 2.0 * M * N * K
-    print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}: bf16 {tb:7.1f} us ({fl / tb / 1e6:6.0f} TF/s)  fp8 {t8:7.1f} us ({fl / t8 / 1e6:6.0f} TF/s)  x{tb / t8:4.2f}   amax+quantise(A) {tq:6.1f} us")
+    print(f"{name:10s} M={M:6d} N={N:5d} K={K:5d}: bf16 {tb:7.1f} us ({fl / tb / 1e6:6.0f} TF/s)  fp8 {t8:7.1f} us ({fl / t8 / 1e6:6.0f} TF/s) x{tb / t8:4.2f}"
+          f"  mxfp8 {tm:7.1f} us ({fl / tm / 1e6:6.0f} TF/s) x{tb / tm:4.2f}   amax+quantise(A) {tq:6.1f} us  mx quantise(A) {tqm:6.1f} us")
