@@ -154,6 +154,11 @@ typedef struct lnx_ln_args {
     int64_t ldadd;
     float* mean;        /* [M] or NULL */
     float* rstd;        /* [M] or NULL */
+    void* y8;           /* optional second output: MXFP8 copy of the bf16 output (exactly lnx_quantize_mxfp8 of y), compact rows
+                           (row m), ldy8 bytes per row, block scales in y8_scales ([C/128][M][4]).  Needs x fp32, y bf16,
+                           an identity y_map and C % 128 == 0: the producer side of the model's fp8 mode. */
+    int64_t ldy8;
+    void* y8_scales;
 } lnx_ln_args;
 int lnx_layernorm_fwd(const lnx_ln_args* args, void* stream);
 

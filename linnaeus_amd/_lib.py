@@ -133,6 +133,7 @@ class LnArgs(C.Structure):
         ("y", C.c_void_p), ("y_dtype", C.c_int), ("ldy", C.c_int64), ("y_map", RowMap),
         ("add", C.c_void_p), ("ldadd", C.c_int64),
         ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("y8", C.c_void_p), ("ldy8", C.c_int64), ("y8_scales", C.c_void_p),
     ]
 
 

@@ -31,6 +31,9 @@ struct LnP {
     RowMap xmap, ymap;
     int M, C;
     float eps;
+    unsigned char* y8 = nullptr;   // optional MXFP8 copy of the bf16 output (ln_fwd_kernel<..., MX = true>)
+    unsigned char* y8s = nullptr;  // its block scales, [C/128][M][4]
+    int64_t ldy8 = 0;
 };
 
 template <typename T> __device__ __forceinline__ float4 load4(const T* p);
@@ -91,8 +94,19 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 // either way (a slot beyond the row reads column 0 and is zeroed afterwards): a load under a branch whose result is
 // merged with a zero is waited for on the spot (s_waitcnt vmcnt(0) right behind it), which turns the V loads of a row
 // into V serial round trips.  gamma / beta live in registers for the whole kernel for the same reason.
-template <typename TX, typename TY, int G, int V, int PAIR = 1, bool FULL = false>
+// MX (PAIR == 1, bf16 output): the row is also written as MXFP8 -- the bf16-rounded output quantised exactly as
+// lnx_quantize_mxfp8 does it.  A 32-element block is the float4 slot i of 8 consecutive lanes: the block maximum is three
+// DPP steps (two quad permutes and a half-row mirror), each lane converts its own 4 values into one dword.
+__device__ __forceinline__ float max8(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));  // row_half_mirror
+    return v;
+}
+
+template <typename TX, typename TY, int G, int V, int PAIR = 1, bool FULL = false, bool MX = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
+    static_assert(!MX || (PAIR == 1 && G % 8 == 0 && sizeof(TY) == 2), "MX output: 8 consecutive lanes hold one 32-element block");
     constexpr int R = 64 / G;  // rows per wave
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -153,8 +167,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
         TY* yr = reinterpret_cast<TY*>(p.y) + map_row(p.ymap, m) * p.ldy;
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
+            float4 o[PAIR];
             if (ok[i]) {
-                float4 o[PAIR];
 #pragma unroll
                 for (int q = 0; q < PAIR; ++q) {
                     const float4 w = wv[i + q], b = bv[i + q];
@@ -165,6 +179,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
                 }
                 if constexpr (PAIR == 2) store4x2<TY>(yr + col[i], o[0], o[1]);
                 else store4<TY>(yr + col[i], o[0]);
+            }
+            if constexpr (MX) {
+                // every lane takes part in the block maximum (a slot beyond the row contributes zeros and stores nothing)
+                float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+                if (ok[i]) {
+                    q0 = (float)(bf16_t)o[0].x; q1 = (float)(bf16_t)o[0].y; q2 = (float)(bf16_t)o[0].z; q3 = (float)(bf16_t)o[0].w;
+                }
+                const float am = max8(fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))));
+                const uint32_t bits = __float_as_uint(am);
+                int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(q0 * inv, -448.f), 448.f), fminf(fmaxf(q1 * inv, -448.f), 448.f), 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(q2 * inv, -448.f), 448.f), fminf(fmaxf(q3 * inv, -448.f), 448.f), pk, true);
+                if (ok[i]) {
+                    *reinterpret_cast<int*>(p.y8 + (int64_t)m * p.ldy8 + col[i]) = pk;
+                    const int kb = col[i] >> 5;
+                    if ((sub & 7) == 0) p.y8s[((int64_t)(kb >> 2) * p.M + m) * 4 + (kb & 3)] = (unsigned char)e;
+                }
             }
         }
     }
@@ -411,6 +444,23 @@ void launch_fwd(const LnP& p, hipStream_t st) {
     int grid = cdiv(p.M, rows_per_wg);
     if (grid > 4096) grid = 4096;
     const dim3 g(grid), b(256);
+    if constexpr (sizeof(TX) == 4 && sizeof(TY) == 2) {
+        if (p.y8) {
+            const bool full = p.C / 4 == G * V;
+#define LN_MX(GG, VV)                                                                                            \
+    do {                                                                                                         \
+        if (full) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, GG, VV, 1, true, true>), g, b, 0, st, p);            \
+        else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, GG, VV, 1, false, true>), g, b, 0, st, p);                \
+    } while (0)
+            if (V == 8) LN_MX(64, 8);
+            else if (G == 8) LN_MX(8, 3);
+            else if (G == 16) LN_MX(16, 3);
+            else if (G == 32) LN_MX(32, 3);
+            else LN_MX(64, 3);
+#undef LN_MX
+            return;
+        }
+    }
     if (V == 8) { if (p.C / 4 == 64 * 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, false>), g, b, 0, st, p); }
     else if (G == 8) { if (p.C / 4 == 8 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, false>), g, b, 0, st, p); }
     else if (G == 16) { if (p.C / 4 == 16 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, false>), g, b, 0, st, p); }
@@ -481,6 +531,12 @@ extern "C" int lnx_layernorm_fwd(const lnx_ln_args* a, void* stream) {
     p.xmap = RowMap{a->x_map.group, a->x_map.pad, a->x_map.off};
     p.ymap = RowMap{a->y_map.group, a->y_map.pad, a->y_map.off};
     p.M = a->M; p.C = a->C; p.eps = a->eps;
+    if (a->y8) {
+        LNX_CHECK(a->y8_scales && a->x_dtype == LNX_F32 && a->y_dtype == LNX_BF16 && a->C % 128 == 0 && a->ldy8 % 4 == 0 && (((uintptr_t)a->y8) & 3) == 0 &&
+                      a->y_map.group == 0 && a->y_map.pad == 0 && a->y_map.off == 0,
+                  "lnx_layernorm_fwd: the MXFP8 output needs x fp32, y bf16, an identity y_map, C %% 128 == 0 and 4-byte aligned rows");
+        p.y8 = (unsigned char*)a->y8; p.y8s = (unsigned char*)a->y8_scales; p.ldy8 = a->ldy8;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int xi = a->x_dtype, yi = a->y_dtype;
     if (xi == LNX_F32 && yi == LNX_F32) launch_fwd<float, float>(p, st);

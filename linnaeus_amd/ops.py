@@ -158,7 +158,7 @@ def gemm_tn(dY, A, dW, *, M=None, N=None, K=None, lda=None, lddw=None, db=None, 
     return dW
 
 
-def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map=None, y_map=None, add=None, mean=None, rstd=None):
+def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map=None, y_map=None, add=None, mean=None, rstd=None, y8=None, y8_scales=None):
     a = L.LnArgs()
     a.M = M if M is not None else x.shape[0]
     a.C = C_ if C_ is not None else x.shape[-1]
@@ -168,6 +168,8 @@ def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map
     a.y, a.y_dtype, a.ldy, a.y_map = _p(y), code_of(y), (ldy if ldy is not None else y.stride(-2)), _map(y_map)
     a.add, a.ldadd = _p(add), (add.stride(-2) if add is not None else 0)
     a.mean, a.rstd = _p(mean), _p(rstd)
+    if y8 is not None:
+        a.y8, a.ldy8, a.y8_scales = _p(y8), y8.stride(0), _p(y8_scales)
     L.check(L.lib().lnx_layernorm_fwd(C.byref(a), _stream()), "lnx_layernorm_fwd")
     return y
 

@@ -480,3 +480,26 @@ def test_mxfp8_quantize_and_gemm(M, N, K, xd):
     rel = (ref - full).norm() / full.norm()
     print(f"[mxfp8 M={M} N={N} K={K}] relative error of the MXFP8 product vs the unquantised one: {rel:.3e}")
     assert rel < 0.05
+
+
+@pytest.mark.parametrize("M,C", [(1000, 384), (777, 768), (300, 1024), (513, 2048), (64, 128), (200, 256)])
+def test_layernorm_fused_mxfp8_output(M, C):
+    """LayerNorm forward with the MXFP8 second output (the producer side of the model's fp8 mode): the bf16 output is what
+    it is without the second output, and the fp8 bytes / block scales equal lnx_quantize_mxfp8 of that bf16 output exactly."""
+    gen = g(M + C)
+    x = (torch.randn(M, C, generator=gen) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=gen).float()) + 0.3).cuda()
+    w = (torch.rand(C, generator=gen) + 0.5).cuda()
+    b = (torch.randn(C, generator=gen) * 0.1).cuda()
+    y0 = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, w, b, y0, 1e-5)
+    y1 = torch.empty_like(y0)
+    y8 = torch.zeros(M, C, device="cuda", dtype=torch.uint8)
+    sc = torch.zeros(C // 128, M, 4, device="cuda", dtype=torch.uint8)
+    mean = torch.empty(M, device="cuda")
+    rstd = torch.empty(M, device="cuda")
+    ops.layernorm_fwd(x, w, b, y1, 1e-5, mean=mean, rstd=rstd, y8=y8, y8_scales=sc)
+    assert torch.equal(y0, y1)
+    r8, rs = ops.quantize_mxfp8(y0)
+    assert torch.equal(sc, rs)
+    assert torch.equal(y8, r8.view(torch.uint8))
+    torch.testing.assert_close(mean, x.mean(-1), rtol=1e-5, atol=1e-5)
