@@ -76,6 +76,9 @@ typedef struct lnx_gemm_args {
     int rows_per_sample;
     const float* res;      /* fp32 residual with the addressing of C, or NULL */
     int64_t ldres;
+    void* c8;              /* lnx_gemm_nt_mxfp8 only, optional: MXFP8 copy of the bf16 output C (exactly lnx_quantize_mxfp8 of C), */
+    int64_t ldc8;          /* ldc8 bytes per row, block scales in c8_scales ([N/128][M][4]); needs N % 128 == 0 and the */
+    void* c8_scales;       /* bias + GELU + pre-activation form (the fc1 -> fc2 hand-over of the model's fp8 mode) */
 } lnx_gemm_args;
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);

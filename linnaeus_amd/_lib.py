@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("gamma", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
         ("res", C.c_void_p), ("ldres", C.c_int64),
+        ("c8", C.c_void_p), ("ldc8", C.c_int64), ("c8_scales", C.c_void_p),
     ]
 
 

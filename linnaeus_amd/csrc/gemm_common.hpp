@@ -36,6 +36,9 @@ struct GemmP {
     const float* sw = nullptr;
     const uint32_t* mxa = nullptr;  // MXFP8 kernels: E8M0 block scales of A / W, [K/128][rows] dwords (byte j = block 4 ks + j)
     const uint32_t* mxw = nullptr;
+    unsigned char* C8 = nullptr;    // F_MXOUT: MXFP8 copy of the bf16 output and its block scales [N/128][M][4]
+    unsigned char* C8s = nullptr;
+    int64_t ldc8 = 0;
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on
@@ -242,7 +245,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
 // on large problems are compiled with their feature set F fixed; preconditions, checked by fast_epilogue_mask():
 // identity row map, plain C addressing, N % 16 == 0, every row pitch and base pointer 16-byte aligned, all element
 // offsets < 2^31.
-enum { F_BIAS = 1, F_C2 = 2, F_GELU = 4, F_GELU_BWD = 8, F_RES = 16, F_GENERIC = 1 << 10 };
+enum { F_BIAS = 1, F_C2 = 2, F_GELU = 4, F_GELU_BWD = 8, F_RES = 16, F_MXOUT = 32, F_GENERIC = 1 << 10 };
 
 template <typename T, bool OUT_F32, int F>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc)[4][4], int mrow0, int ncol0, int lane) {
@@ -342,6 +345,32 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
 #pragma unroll
                 for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
                 st16(cp + h * EPV, o.raw);
+                if (F & F_MXOUT) {
+#pragma unroll
+                    for (int j = 0; j < EPV; ++j) v[h * EPV + j] = o.get(j);  // the stored (rounded) values are what gets quantised
+                }
+            }
+            if (F & F_MXOUT) {
+                // a 32-element block = this lane's 16 columns and those of lane ^ 16 (same row, g ^ 1); N % 32 == 0, so both
+                // lanes are here together
+                float am = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(v[j]));
+                am = fmaxf(am, __shfl_xor(am, 16, 64));
+                const uint32_t bits = __float_as_uint(am);
+                int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+                uint32_t w[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 1] * inv, -448.f), 448.f), 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * h + 2] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * h + 3] * inv, -448.f), 448.f), pk, true);
+                    w[h] = (uint32_t)pk;
+                }
+                st16(p.C8 + (int64_t)m * p.ldc8 + nb, make_uint4(w[0], w[1], w[2], w[3]));
+                const int kb = nb >> 5;
+                if ((g & 1) == 0) p.C8s[((int64_t)(kb >> 2) * p.M + m) * 4 + (kb & 3)] = (unsigned char)e;
             }
         }
     }

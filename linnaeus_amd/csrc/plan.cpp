@@ -123,7 +123,9 @@ struct lnx_plan {
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_cmws = 0, cmws_floats = 0;  // row-range partials of the fused conv-MLP weight gradients
     int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
-    int64_t o_a8 = 0, o_a8s = 0;  // fp8 plans: MXFP8 copy of the current GEMM's activation operand and its block scales (forward scratch)
+    // fp8 plans, forward scratch: MXFP8 copy (+ block scales) of the LayerNorm output feeding qkv / fc1, and of the MLP hidden
+    // feeding fc2 (two buffers: fc1 reads the first while its epilogue writes the second)
+    int64_t o_a8 = 0, o_a8s = 0, o_h8 = 0, o_h8s = 0;
     const float* last_drop = nullptr;
     const unsigned char* last_mask = nullptr;
     std::vector<unsigned char> mask_host;
@@ -622,14 +624,16 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_dlT = cv.take((int64_t)B * maxld * esz);
     }
     if (c.fp8) {
-        int64_t mk = 0;
+        int64_t mc = 0, mh = 0;
         for (int s = 0; s < 2; ++s) {
             const int64_t M = (int64_t)B * (s == 0 ? p->N2 : p->N3);
-            const int64_t k = c.mlp_hidden[s] > D[2 + s] ? c.mlp_hidden[s] : D[2 + s];
-            if (M * k > mk) mk = M * k;
+            if (M * D[2 + s] > mc) mc = M * D[2 + s];
+            if (M * c.mlp_hidden[s] > mh) mh = M * c.mlp_hidden[s];
         }
-        p->o_a8 = cv.take(mk);
-        p->o_a8s = cv.take(mk / 32);
+        p->o_a8 = cv.take(mc);
+        p->o_a8s = cv.take(mc / 32);
+        p->o_h8 = cv.take(mh);
+        p->o_h8s = cv.take(mh / 32);
     }
     p->lnws_floats = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);
     p->lnws_side_floats = (int64_t)256 * 2 * D[3];
@@ -854,9 +858,10 @@ lnx_gemm_args gemm_base(const Ctx& c, int M, int N, int K, const void* A, int64_
 }
 
 int ln_fwd(const Ctx& c, int M, int C, float eps, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi, int bi, void* y, int ydt, int64_t ldy,
-           lnx_rowmap ym, const void* add, int64_t ldadd, float* mean, float* rstd) {
+           lnx_rowmap ym, const void* add, int64_t ldadd, float* mean, float* rstd, void* y8 = nullptr, void* y8s = nullptr) {
     lnx_ln_args a;
     memset(&a, 0, sizeof a);
+    a.y8 = y8; a.ldy8 = C; a.y8_scales = y8s;
     a.M = M; a.C = C; a.eps = eps;
     a.x = x; a.x_dtype = xdt; a.ldx = ldx; a.x_map = xm;
     a.w = c.p->P[wi]; a.b = c.p->P[bi];
@@ -911,22 +916,25 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
 
 const lnx_rowmap IDM = {0, 0, 0};
 
-// A RoPE-block Linear in the forward: on fp8 plans (and M >= 256, the MXFP8 kernel's floor) the bf16 activation `g.A` is
-// quantised into the plan's MXFP8 scratch and the product runs on lnx_gemm_nt_mxfp8 with the weight's MXFP8 copy; the
-// epilogue (bias, GELU + pre-activation copy, fp32 residual with DropPath scale) is the same code either way.
-int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w) {
+// A RoPE-block Linear in the forward.  On fp8 plans (and M >= 256, the MXFP8 kernel's floor) the product runs on
+// lnx_gemm_nt_mxfp8 with the weight's MXFP8 copy and the MXFP8 copy of the activation its producer wrote (`a8` / `a8s`: the
+// LayerNorm forward for qkv and fc1, the fc1 epilogue for fc2); `out8` / `out8s` ask this product's epilogue for the MXFP8
+// copy of its own output.  The epilogue (bias, GELU + pre-activation copy, fp32 residual with DropPath scale) is the same
+// code either way.
+bool fp8_rows(const lnx_plan* p, int M) { return p->c.fp8 != 0 && M >= 256; }
+int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w, int64_t a8, int64_t a8s, int64_t out8 = 0, int64_t out8s = 0) {
     lnx_plan* p = c.p;
-    if (!p->c.fp8 || w.off8s == 0 || g.M < 256) return gemm_nt_t(c, &g);
-    RUN(lnx_quantize_mxfp8(g.A, LNX_BF16, g.lda, g.M, g.K, c.at<void>(p->o_a8), g.K, c.at<void>(p->o_a8s), c.st));
-    g.A = c.at<void>(p->o_a8);
+    if (!fp8_rows(p, g.M) || w.off8s == 0) return gemm_nt_t(c, &g);
+    g.A = c.at<void>(a8);
     g.lda = g.K;
     g.W = c.at<void>(w.off8);
     g.ldw = w.K;
+    if (out8s) {
+        g.c8 = c.at<void>(out8); g.ldc8 = g.N; g.c8_scales = c.at<void>(out8s);
+    }
     Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K);
-    return lnx_gemm_nt_mxfp8(&g, c.at<void>(p->o_a8s), c.at<void>(w.off8s), c.st);
+    return lnx_gemm_nt_mxfp8(&g, c.at<void>(a8s), c.at<void>(w.off8s), c.st);
 }
-
-
 
 // ------------------------------ forward pieces ------------------------------
 int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
@@ -1011,10 +1019,13 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
     const float* xin = c.at<float>(k.xin);
     p->resident[2 + s] = i;
-    RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1)));
+    const bool f8 = fp8_rows(p, M);
+    void* a8 = f8 ? c.at<void>(p->o_a8) : nullptr;
+    void* a8s = f8 ? c.at<void>(p->o_a8s) : nullptr;
+    RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1), a8, a8s));
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
-    RUN(linear_fwd(c, g, k.qkv));
+    RUN(linear_fwd(c, g, k.qkv, p->o_a8, p->o_a8s));
     RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), c.st));
     lnx_attn_args a;
     memset(&a, 0, sizeof a);
@@ -1027,13 +1038,13 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<float>(k.xmid), C, true);
     g.bias = p->P[k.projb]; g.rowscale = p->drop_ptr(p->drop_attn[s][i]); g.rows_per_sample = N; g.res = xin; g.ldres = C;
     RUN(gemm_nt_t(c, &g));
-    RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2)));
+    RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2), a8, a8s));
     g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
     g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
-    RUN(linear_fwd(c, g, k.fc1));
+    RUN(linear_fwd(c, g, k.fc1, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, xout, C, true);
     g.bias = p->P[k.fc2b]; g.rowscale = p->drop_ptr(p->drop_mlp[s][i]); g.rows_per_sample = N; g.res = c.at<float>(k.xmid); g.ldres = C;
-    RUN(linear_fwd(c, g, k.fc2));
+    RUN(linear_fwd(c, g, k.fc2, p->o_h8, p->o_h8s));
     return 0;
 }
 

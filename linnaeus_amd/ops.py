@@ -123,7 +123,8 @@ def dequantize_mxfp8(x8, scales):
     return (x8.to(torch.float32).view(rows, cols // 32, 32) * torch.exp2(e).unsqueeze(-1)).view(rows, cols)
 
 
-def gemm_nt_mxfp8(A8, a_scales, W8, w_scales, out, *, bias=None, act=L.ACT_NONE, aux=None, c2=None, rowscale=None, rows_per_sample=0, res=None):
+def gemm_nt_mxfp8(A8, a_scales, W8, w_scales, out, *, bias=None, act=L.ACT_NONE, aux=None, c2=None, rowscale=None, rows_per_sample=0, res=None,
+                  c8=None, c8_scales=None):
     """out = epilogue(dequant(A8) . dequant(W8)^T) with MXFP8 operands (block scales applied by the matrix core); see lnx_gemm_nt_mxfp8."""
     a = L.GemmArgs()
     a.dtype = L.BF16
@@ -137,6 +138,8 @@ def gemm_nt_mxfp8(A8, a_scales, W8, w_scales, out, *, bias=None, act=L.ACT_NONE,
     a.act, a.aux, a.ldaux = act, _p(aux), (aux.stride(0) if aux is not None else 0)
     a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
     a.res, a.ldres = _p(res), (res.stride(0) if res is not None else 0)
+    if c8 is not None:
+        a.c8, a.ldc8, a.c8_scales = _p(c8), c8.stride(0), _p(c8_scales)
     assert tuple(a_scales.shape) == (a.K // 128, a.M, 4) and tuple(w_scales.shape) == (a.K // 128, a.N, 4)
     L.check(L.lib().lnx_gemm_nt_mxfp8(C.byref(a), _p(a_scales), _p(w_scales), _stream()), "lnx_gemm_nt_mxfp8")
     return out

@@ -34,6 +34,34 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(L.PrepDesc) == 56
 
 
+def test_ctypes_mirrors_have_the_sizes_the_c_compiler_gives(tmp_path):
+    """Every argument struct of include/lnx.h against its ctypes mirror: sizeof from a gcc-compiled probe (a field added to
+    the header but not to the binding would make the library read past the Python object)."""
+    import shutil
+    import subprocess
+
+    from linnaeus_amd.model import _Cfg
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {
+        "lnx_rowmap": L.RowMap, "lnx_gemm_args": L.GemmArgs, "lnx_wgrad_args": L.WgradArgs, "lnx_ln_args": L.LnArgs, "lnx_ln_bwd_args": L.LnBwdArgs,
+        "lnx_dwconv_args": L.DwconvArgs, "lnx_dwconv_wgrad_args": L.DwconvWgradArgs, "lnx_attn_args": L.AttnArgs, "lnx_attn_bwd_args": L.AttnBwdArgs,
+        "lnx_prep_desc": L.PrepDesc, "lnx_softce_args": L.SoftCEArgs, "lnx_mix_args": L.MixArgs, "lnx_adamw_desc": L.AdamWDesc,
+        "lnx_adamw_hyper": L.AdamWHyper, "lnx_convmlp_args": L.ConvMlpArgs, "lnx_convmlp_bwd_args": L.ConvMlpBwdArgs,
+        "lnx_convmlp_wgrad_args": L.ConvMlpWgradArgs, "lnx_mformer_cfg": _Cfg,
+    }
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "lnx.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for n, cls in pairs.items():
+        assert int(got[n]) == C.sizeof(cls), (n, got[n], C.sizeof(cls))
+
+
 def test_argument_validation_without_gpu():
     lib = L.lib()
     a = L.GemmArgs()

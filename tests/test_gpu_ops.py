@@ -468,6 +468,16 @@ def test_mxfp8_quantize_and_gemm(M, N, K, xd):
     h = ref + bias.double().cpu()
     torch.testing.assert_close(pre.double().cpu(), h, rtol=8e-3, atol=tol)
     torch.testing.assert_close(out.double().cpu(), torch.nn.functional.gelu(h), rtol=8e-3, atol=tol)
+    if N % 128 == 0:
+        # the fc1 -> fc2 hand-over: the epilogue also writes the MXFP8 copy of its bf16 output, bit-identical to quantising it
+        out2, pre2 = torch.empty_like(out), torch.empty_like(out)
+        c8 = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+        c8s = torch.zeros(N // 128, M, 4, device="cuda", dtype=torch.uint8)
+        ops.gemm_nt_mxfp8(a8, sa, w8, sw, out2, bias=bias, act=L.ACT_GELU, c2=pre2, c8=c8, c8_scales=c8s)
+        assert torch.equal(out2, out) and torch.equal(pre2, pre)
+        r8, rsc = ops.quantize_mxfp8(out)
+        assert torch.equal(c8s, rsc)
+        assert torch.equal(c8, r8.view(torch.uint8))
     res = torch.randn(M, N, generator=gen).cuda()
     rs = (torch.rand(4, generator=gen) + 0.5).cuda()
     rps = (M + 3) // 4
