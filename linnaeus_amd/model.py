@@ -120,23 +120,43 @@ class _Holder(nn.Sequential):
 
 
 class _PlanFn(torch.autograd.Function):
+    """Outputs: feats and one [B, classes] logits view PER TASK (views of one buffer made here, inside the Function), so that
+    autograd hands the per-task gradients straight to backward() -- slicing the buffer outside would cost a zero-fill, a
+    copy and an accumulation per task in the launch-bound gap between forward and backward."""
+
     @staticmethod
     def forward(ctx, model, x, meta, drop, *params):
         feats, logits = model._plan_forward(x, meta, drop)
         ctx.model = model
         ctx.st = model._active
         ctx.fwd_id = ctx.st["fwd_id"]
-        return feats, logits
+        ctx.set_materialize_grads(False)  # an unused output (feats under a logits-only loss) arrives as None, not as zeros
+        return (feats, *model._task_views(ctx.st, logits, x.shape[0]))
 
     @staticmethod
-    def backward(ctx, dfeats, dlogits):
-        if ctx.st.get("destroyed"):
+    def backward(ctx, dfeats, *dtasks):
+        st = ctx.st
+        if st.get("destroyed"):
             raise L.LnxError("backward() of a forward whose plan was evicted from the plan cache (more than "
                              "`max_cached_plans` distinct batch shapes were used in between); raise model.max_cached_plans")
-        if ctx.st["fwd_id"] != ctx.fwd_id:
+        if st["fwd_id"] != ctx.fwd_id:
             raise L.LnxError("backward() of a forward whose saved activations were overwritten by a later forward of the same "
                              "(batch, image-size) plan; run backward before the next forward")
-        grads = ctx.model._plan_backward(ctx.st, dfeats, dlogits)
+        dlogits = None
+        if any(d is not None for d in dtasks):
+            # persistent staging buffer in the plan's padded layout; the padding columns are zero from the start and stay so
+            dlogits = st.get("dl_buf")
+            if dlogits is None:
+                dlogits = st["dl_buf"] = torch.zeros(max(st["logits_numel"], 1), device=st["ws"].device, dtype=torch.float32)
+                st["dl_views"] = ctx.model._task_views(st, dlogits, st["B"])
+            for v, d in zip(st["dl_views"], dtasks):
+                if d is None:
+                    v.zero_()
+                else:
+                    v.copy_(d)
+        if dfeats is None and dlogits is None:
+            raise L.LnxError("backward() reached the model with no gradient for any of its outputs")
+        grads = ctx.model._plan_backward(st, dfeats, dlogits)
         return (None, None, None, None, *grads)
 
 
@@ -319,6 +339,7 @@ class mFormerV1(nn.Module):
         finally:
             st["handle"] = None
             st["ws"] = None       # the workspace goes back to the caching allocator
+            st["dl_buf"] = st["dl_views"] = None
             st["saved_inputs"] = None
 
     def release_plans(self) -> None:
@@ -529,6 +550,15 @@ class mFormerV1(nn.Module):
         st["drop_mask"] = mask
         return scales
 
+    def _task_views(self, st, logits: torch.Tensor, B: int) -> List[torch.Tensor]:
+        """[B, classes] views, one per task, of a flat buffer in the plan's layout (task t: [B, ld_t] at offset off_t)."""
+        out = []
+        for i, t in enumerate(st["tasks"]):
+            ld = st["logit_ld"][i]
+            nc = self.head[t].effective_linear.out_features
+            out.append(logits[st["logit_off"][i]: st["logit_off"][i] + B * ld].view(B, ld)[:, :nc])
+        return out
+
     def _plan_forward(self, x, meta, drop):
         st = self._active
         B = x.shape[0]
@@ -607,10 +637,11 @@ class mFormerV1(nn.Module):
         self._active = st
         drop = self._draw_drop_scales(st, B, x.device)
         if train:
-            feats, logits = _PlanFn.apply(self, x, meta, drop, *st["params"])
+            feats, *views = _PlanFn.apply(self, x, meta, drop, *st["params"])
         else:
             feats, logits = self._plan_forward(x, meta, drop)
-        return st, feats, logits
+            views = self._task_views(st, logits, B)
+        return st, feats, views
 
     def forward_features(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> torch.Tensor:
         """[B, D3] features after final_norm (mFormerV1.py:407-529).  `force_checkpointing` / the config's
@@ -618,14 +649,11 @@ class mFormerV1(nn.Module):
         return self._run(x, meta, force_checkpointing)[1]
 
     def forward(self, x: torch.Tensor, meta: Optional[torch.Tensor] = None, force_checkpointing: Optional[bool] = None) -> Dict[str, torch.Tensor]:
-        st, feats, logits = self._run(x, meta, force_checkpointing)
-        B = x.shape[0]
+        st, feats, views = self._run(x, meta, force_checkpointing)
         acast = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
         out = {}
-        for i, t in enumerate(st["tasks"]):
-            ld = st["logit_ld"][i]
-            nc = self.head[t].effective_linear.out_features
-            out[t] = logits[st["logit_off"][i]: st["logit_off"][i] + B * ld].view(B, ld)[:, :nc]
+        for t, v in zip(st["tasks"], views):
+            out[t] = v
             if acast is not None:
                 out[t] = out[t].to(acast)  # the reference returns logits in the autocast dtype (SURVEY 8b "Tensor conventions")
         self._last_feats = feats
