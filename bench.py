@@ -306,16 +306,17 @@ def main():
         cpu = cpu_baseline(args, cfg)
         log("cpu baseline done")
     line = {
-        "metric": "images/sec (train fwd+bwd) mFormerV1_sm 3x224x224",
+        "metric": f"images/sec (train fwd+bwd) mFormerV1_{args.arch} 3x{args.img}x{args.img}",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"mFormerV1_{args.arch} train step (forward + 4-task CE loss + backward"
                                f"{' + RCCL gradient all-reduce' if world > 1 else ''}{'' if args.no_optim else ' + AdamW (' + ('torch fused' if args.torch_optim else 'one HIP launch') + ')'}), "
-                               f"{args.dtype} operands / fp32 accumulate+residual, batch {B}/GPU, 3x{args.img}x{args.img} synthetic, "
+                               f"{'bf16 operands with MXFP8 forward products in the RoPE blocks' if args.dtype == 'fp8' else args.dtype + ' operands'} / fp32 accumulate+residual, batch {B}/GPU, 3x{args.img}x{args.img} synthetic, "
                                "DropPath 0.2, gradient checkpointing off",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "tasks": dict(TASKS)},
-        "step_mfma_roofline_frac": round(ips / world * FLOP_PER_IMG / (PEAK_BF16_TFLOPS * 1e12), 4),
+        # FLOP_PER_IMG is the sm @224 figure: other architectures / sizes report no whole-step fraction
+        "step_mfma_roofline_frac": round(ips / world * FLOP_PER_IMG / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.arch == "sm" and args.img == 224) else None,
         "loss": round(last_loss, 4),
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }

@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
         for (int i = 0; i < V; ++i) {
             if (ok[i]) {
                 v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
-                sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                sq += fmaf(v[i].x, v[i].x, v[i].y * v[i].y) + fmaf(v[i].z, v[i].z, v[i].w * v[i].w);  // contraction spelled out, as below
             }
         }
-        const float rs = 1.0f / sqrtf(group_sum<G>(sq) * invC + p.eps);
+        const float rs = 1.0f / sqrtf(fmaf(group_sum<G>(sq), invC, p.eps));
         if (!rv) continue;
         if (sub == 0) {
             if (p.mean) p.mean[m] = mu;
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnP p) {
 #pragma unroll
                 for (int q = 0; q < PAIR; ++q) {
                     const float4 w = wv[i + q], b = bv[i + q];
-                    o[q] = make_float4(v[i + q].x * rs * w.x + b.x, v[i + q].y * rs * w.y + b.y, v[i + q].z * rs * w.z + b.z, v[i + q].w * rs * w.w + b.w);
+                    // explicit fma: every instantiation (with / without the MXFP8 copy, full / partial rows) rounds the same way
+                    o[q] = make_float4(fmaf(v[i + q].x * rs, w.x, b.x), fmaf(v[i + q].y * rs, w.y, b.y), fmaf(v[i + q].z * rs, w.z, b.z), fmaf(v[i + q].w * rs, w.w, b.w));
                     if (p.add) {
                         o[q].x += av[i + q].x; o[q].y += av[i + q].y; o[q].z += av[i + q].z; o[q].w += av[i + q].w;
                     }
@@ -410,8 +411,9 @@ inline void pick_gv(int C, int& G, int& V) {
             V = 3;
             return;
         }
+    // wide rows: 64 lanes with 4, 6 or 8 float4 slots each (C = 1024 and 1536 fill 4 / 6 exactly: the xl / lg RoPE widths)
     G = 64;
-    V = 8;
+    V = nvec <= 64 * 4 ? 4 : (nvec <= 64 * 6 ? 6 : 8);
 }
 
 // pair mode (16-byte accesses on bf16 rows): lane group of G2 lanes, each holding <= 3 float4 pairs; 0 = not applicable
@@ -453,6 +455,8 @@ void launch_fwd(const LnP& p, hipStream_t st) {
         else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, GG, VV, 1, false, true>), g, b, 0, st, p);                \
     } while (0)
             if (V == 8) LN_MX(64, 8);
+            else if (V == 4) LN_MX(64, 4);
+            else if (V == 6) LN_MX(64, 6);
             else if (G == 8) LN_MX(8, 3);
             else if (G == 16) LN_MX(16, 3);
             else if (G == 32) LN_MX(32, 3);
@@ -462,6 +466,8 @@ void launch_fwd(const LnP& p, hipStream_t st) {
         }
     }
     if (V == 8) { if (p.C / 4 == 64 * 8) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 8, 1, false>), g, b, 0, st, p); }
+    else if (V == 4) { if (p.C / 4 == 64 * 4) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 4, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 4, 1, false>), g, b, 0, st, p); }
+    else if (V == 6) { if (p.C / 4 == 64 * 6) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 6, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 64, 6, 1, false>), g, b, 0, st, p); }
     else if (G == 8) { if (p.C / 4 == 8 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 8, 3, 1, false>), g, b, 0, st, p); }
     else if (G == 16) { if (p.C / 4 == 16 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 16, 3, 1, false>), g, b, 0, st, p); }
     else if (G == 32) { if (p.C / 4 == 32 * 3) hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_fwd_kernel<TX, TY, 32, 3, 1, false>), g, b, 0, st, p); }
@@ -509,6 +515,8 @@ void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats) {
     }
     if (launched) {
     } else if (V == 8) { if (p.C / 4 == 64 * 8) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 8, 1, false>), g, b, 0, st, p); }
+    else if (V == 4) { if (p.C / 4 == 64 * 4) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 4, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 4, 1, false>), g, b, 0, st, p); }
+    else if (V == 6) { if (p.C / 4 == 64 * 6) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 6, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 6, 1, false>), g, b, 0, st, p); }
     else if (G == 8) { if (p.C / 4 == 8 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 8, 3, 1, false>), g, b, 0, st, p); }
     else if (G == 16) { if (p.C / 4 == 16 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 16, 3, 1, false>), g, b, 0, st, p); }
     else if (G == 32) { if (p.C / 4 == 32 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 32, 3, 1, false>), g, b, 0, st, p); }

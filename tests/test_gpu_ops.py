@@ -17,7 +17,7 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.mark.parametrize("C_", [32, 96, 192, 384, 768, 2048])
+@pytest.mark.parametrize("C_", [32, 96, 192, 384, 768, 1024, 1280, 1536, 2048])
 @pytest.mark.parametrize("xd,yd", [(L.F32, L.F32), (L.F32, L.BF16), (L.BF16, L.BF16), (L.BF16, L.F32)])
 def test_layernorm_fwd_bwd(C_, xd, yd):
     M = 77
@@ -492,7 +492,7 @@ def test_mxfp8_quantize_and_gemm(M, N, K, xd):
     assert rel < 0.05
 
 
-@pytest.mark.parametrize("M,C", [(1000, 384), (777, 768), (300, 1024), (513, 2048), (64, 128), (200, 256)])
+@pytest.mark.parametrize("M,C", [(1000, 384), (777, 768), (300, 1024), (513, 2048), (64, 128), (200, 256), (130, 1536), (99, 1280)])
 def test_layernorm_fused_mxfp8_output(M, C):
     """LayerNorm forward with the MXFP8 second output (the producer side of the model's fp8 mode): the bf16 output is what
     it is without the second output, and the fp8 bytes / block scales equal lnx_quantize_mxfp8 of that bf16 output exactly."""
