@@ -78,7 +78,8 @@ typedef struct lnx_gemm_args {
     int64_t ldres;
     void* c8;              /* lnx_gemm_nt_mxfp8 only, optional: MXFP8 copy of the bf16 output C (exactly lnx_quantize_mxfp8 of C), */
     int64_t ldc8;          /* ldc8 bytes per row, block scales in c8_scales ([N/128][M][4]); needs N % 128 == 0 and the */
-    void* c8_scales;       /* bias + GELU + pre-activation form (the fc1 -> fc2 hand-over of the model's fp8 mode) */
+    void* c8_scales;       /* bias + GELU + pre-activation form or the GELU' form (the fc1 -> fc2 hand-over of the model's fp8 mode
+                              and its mirror image in the backward) */
 } lnx_gemm_args;
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
@@ -501,8 +502,11 @@ typedef struct lnx_mformer_cfg {
     int fp8;                   /* 1 (with dtype = LNX_BF16): the forward products of the RoPE blocks' qkv / fc1 / fc2 Linear layers run
                                   on the block-scaled fp8 matrix cores (MXFP8: lnx_quantize_mxfp8 + lnx_gemm_nt_mxfp8) -- BASELINE
                                   config 5's "fp8 MFMA path".  Weights are re-quantised from the fp32 masters every forward,
-                                  activations as they are produced; everything saved for the backward, and the whole backward,
-                                  stay bf16.  Needs RoPE dims and MLP widths that are multiples of 128. */
+                                  activations as they are produced; everything saved for the backward, and the backward, stay
+                                  bf16 (environment LNX_FP8_DGRAD=1: the proj / fc2 / fc1 data-gradient products in MXFP8 as
+                                  well, gradients quantised per 32-element block -- measured: +0.5 % speed at xl for a quarter
+                                  more gradient error, so off by default).  Needs RoPE dims and MLP widths that are multiples
+                                  of 128. */
 } lnx_mformer_cfg;
 
 typedef struct lnx_plan lnx_plan;

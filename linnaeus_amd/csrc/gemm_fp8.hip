@@ -355,8 +355,8 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
     const bool out_f32 = a->out_f32 != 0;
     int f = fast_epilogue_mask(p, out_f32);
     if (a->c8) {
-        LNX_CHECK(mx && a->c8_scales && f == (F_BIAS | F_C2 | F_GELU) && a->N % 128 == 0 && a->ldc8 % 16 == 0 && (((uintptr_t)a->c8) & 15) == 0,
-                  "%s: the MXFP8 output copy needs the MX kernel, the bias + GELU + pre-activation form, N %% 128 == 0 and 16-byte aligned rows", who);
+        LNX_CHECK(mx && a->c8_scales && (f == (F_BIAS | F_C2 | F_GELU) || f == F_GELU_BWD) && a->N % 128 == 0 && a->ldc8 % 16 == 0 && (((uintptr_t)a->c8) & 15) == 0,
+                  "%s: the MXFP8 output copy needs the MX kernel, the bias + GELU + pre-activation form or the GELU' form, N %% 128 == 0 and 16-byte aligned rows", who);
         p.C8 = (unsigned char*)a->c8; p.C8s = (unsigned char*)a->c8_scales; p.ldc8 = a->ldc8;
         f |= F_MXOUT;
     }
@@ -386,6 +386,7 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
     else if (f == (F_BIAS | F_C2 | F_GELU)) F8_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
     else if (f == (F_BIAS | F_C2 | F_GELU | F_MXOUT)) F8_LAUNCH_(false, F_BIAS | F_C2 | F_GELU | F_MXOUT, true);
     else if (f == F_GELU_BWD) F8_LAUNCH(false, F_GELU_BWD);
+    else if (f == (F_GELU_BWD | F_MXOUT)) F8_LAUNCH_(false, F_GELU_BWD | F_MXOUT, true);
     else LNX_CHECK(false, "%s: unsupported epilogue feature set %d", who, f);
 #undef F8_LAUNCH
 #undef F8_LAUNCH_

@@ -784,6 +784,32 @@ def test_fp8_mode_sm_b24_against_oracle_and_bf16():
     assert all(torch.isfinite(p_.grad).all() for p_ in model.parameters())
 
 
+def test_fp8_dgrad_opt_in(monkeypatch):
+    """LNX_FP8_DGRAD=1: the proj / fc2 / fc1 data-gradient products in MXFP8 too (transposed MXFP8 weight copies, dY quantised
+    per branch, dH handed on by the GELU' epilogue).  Same forward; gradients within the fp8 mode's stated 12 % of the oracle."""
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300)), drop_path_rate=0.2)
+    B = 24
+    sd = O.seeded_state_dict(O.param_shapes(spec), 777)
+    x, meta = O.seeded_inputs(spec, B, 224, 778)
+    drops = _drop_scales(spec, B, 779)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    O.probe_loss(O.forward(osd, spec, x, meta, drops)).backward()
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype("fp8")
+    out_a = {t: v.detach().clone() for t, v in run(model, x, meta, drops, train=True).items()}
+    monkeypatch.setenv("LNX_FP8_DGRAD", "1")
+    model.release_plans()
+    out = run(model, x, meta, drops, train=True)
+    for t in out:
+        assert torch.equal(out[t], out_a[t]), t
+    O.probe_loss(out).backward()
+    glob, wk = _grad_errors(model, osd)
+    print(f"[sm B=24/fp8 + fp8 dgrad] global relative gradient error {glob:.3e}; worst tensor {wk[0]} {wk[1]:.2e}")
+    assert glob <= 0.12, (glob, wk)
+
+
 def test_fp8_mode_rejects_unsupported_widths(golden_dir):
     """MXFP8 blocks are 32 wide and a K slice of the kernel 128: the planner refuses other widths loudly (no silent bf16)."""
     import ctypes as C
