@@ -233,6 +233,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// exp of the softmax: the bf16 kernels use the hardware exponential (v_exp_f32, ~1 ulp), the fp32 (strict-parity) ones libm's
+template <typename T> __device__ __forceinline__ float fexp(float x) {
+    if constexpr (sizeof(T) == 2) return __expf(x);
+    else return expf(x);
+}
+
 struct AttnP {
     const void* qkv;
     const float* cos_tab;
@@ -296,13 +302,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             }
         mx = group_max(mx);
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = fexp<T>(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(pv[t][r] - m_new);
+                const float e = fexp<T>(pv[t][r] - m_new);
                 pv[t][r] = e;
                 psum += e;
             }
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * BT + t * 16 + 4 * g + r;
-                const float pr = (key < p.N && q < p.N) ? expf(sacc[t][r] - lse) : 0.f;
+                const float pr = (key < p.N && q < p.N) ? fexp<T>(sacc[t][r] - lse) : 0.f;
                 ds[t][r] = pr * (dpacc[t][r] - delta);
             }
         imgT_times_regs<T>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
             for (int r = 0; r < 4; ++r) {
                 const int ql = t * 16 + 4 * g + r;
                 const int qq = qt * BT + ql;
-                const float pp = (qq < p.N && key < p.N) ? expf(sacc[t][r] - lse_s[ql]) : 0.f;
+                const float pp = (qq < p.N && key < p.N) ? fexp<T>(sacc[t][r] - lse_s[ql]) : 0.f;
                 pr[t][r] = pp;
                 ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
             }
