@@ -486,8 +486,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         for (auto& k : p->conv[s]) k.w49 = cv.take((int64_t)49 * D[s] * 4);
     if (c.fp8)
         for (int s = 0; s < 2; ++s)
-            for (auto& k : p->rope[s])
-            {
+            for (auto& k : p->rope[s]) {
                 for (OpW* w : {&k.qkv, &k.fc1, &k.fc2}) {
                     w->off8 = cv.take((int64_t)w->N * w->K);
                     w->off8s = cv.take((int64_t)(w->K / 128) * w->N * 4);
@@ -1099,8 +1098,7 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         RUN(lnx_prep_weights(c.at<lnx_prep_desc>(p->o_descs) + p->n_descs_t, (int)p->n_descs_f, (int)p->prep_blocks_f, LNX_F32, stream));
     if (cf.fp8)  // MXFP8 copies of the RoPE blocks' forward weights, straight from the fp32 masters
         for (int s = 0; s < 2; ++s)
-            for (auto& k : p->rope[s])
-            {
+            for (auto& k : p->rope[s]) {
                 for (const OpW* w : {&k.qkv, &k.fc1, &k.fc2})
                     RUN(lnx_quantize_mxfp8(p->P[w->param], LNX_F32, w->K, w->N, w->K, c.at<void>(w->off8), w->K, c.at<void>(w->off8s), stream));
                 for (const OpW* w : {&k.proj, &k.fc1, &k.fc2})  // transposed copies for the data-gradient products, from the bf16 arena

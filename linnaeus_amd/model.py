@@ -142,9 +142,12 @@ class _PlanFn(torch.autograd.Function):
         if st["fwd_id"] != ctx.fwd_id:
             raise L.LnxError("backward() of a forward whose saved activations were overwritten by a later forward of the same "
                              "(batch, image-size) plan; run backward before the next forward")
+        if dfeats is None and all(d is None for d in dtasks):
+            raise L.LnxError("backward() reached the model with no gradient for any of its outputs")
         dlogits = None
-        if any(d is not None for d in dtasks):
-            # persistent staging buffer in the plan's padded layout; the padding columns are zero from the start and stay so
+        if st["logits_numel"] > 0:
+            # persistent staging buffer in the plan's padded layout; the padding columns are zero from the start and stay so.
+            # A task the loss did not use gets a zero gradient (the plan differentiates all heads in one pass).
             dlogits = st.get("dl_buf")
             if dlogits is None:
                 dlogits = st["dl_buf"] = torch.zeros(max(st["logits_numel"], 1), device=st["ws"].device, dtype=torch.float32)
@@ -154,8 +157,6 @@ class _PlanFn(torch.autograd.Function):
                     v.zero_()
                 else:
                     v.copy_(d)
-        if dfeats is None and dlogits is None:
-            raise L.LnxError("backward() reached the model with no gradient for any of its outputs")
         grads = ctx.model._plan_backward(st, dfeats, dlogits)
         return (None, None, None, None, *grads)
 

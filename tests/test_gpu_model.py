@@ -824,3 +824,36 @@ def test_fp8_mode_rejects_unsupported_widths(golden_dir):
     handle = C.c_void_p()
     with pytest.raises(L.LnxError, match="multiples of 128"):
         L.check(L.lib().lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
+
+
+def test_backward_through_features_only_and_a_single_task(golden_dir):
+    """autograd may reach the model with gradients for only some of its outputs: forward_features() alone (no logits
+    gradient at all) and a loss on one task (the other heads then get exactly zero gradient, the trunk only that task's)."""
+    spec, z, sd, x, meta, drops = load_case("tiny_b", golden_dir)
+    model = build("tiny_b", spec, sd, "fp32")
+    model.train(True)
+    model._inject_drop = drops
+    xs, ms = x.cuda(), meta.cuda() if meta is not None else None
+    feats = model.forward_features(xs, ms)
+    feats.square().sum().backward()
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    O.forward_features(osd, spec, x, meta, drops).square().sum().backward()
+    for k, p_ in model.named_parameters():
+        if k.startswith("head."):
+            assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, k
+        else:
+            ref = osd[k].grad
+            assert (p_.grad.cpu() - ref).norm() <= 2e-3 * max(ref.norm().item(), 1e-3), k
+    model.zero_grad(set_to_none=True)
+    out = model(xs, ms)
+    t0, t1 = list(out)[:2]
+    out[t0].float().square().sum().backward()
+    for v in osd.values():
+        v.grad = None
+    O.forward(osd, spec, x, meta, drops)[t0].square().sum().backward()
+    for k, p_ in model.named_parameters():
+        ref = osd[k].grad if k in osd else None
+        if k.startswith("head.") and t1 in k:
+            assert float(p_.grad.abs().max()) == 0.0, k
+        elif ref is not None:
+            assert (p_.grad.cpu() - ref).norm() <= 2e-3 * max(ref.norm().item(), 1e-3), k
