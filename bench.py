@@ -145,9 +145,13 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29544")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.init_process_group("nccl", rank=0, world_size=1)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl")
+        # No device_id= here on purpose: binding the process group to the device at init (eager communicator creation) makes
+        # EVERY step ~1 ms slower on this stack (13.6 -> 14.6 ms at batch 128, with no collective ever issued;
+        # tools/bench_segments.py --pg [--lazy]); the lazily created communicator does not.  torch.cuda.set_device() above
+        # tells RCCL which GPU this rank owns; barriers name it explicitly.
 
     torch.manual_seed(42 + rank)
     cfg, model = make_model(args)
@@ -208,14 +212,14 @@ def main():
     torch.cuda.synchronize()
     log("warm-up done; timing")
     if dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     if dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
@@ -236,7 +240,7 @@ def main():
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(k):

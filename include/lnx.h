@@ -545,7 +545,9 @@ int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, in
 #define LNX_PROFILE_CLASSES 9 /* class 8: fused conv-MLP weight gradients (lnx_convmlp_wgrad), work = FLOPs */
 int lnx_plan_profile_begin(lnx_plan* p);
 int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
-/* indices of the parameters whose gradient is final after `segment`; returns their count */
+/* indices of the parameters whose gradient is final after `segment`; returns their count.  The metadata heads' backward
+ * runs on the plan's side stream and is joined one segment after the one that forks it, so the stage-4 heads report
+ * segment 1 and the stage-3 heads segment 2 (a caller that stops early must run the following segment, or -1, to join). */
 int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_out, int max_out);
 
 #ifdef __cplusplus

@@ -1519,8 +1519,9 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         RUN(ln_bwd(c, B * p->N2, C2, dt1, cf.dtype, C2, IDM, c.at<float>(p->o_stage_out[2]), LNX_F32, C2, IDM, p->norm_w[0], p->norm_b[0], c.at<float>(p->o_t1_mean),
                    c.at<float>(p->o_t1_rstd), nullptr, g2, LNX_F32, C2, false, dn));
         // the stage-4 metadata-head backward (side stream, ~10 small fp32 GEMMs) is joined at the END OF SEGMENT 1: it only
-        // produces parameter gradients, and joining here exposed most of its ~0.7 ms behind the three downsample kernels
-        if (!all) RUN(join_side(c, 1));  // segment-wise callers may stop after any segment: keep every segment self-contained
+        // produces parameter gradients, and joining here exposed most of its ~0.7 ms behind the three downsample kernels.
+        // That holds for segment-wise callers too (segments run 0..3 in order): the gradients of the stage-4 metadata heads
+        // are reported as final after segment 1, those of the stage-3 heads after segment 2 (lnx_plan_segment_params).
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);
@@ -1531,8 +1532,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         RUN(tokens_bwd(c, 0, g2));
         const lnx_rowmap gm = {p->HW[2], p->E, p->E};
         RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
-        if (all) RUN(join_side(c, 1));
-        else RUN(join_side(c, 0));
+        RUN(join_side(c, 1));
     }
     if (all || segment == 2) {
         float* g1 = c.at<float>(p->o_g[1]);
@@ -1541,7 +1541,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
             RUN(conv_block_bwd(c, 1, i, g1));
         }
         RUN(downsample_bwd(c, 0, g1, D[1], IDM, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, c.at<float>(p->o_g[0]), LNX_F32, D[0]));
-        if (all) RUN(join_side(c, 0));  // stage-3 metadata heads: hidden behind the whole ConvNeXt stage-2 backward
+        RUN(join_side(c, 0));  // stage-3 metadata heads: hidden behind the whole ConvNeXt stage-2 backward
     }
     if (all || segment == 3) {
         float* g0 = c.at<float>(p->o_g[0]);
@@ -1567,7 +1567,8 @@ extern "C" int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_
         if (nm.rfind("stages.3.", 0) == 0 || nm.rfind("head.", 0) == 0 || nm.rfind("norm_", 0) == 0 || nm.rfind("cl_1_fc", 0) == 0 ||
             nm.rfind("aggregate", 0) == 0 || nm.rfind("final_norm", 0) == 0 || nm == "cls_token_2" || nm.rfind("downsample_layers.2", 0) == 0)
             return 0;
-        if (nm.rfind("meta.", 0) == 0) return nm.find("head_2") != std::string::npos ? 0 : 1;
+        // metadata heads run on the side stream and are joined one segment after the one that forks them
+        if (nm.rfind("meta.", 0) == 0) return nm.find("head_2") != std::string::npos ? 1 : 2;
         if (nm.rfind("stages.2.", 0) == 0 || nm == "cls_token_1" || nm.rfind("downsample_layers.1", 0) == 0) return 1;
         if (nm.rfind("stages.1.", 0) == 0 || nm.rfind("downsample_layers.0", 0) == 0) return 2;
         return 3;

@@ -9,6 +9,9 @@ gradient arena ordered by segment, each segment is exactly one contiguous all-re
     backward segment 1 (RoPE stage 3 + downsample 2)          ~42 %
     backward segment 2 (ConvNeXt stage 2 + downsample 1)      ~ 5 %
     backward segment 3 (ConvNeXt stage 1 + stem)              ~ 1 %
+    (the metadata heads' backward runs on the plan's side stream and is joined one segment later: the stage-4 heads
+    travel with segment 1's bucket, the stage-3 heads with segment 2's -- joining them in their own segment exposed
+    ~1.5 ms of small fp32 GEMMs per step)
 
 As soon as a segment's kernels are enqueued, its bucket's all-reduce is issued on a side HIP
 stream behind an event, so the collective of segment k runs under the compute of segments

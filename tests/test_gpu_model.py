@@ -297,7 +297,7 @@ def test_data_parallel_stream_logic_single_rank(golden_dir):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         spec, z, sd, x, meta, drops = load_case("tiny_b", golden_dir)
         ref = build("tiny_b", spec, sd, "fp32")
