@@ -137,6 +137,11 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # stdout carries the one JSON line and nothing else: anything a library prints on the way (RCCL's version banner goes to
+    # stdout through printf) is sent to stderr by pointing fd 1 at fd 2 until the line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     if world > 1 or args.force_dp:
         import torch.distributed as dist
@@ -331,6 +336,8 @@ def main():
         line["workspace_gb"] = round(model._active["ws"].numel() / 1e9, 2)
     if args.drop_in:
         line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()
