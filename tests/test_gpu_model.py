@@ -860,3 +860,57 @@ def test_backward_through_features_only_and_a_single_task(golden_dir):
             assert float(p_.grad.abs().max()) == 0.0, k
         elif ref is not None:
             assert (p_.grad.cpu() - ref).norm() <= 2e-3 * max(ref.norm().item(), 1e-3), k
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_grad_scaler_flow_of_the_reference_train_loop(dtype, golden_dir):
+    """train.py:176,280,311-312: scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_norm_; scaler.step();
+    scaler.update() under torch.autocast(float16) around the drop-in model (A18).  The loss scale is a power of two, so the
+    step must equal the unscaled flow's (bf16 operands share fp32's exponent range: nothing overflows at 2^16), the
+    logits come back in the autocast dtype, and an inf gradient makes the scaler skip the step and back off."""
+    spec, z, sd, x, meta, drops = load_case("tiny_b", golden_dir)
+    xs, ms = x.cuda(), meta.cuda()
+    tg = {t: torch.randint(0, c, (x.shape[0],), generator=torch.Generator().manual_seed(5)).cuda() for t, c in spec.heads}
+
+    def one_step(use_scaler):
+        model = build("tiny_b", spec, sd, dtype)
+        model.train(True)
+        model._inject_drop = drops
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 16, enabled=use_scaler)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_scaler):
+            out = model(xs, ms)
+            if use_scaler:
+                assert all(v.dtype == torch.float16 for v in out.values())
+            loss = sum(torch.nn.functional.cross_entropy(out[t].float(), tg[t]) for t, _ in spec.heads)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        grads = [p_.grad.detach().clone() for p_ in model.parameters()]
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        before = [p_.detach().clone() for p_ in model.parameters()]
+        scaler.step(opt)
+        scaler.update()
+        assert any(not torch.equal(p_, q) for p_, q in zip(model.parameters(), before)), "the optimizer step did not happen"
+        return model, opt, scaler, float(norm), float(loss.detach()), grads
+
+    m0, _, _, n0, l0, g0 = one_step(False)
+    m1, opt1, sc1, n1, l1, g1 = one_step(True)
+    # fp16 logits feed the loss in the scaled flow: loss and (unscaled) gradients differ by that rounding only
+    assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)) and abs(n0 - n1) <= 5e-3 * max(n0, 1e-3), (l0, l1, n0, n1)
+    err = sum((a - b).double().pow(2).sum().item() for a, b in zip(g0, g1)) ** 0.5
+    ref = sum(a.double().pow(2).sum().item() for a in g0) ** 0.5
+    assert err <= 5e-3 * ref, (err, ref)
+    # an overflowing gradient: the scaler must see the inf in the model's .grad views, skip the step and halve the scale
+    before = [p_.detach().clone() for p_ in m1.parameters()]
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = m1(xs, ms)
+        loss = sum(torch.nn.functional.cross_entropy(out[t].float(), tg[t]) for t, _ in spec.heads)
+    sc1.scale(loss).backward()
+    next(iter(m1.parameters())).grad.view(-1)[0] = float("inf")
+    sc1.unscale_(opt1)
+    s_before = sc1.get_scale()
+    sc1.step(opt1)
+    sc1.update()
+    assert sc1.get_scale() == s_before * 0.5
+    for p_, q in zip(m1.parameters(), before):
+        assert torch.equal(p_, q)
