@@ -914,3 +914,26 @@ def test_grad_scaler_flow_of_the_reference_train_loop(dtype, golden_dir):
     assert sc1.get_scale() == s_before * 0.5
     for p_, q in zip(m1.parameters(), before):
         assert torch.equal(p_, q)
+
+
+def test_hierarchical_softmax_heads_match_oracle(golden_dir):
+    """A15: MODEL.CLASSIFICATION.HEADS of TYPE HierarchicalSoftmax (heads/hierarchical_softmax_head.py:28-210) -- effectively
+    one shared Linear per task (finding F3), so logits and gradients are the tiny_c fixture's."""
+    spec, z, sd, x, meta, drops = load_case("tiny_c", golden_dir)
+    tree = TinyTree({"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}},
+                    [t for t, _ in spec.heads], {t: c for t, c in spec.heads})
+    model = build_model(make_config(spec, IMG["tiny_c"], "HierarchicalSoftmax"), num_classes={t: c for t, c in spec.heads}, taxonomy_tree=tree)
+    assert all(type(h).__name__ == "HierarchicalSoftmaxHead" for h in model.head.values())
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype("fp32")
+    out = run(model, x, meta, drops, train=True)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta, drops)
+    for t, _ in spec.heads:
+        torch.testing.assert_close(out[t].float().cpu(), oout[t].detach(), rtol=1e-4, atol=1e-4)
+        assert (out[t].argmax(-1).cpu() == oout[t].argmax(-1)).all()
+    O.probe_loss(out).backward()
+    O.probe_loss(oout).backward()
+    glob, wk = _grad_errors(model, osd)
+    assert glob <= 1e-3, (glob, wk)
