@@ -107,12 +107,12 @@ __device__ __forceinline__ uint4 load_chunk(const T* __restrict__ base, int64_t 
 
 // Stage a 64-row tile (tokens n0..n0+63) into LDS: swizzled row image (16-byte fragment
 // reads, rows = MFMA rows) and/or padded image for transposed reads.
-template <typename T, bool COS, bool ROWIMG, bool TRIMG>
+template <typename T, bool COS, bool ROWIMG, bool TRIMG, int NT = 256>
 __device__ __forceinline__ void stage_tile(unsigned char* rowimg, unsigned char* trimg, const T* __restrict__ base, int64_t ld, int n0, int N, int E,
                                            const float* __restrict__ cos_tab, int heads, int head, float scale) {
     constexpr int NCH = AT<T>::NCH;
     constexpr int EPV = AT<T>::EPV;
-    for (int i = threadIdx.x; i < BT * NCH; i += 256) {
+    for (int i = threadIdx.x; i < BT * NCH; i += NT) {
         const int r = i / NCH, c = i % NCH;
         const uint4 v = load_chunk<T, COS>(base, ld, n0 + r, N, E, c * EPV, cos_tab, heads, head, scale);
         if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
@@ -253,10 +253,12 @@ struct AttnP {
 };
 
 // ---------------------------------------------------------------------------------
-// forward: one workgroup = 64 queries of one (b, head); wave = 16 queries (lane s)
+// forward: one workgroup = 16 NW queries of one (b, head); wave = 16 queries (lane s).  NW = 8 (bf16, long sequences): every
+// staged 64-key tile serves 128 queries, i.e. half the staging work, LDS writes and barriers per query of NW = 4.
+// p.qtiles = ceil(N / (16 NW)).
 // ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+template <typename T, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kimg = smem;                       // K~ row image
     unsigned char* vimg = smem + AT<T>::ROW_IMG;      // V transposed-read image
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const T* vb = qb + 2 * C;
     const float scale = 0.125f;  // 64^-0.5
 
-    const int q = qt * BT + wave * 16 + s;
+    const int q = qt * (16 * NW) + wave * 16 + s;
     uint4 qf[AT<T>::NKK];
     load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
 
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const int nkt = (p.N + BT - 1) / BT;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_tile<T, true, true, false>(kimg, nullptr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
-        stage_tile<T, false, false, true>(nullptr, vimg, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        stage_tile<T, true, true, false, 64 * NW>(kimg, nullptr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+        stage_tile<T, false, false, true, 64 * NW>(nullptr, vimg, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
         __syncthreads();
         f32x4_t sacc[4];
         rows_times_frag<T>(sacc, kimg, s, g, qf);  // S^T[key = 16t + 4g + r][query = s]
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
 // ---------------------------------------------------------------------------------
 // backward, query side: delta, dq (and the q part of the cos gradient)
 // ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+template <typename T, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kimg = smem;                                        // K~ rows
     unsigned char* vimg = smem + AT<T>::ROW_IMG;                       // V rows
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
     const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
 
-    const int q = qt * BT + wave * 16 + s;
+    const int q = qt * (16 * NW) + wave * 16 + s;
     uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
     load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
     load_row_frag<T, false>(dof, dob, C, q, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
     const int nkt = (p.N + BT - 1) / BT;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        stage_tile<T, true, true, true>(kimg, ktr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
-        stage_tile<T, false, true, false>(vimg, nullptr, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        stage_tile<T, true, true, true, 64 * NW>(kimg, ktr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
+        stage_tile<T, false, true, false, 64 * NW>(vimg, nullptr, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
         __syncthreads();
         f32x4_t sacc[4], dpacc[4];
         rows_times_frag<T>(sacc, kimg, s, g, qf);    // S^T[key][q]
@@ -428,8 +430,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
 // backward, key side: dk, dv (and the k part of the cos gradient)
 // wave = 16 keys (lane s); loops over 64-query tiles
 // ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+// NW = 8: at least 4 waves per SIMD (two 8-wave workgroups per CU) -- left to itself the compiler takes 130 registers and
+// only one workgroup fits
+template <typename T, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* qimg = smem;                                   // Q~ rows
     unsigned char* doimg = smem + AT<T>::ROW_IMG;                 // dO rows
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
     const float scale = 0.125f;
     const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
 
-    const int key = ktile * BT + wave * 16 + s;
+    const int key = ktile * (16 * NW) + wave * 16 + s;
     uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
     load_row_frag<T, true>(kf, kb, ld, key, p.N, p.E, g, p.cos_tab, p.heads, head, 1.0f);
     load_row_frag<T, false>(vf, vb, ld, key, p.N, p.E, g, nullptr, p.heads, head, 1.0f);
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
     const int nqt = (p.N + BT - 1) / BT;
     for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
-        stage_tile<T, true, true, true>(qimg, qtr, qb, ld, qt * BT, p.N, p.E, p.cos_tab, p.heads, head, scale);
-        stage_tile<T, false, true, true>(doimg, dotr, dob, C, qt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        stage_tile<T, true, true, true, 64 * NW>(qimg, qtr, qb, ld, qt * BT, p.N, p.E, p.cos_tab, p.heads, head, scale);
+        stage_tile<T, false, true, true, 64 * NW>(doimg, dotr, dob, C, qt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
         if (threadIdx.x < BT) {
             const int qq = qt * BT + threadIdx.x;
             lse_s[threadIdx.x] = qq < p.N ? p.lse[statbase + qq] : 0.f;
@@ -941,6 +945,13 @@ extern "C" int lnx_rope_freqs_bwd(const float* freqs, const float* gcos, int B, 
     return 0;
 }
 
+// tiled bf16 kernels: 8 waves (128 rows) per workgroup for sequences beyond the resident kernels' reach, where every staged
+// tile is then shared by twice the rows; 4 waves for short ones (more workgroups) and with LNX_ATTN_NW=4 (A/B switch)
+static bool tiled_nw8(int N) {
+    static const bool force4 = getenv("LNX_ATTN_NW") != nullptr && atoi(getenv("LNX_ATTN_NW")) == 4;
+    return !force4 && N > 128;
+}
+
 extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
     LNX_CHECK(a && a->qkv && a->o, "lnx_attn_fwd: null operand");
     if (check_attn(a->dtype, a->B, a->N, a->E, a->heads, "lnx_attn_fwd")) return 1;
@@ -963,7 +974,12 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
         hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds, st, p);
     } else if (a->dtype == LNX_BF16) {
         const size_t lds = AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG;
-        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, p);
+        if (tiled_nw8(a->N)) {  // 128 queries per workgroup
+            p.qtiles = cdiv(a->N, 128);
+            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 8>), dim3(a->B * a->heads * p.qtiles), dim3(512), lds, st, p);
+        } else {
+            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), lds, st, p);
+        }
     } else {
         const size_t lds = AT<float>::ROW_IMG + AT<float>::TR_IMG;
         hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(grid), dim3(256), lds, st, p);
@@ -1000,8 +1016,15 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
         typedef bf16_t T;
         const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
         const size_t lds_k = 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+        if (tiled_nw8(a->N)) {  // 128 queries / keys per workgroup
+            p.qtiles = cdiv(a->N, 128);
+            const int g8 = a->B * a->heads * p.qtiles;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 8>), dim3(g8), dim3(512), lds_q, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8>), dim3(g8), dim3(512), lds_k, st, p);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+        }
     } else {
         typedef float T;
         const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
