@@ -20,6 +20,9 @@ def time_it(fn, n=20):
 shapes = [("s0.pw1", 802816, 384, 96), ("s0.pw2", 802816, 96, 384), ("s1.pw1", 200704, 768, 192), ("s1.pw2", 200704, 192, 768),
           ("r0.qkv", 50944, 1152, 384), ("r0.proj", 50944, 384, 384), ("r0.fc1", 50944, 1536, 384), ("r0.fc2", 50944, 384, 1536),
           ("r1.qkv", 13312, 2304, 768), ("r1.fc1", 13312, 3072, 768), ("r1.fc2", 13312, 768, 3072), ("sq4k", 4096, 4096, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] == "xl":  # mFormerV1_xl @224, B = 128: RoPE stage 3 (M = 128 * 200) and stage 4 (M = 128 * 53)
+    shapes = [("xl.qkv", 25600, 3072, 1024), ("xl.proj", 25600, 1024, 1024), ("xl.fc1", 25600, 4096, 1024), ("xl.fc2", 25600, 1024, 4096),
+              ("xl4.qkv", 6784, 6144, 2048), ("xl4.fc1", 6784, 8192, 2048), ("xl4.fc2", 6784, 2048, 8192)]
 for name, M, N, K in shapes:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = torch.randn(N, K, device="cuda").bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
