@@ -270,7 +270,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const GemmP p) {
         // end of memory phase kt: own pieces of slice kt+1 landed, fragment reads of slice kt done; the slot refilled
         // in memory phase kt+1 (slice kt+4) is the one read in phase kt
         if (kt + 3 < nk) {
+#ifndef V4_ABLATE_DMA  // diagnostic (wrong results): no fill traffic in the loop -- how much of the time is the fill path?
             issue_stage(kt + 3, (kt + 3) % NST4);
+#endif
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else if (kt + 2 < nk) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
