@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--recompute", action="store_true",
                     help="gradient checkpointing on (TRAIN.GRADIENT_CHECKPOINTING: block inputs kept, activations recomputed in backward); "
                          "not the headline configuration")
+    ap.add_argument("--host-input", action="store_true",
+                    help="every step's batch starts in pinned HOST memory and is moved by linnaeus_amd.prefetch.DevicePrefetcher "
+                         "(copy stream, two batches in flight): the PCIe-inclusive rate -- reported in DESIGN.md, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -192,7 +195,23 @@ def main():
 
     params = [p_ for p_ in model.parameters() if p_.requires_grad]
 
+    feed = None
+    if args.host_input:
+        from linnaeus_amd.prefetch import DevicePrefetcher
+
+        host = [(torch.rand(B, 3, args.img, args.img).pin_memory(), torch.rand(B, 5).pin_memory(),
+                 {t: torch.randint(1, c, (B,)).pin_memory() for t, c in TASKS}) for _ in range(3)]
+
+        def cycle():
+            while True:
+                yield from host
+
+        feed = iter(DevicePrefetcher(cycle(), dev))
+
     def step():
+        nonlocal x, meta, tg
+        if feed is not None:
+            x, meta, tg = next(feed)
         if args.drop_in:
             # the reference's step glue (train.py:147-176,279-316) around the drop-in model, torch ops only
             out = net(x, meta)
@@ -334,6 +353,8 @@ def main():
     if args.recompute:
         line["config"]["workload"] = line["config"]["workload"].replace("gradient checkpointing off", "gradient checkpointing ON (recompute plan)")
         line["workspace_gb"] = round(model._active["ws"].numel() / 1e9, 2)
+    if args.host_input:
+        line["config"]["workload"] += "; inputs start in pinned host memory every step (DevicePrefetcher: PCIe-inclusive, NOT the headline)"
     if args.drop_in:
         line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
     sys.stdout.flush()

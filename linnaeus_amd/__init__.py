@@ -13,4 +13,4 @@ __version__ = "0.1.0"
 from .config import ConfigNode, arch_config, default_config  # noqa: F401
 from .registry import build_model, create_model, install_into_linnaeus, register_head, register_model  # noqa: F401
 from .model import mFormerV1  # noqa: F401
-from . import autobatch, loss, optim  # noqa: F401
+from . import autobatch, loss, optim, prefetch  # noqa: F401

@@ -937,3 +937,33 @@ def test_hierarchical_softmax_heads_match_oracle(golden_dir):
     O.probe_loss(oout).backward()
     glob, wk = _grad_errors(model, osd)
     assert glob <= 1e-3, (glob, wk)
+
+
+def test_device_prefetcher_delivers_batches_in_order():
+    """linnaeus_amd.prefetch.DevicePrefetcher: tuples / dicts of host tensors (pinned or not) arrive on the GPU unchanged and
+    in order, with `depth` transfers in flight, over several passes; device tensors pass through."""
+    from linnaeus_amd.prefetch import DevicePrefetcher
+
+    gen = torch.Generator().manual_seed(0)
+    batches = []
+    for i in range(7):
+        img = torch.rand(4, 3, 32, 32, generator=gen)
+        if i % 2 == 0:
+            img = img.pin_memory()
+        batches.append((img, {"taxa_L10": torch.randint(0, 9, (4,), generator=gen), "n": i}, [torch.full((2,), float(i))], torch.ones(1, device="cuda") * i))
+    for depth in (1, 2, 3):
+        pf = DevicePrefetcher(batches, depth=depth)
+        assert len(pf) == 7
+        for _ in range(2):
+            seen = 0
+            for i, (img, tgt, lst, dev_t) in enumerate(pf):
+                assert img.is_cuda and tgt["taxa_L10"].is_cuda and lst[0].is_cuda and tgt["n"] == i
+                # consume on the current stream right away (what a training step does)
+                s = (img * 2).sum()
+                assert torch.equal(img.cpu(), batches[i][0]) and torch.equal(tgt["taxa_L10"].cpu(), batches[i][1]["taxa_L10"])
+                assert float(lst[0][0]) == float(i) and float(dev_t) == float(i)
+                assert abs(float(s) - 2 * float(batches[i][0].sum())) < 1e-2
+                seen += 1
+            assert seen == 7
+    with pytest.raises(ValueError):
+        DevicePrefetcher(batches, depth=0)
