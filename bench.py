@@ -324,6 +324,10 @@ def main():
                     "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
                     "flops_per_step": work[0] / args.profile_steps}
 
+    if dist:
+        # every rank gets here before any communicator is torn down (rank 0 has just run its profiled steps alone)
+        torch.cuda.synchronize()
+        dist.barrier(device_ids=[local])
     if rank != 0:
         if dist:
             dist.destroy_process_group()
