@@ -173,8 +173,9 @@ class mFormerV1(nn.Module):
         self.attn_drop_rate = M.get("ATTN_DROP_RATE", 0.0)
         self.label_smoothing = M.LABEL_SMOOTHING
         self.only_last_cls = M.ONLY_LAST_CLS
-        if self.drop_rate != 0.0 or self.attn_drop_rate != 0.0:
-            raise NotImplementedError("DROP_RATE / ATTN_DROP_RATE > 0 are not implemented in the HIP path (all shipped configs use 0.0)")
+        # Dropout (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503) is the identity in eval mode: a model configured with
+        # DROP_RATE / ATTN_DROP_RATE > 0 can be built, loaded and validated; a TRAINING forward with them raises (no shipped
+        # config uses them, and the kernels carry no dropout masks).
 
         img = M.IMG_SIZE
         self.img_size = (img, img) if isinstance(img, int) else tuple(img)
@@ -634,6 +635,9 @@ class mFormerV1(nn.Module):
         else:
             meta = None
         train = torch.is_grad_enabled() and any(p_.requires_grad for p_ in self.parameters())
+        if self.training and (self.drop_rate != 0.0 or self.attn_drop_rate != 0.0):
+            raise NotImplementedError("training with DROP_RATE / ATTN_DROP_RATE > 0 is not implemented in the HIP path (all shipped configs "
+                                      "use 0.0); model.eval() forwards are unaffected (dropout is the identity there)")
         st = self._get_plan(B, H, W, train, self._wants_recompute(force_checkpointing))
         self._active = st
         drop = self._draw_drop_scales(st, B, x.device)

@@ -967,3 +967,28 @@ def test_device_prefetcher_delivers_batches_in_order():
             assert seen == 7
     with pytest.raises(ValueError):
         DevicePrefetcher(batches, depth=0)
+
+
+def test_dropout_configs_validate_but_do_not_train(golden_dir):
+    """MODEL.DROP_RATE / ATTN_DROP_RATE > 0 (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503): dropout is the identity in eval
+    mode, so such a model builds, loads and evaluates exactly like the same weights without dropout; a training forward
+    raises loudly (the kernels carry no dropout masks; no shipped config sets them)."""
+    spec, z, sd, x, meta, drops = load_case("tiny_a", golden_dir)
+    ref = build("tiny_a", spec, sd, "fp32")
+    cfg = make_config(spec, IMG["tiny_a"])
+    cfg.MODEL.DROP_RATE = 0.1
+    cfg.MODEL.ATTN_DROP_RATE = 0.05
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype("fp32")
+    xs, ms = x.cuda(), meta.cuda() if meta is not None else None
+    model.eval()
+    ref.eval()
+    with torch.no_grad():
+        a, b = model(xs, ms), ref(xs, ms)
+    for t in a:
+        assert torch.equal(a[t], b[t]), t
+    model.train()
+    with pytest.raises(NotImplementedError, match="DROP_RATE"):
+        model(xs, ms)
