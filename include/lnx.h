@@ -284,6 +284,15 @@ int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float
 int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* gamma, const float* rowscale,
                        int rows_per_sample, void* dz, float* dgamma, int M, int C, void* stream);
 
+/* Dropout of the RoPE blocks' Linear outputs (MODEL.DROP_RATE: blocks/mlp.py:61-66 `self.drop`, rope_2d_mhsa.py:503
+ * `proj_drop`), with the keep mask drawn by the caller (one byte per element, 1 = keep):
+ *   lnx_dropout_mul       x[m, c] = mask[m, c] ? x[m, c] * inv_keep : 0            (in place; T or fp32; C % 8 == 0)
+ *   lnx_dropout_residual  out[m, c] = res[m, c] + rowscale[m / rps] * (mask[m, c] ? z[m, c] * inv_keep : 0)   (z of T, fp32 res / out)
+ * They are separate passes, not epilogue forms: no shipped configuration trains with dropout, the default path stays as it is. */
+int lnx_dropout_mul(void* x, int dtype, const unsigned char* mask, float inv_keep, int M, int C, void* stream);
+int lnx_dropout_residual(const void* z, int z_dtype, const unsigned char* mask, float inv_keep, const float* rowscale, int rows_per_sample,
+                         const float* res, float* out, int M, int C, void* stream);
+
 /* out[map(m), :] = vec[:]  for m in [0, M)   (CLS token expand, mFormerV1.py:448,487) */
 int lnx_fill_rows(const float* vec, float* out, int64_t ldout, lnx_rowmap map, int M, int C, void* stream);
 /* out[c] += sum_m in[map(m), c]   (fp32 atomics) */
@@ -530,6 +539,12 @@ int lnx_plan_bind(lnx_plan* p, const float* const* params, float* const* grads, 
  * which calls use their row.  Outputs: feats [B, dims[3]] fp32, logits (layout above). */
 int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, const float* drop_scales, const unsigned char* drop_mask,
                      float* feats, float* logits, void* stream);
+/* Training-time dropout of the RoPE blocks (MODEL.DROP_RATE): keep masks for the next forward and its backward, one byte per
+ * element, per RoPE block (stage 3 blocks first) [proj output M x C][MLP hidden M x hidden][fc2 output M x C] -- the caller
+ * draws them (Bernoulli(1 - drop_rate)) and keeps the buffer alive until the backward has run.  masks = NULL or
+ * drop_rate = 0 switches dropout off.  Not available on fp8 or inference plans. */
+int64_t lnx_plan_dropout_bytes(const lnx_plan* p);
+int lnx_plan_set_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate);
 /* Backward of the last forward.  dlogits has the logits layout; dfeats [B, dims[3]] is an
  * optional extra gradient on feats (NULL).  Parameter gradients are ACCUMULATED into the bound
  * grads.  segment: -1 = everything, or 0..3 = {tail + RoPE stage 4, RoPE stage 3, ConvNeXt

@@ -112,7 +112,7 @@ def check(rc: int, what: str) -> None:
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus",
-    "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8",
+    "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",

@@ -261,6 +261,101 @@ extern "C" int lnx_im2col_stem(const float* x, int B, int Cin, int H, int W, voi
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dropout with a caller-drawn keep mask (lnx_dropout_mul / lnx_dropout_residual): 8 elements per thread
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_mul_kernel(T* __restrict__ x, const unsigned char* __restrict__ mask, float inv_keep, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const uint2 mk = *reinterpret_cast<const uint2*>(mask + i * 8);
+        const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mk);
+        T* px = x + i * 8;
+        float v[8];
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> t;
+            t.raw = ld16(px);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = mb[j] ? t.get(j) * inv_keep : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t.set(j, v[j]);
+            st16(px, t.raw);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 t = *reinterpret_cast<const float4*>(px + 4 * h);
+                t.x = mb[4 * h] ? t.x * inv_keep : 0.f; t.y = mb[4 * h + 1] ? t.y * inv_keep : 0.f;
+                t.z = mb[4 * h + 2] ? t.z * inv_keep : 0.f; t.w = mb[4 * h + 3] ? t.w * inv_keep : 0.f;
+                *reinterpret_cast<float4*>(px + 4 * h) = t;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_residual_kernel(const T* __restrict__ z, const unsigned char* __restrict__ mask, float inv_keep,
+                                                               const float* __restrict__ rowscale, int rps, const float* __restrict__ res,
+                                                               float* __restrict__ out, int C8, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / C8;
+        const float rs = (rowscale ? rowscale[m / rps] : 1.0f) * inv_keep;
+        const uint2 mk = *reinterpret_cast<const uint2*>(mask + i * 8);
+        const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mk);
+        float zv[8];
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> t;
+            t.raw = ld16(z + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) zv[j] = t.get(j);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 t = *reinterpret_cast<const float4*>(z + i * 8 + 4 * h);
+                zv[4 * h] = t.x; zv[4 * h + 1] = t.y; zv[4 * h + 2] = t.z; zv[4 * h + 3] = t.w;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 r = *reinterpret_cast<const float4*>(res + i * 8 + 4 * h);
+            r.x += mb[4 * h] ? zv[4 * h] * rs : 0.f; r.y += mb[4 * h + 1] ? zv[4 * h + 1] * rs : 0.f;
+            r.z += mb[4 * h + 2] ? zv[4 * h + 2] * rs : 0.f; r.w += mb[4 * h + 3] ? zv[4 * h + 3] * rs : 0.f;
+            *reinterpret_cast<float4*>(out + i * 8 + 4 * h) = r;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int lnx_dropout_mul(void* x, int dtype, const unsigned char* mask, float inv_keep, int M, int C, void* stream) {
+    LNX_CHECK(x && mask && M > 0 && C > 0 && C % 8 == 0, "lnx_dropout_mul: null operand / C %% 8 != 0");
+    LNX_CHECK(dtype == LNX_F32 || dtype == LNX_BF16, "lnx_dropout_mul: bad dtype %d", dtype);
+    LNX_CHECK((((uintptr_t)x) & 15) == 0 && (((uintptr_t)mask) & 7) == 0, "lnx_dropout_mul: x 16-byte, mask 8-byte aligned");
+    const int64_t n8 = (int64_t)M * C / 8;
+    int grid = (int)((n8 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (dtype == LNX_BF16) hipLaunchKernelGGL(dropout_mul_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, mask, inv_keep, n8);
+    else hipLaunchKernelGGL(dropout_mul_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)x, mask, inv_keep, n8);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_dropout_residual(const void* z, int z_dtype, const unsigned char* mask, float inv_keep, const float* rowscale, int rows_per_sample,
+                                    const float* res, float* out, int M, int C, void* stream) {
+    LNX_CHECK(z && mask && res && out && M > 0 && C > 0 && C % 8 == 0, "lnx_dropout_residual: null operand / C %% 8 != 0");
+    LNX_CHECK(z_dtype == LNX_F32 || z_dtype == LNX_BF16, "lnx_dropout_residual: bad dtype %d", z_dtype);
+    LNX_CHECK(((((uintptr_t)z) | ((uintptr_t)res) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)mask) & 7) == 0, "lnx_dropout_residual: misaligned operand");
+    if (rowscale) LNX_CHECK(rows_per_sample > 0, "lnx_dropout_residual: rowscale needs rows_per_sample");
+    const int64_t n8 = (int64_t)M * C / 8;
+    int grid = (int)((n8 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    const int rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    if (z_dtype == LNX_BF16)
+        hipLaunchKernelGGL(dropout_residual_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)z, mask, inv_keep, rowscale, rps, res, out, C / 8, n8);
+    else
+        hipLaunchKernelGGL(dropout_residual_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)z, mask, inv_keep, rowscale, rps, res, out, C / 8, n8);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float* rowscale, int rows_per_sample, void* out,
                               int out_dtype, int64_t ldout, int M, int C, void* stream) {
     LNX_CHECK(in && out && M > 0 && C > 0 && C % 4 == 0 && ldin % 4 == 0, "lnx_scale_cast: bad arguments M=%d C=%d", M, C);

@@ -64,6 +64,7 @@ struct RopeBlk {
     int n1w, n1b, n2w, n2b, freqs, qkvb, projb, fc1b, fc2b;
     OpW qkv, proj, fc1, fc2;
     int64_t xin, n1, mean1, rstd1, qkvbuf, cos, o, lse, xmid, n2, mean2, rstd2, hpre, act;
+    int64_t dm_proj = 0, dm_hid = 0, dm_fc2 = 0;  // byte offsets of this block's dropout keep masks in the caller's mask buffer
 };
 struct MetaHead {
     int b0, lnw0, lnb0, nf1w, nf1b, nf2w, nf2b, b1, b2;
@@ -133,6 +134,10 @@ struct lnx_plan {
     const float* last_meta = nullptr;
     // recompute plans: index of the block whose activations currently sit in each stage's shared buffer set
     int resident[4] = {-1, -1, -1, -1};
+    // training-time dropout of the RoPE blocks (lnx_plan_set_dropout): caller-owned keep masks, 1 / (1 - drop_rate)
+    const unsigned char* dmask = nullptr;
+    float inv_keep = 1.0f;
+    int64_t dmask_bytes = 0;
     // side stream for the tiny M = batch metadata-head chains: they are independent of the image path
     // until token assembly, so they run concurrently with the conv stages (forward) / the downsample
     // backward (backward) instead of serialising ~100 small launches on the main stream
@@ -681,8 +686,35 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_gcos = cv.take(gmax);
         p->o_delta = cv.take(dmax);
     }
+    for (int s = 0; s < 2; ++s) {
+        const int64_t M = (int64_t)B * (s == 0 ? p->N2 : p->N3), C = D[2 + s], hid = c.mlp_hidden[s];
+        for (auto& k : p->rope[s]) {
+            k.dm_proj = p->dmask_bytes;
+            k.dm_hid = k.dm_proj + M * C;
+            k.dm_fc2 = k.dm_hid + M * hid;
+            p->dmask_bytes = k.dm_fc2 + M * C;  // M * C and M * hid are multiples of 8: every mask stays 8-byte aligned
+        }
+    }
     p->ws_bytes = cv.cur;
     *out = p;
+    return 0;
+}
+
+extern "C" int64_t lnx_plan_dropout_bytes(const lnx_plan* p) { return p ? p->dmask_bytes : 0; }
+
+extern "C" int lnx_plan_set_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate) {
+    if (!p) FAIL("lnx_plan_set_dropout: null plan");
+    if (masks == nullptr || drop_rate == 0.0f) {
+        p->dmask = nullptr;
+        p->inv_keep = 1.0f;
+        return 0;
+    }
+    if (!(drop_rate > 0.0f && drop_rate < 1.0f)) FAIL("lnx_plan_set_dropout: drop_rate %g must be in [0, 1)", (double)drop_rate);
+    if (p->c.inference) FAIL("lnx_plan_set_dropout: dropout is a training-time operation; this is an inference plan");
+    if (p->c.fp8) FAIL("lnx_plan_set_dropout: dropout is not available on fp8 plans");
+    if ((((uintptr_t)masks) & 7) != 0) FAIL("lnx_plan_set_dropout: the mask buffer must be 8-byte aligned");
+    p->dmask = masks;
+    p->inv_keep = 1.0f / (1.0f - drop_rate);
     return 0;
 }
 
@@ -1061,13 +1093,31 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
         Timed t(c, 2, 4.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_fwd(&a, c.st));
     }
-    g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<float>(k.xmid), C, true);
-    g.bias = p->P[k.projb]; g.rowscale = p->drop_ptr(p->drop_attn[s][i]); g.rows_per_sample = N; g.res = xin; g.ldres = C;
-    RUN(gemm_nt_t(c, &g));
+    if (p->dmask) {
+        // proj_drop (rope_2d_mhsa.py:503): the product with its bias goes to scratch, dropout + DropPath + residual in one pass
+        g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<void>(p->o_sD), C, false);
+        g.bias = p->P[k.projb];
+        RUN(gemm_nt_t(c, &g));
+        RUN(lnx_dropout_residual(c.at<void>(p->o_sD), c.dt, p->dmask + k.dm_proj, p->inv_keep, p->drop_ptr(p->drop_attn[s][i]), N, xin, c.at<float>(k.xmid), M, C, c.st));
+    } else {
+        g = gemm_base(c, M, C, C, c.at<void>(k.o), C, c.wptr(k.proj), k.proj.ld, c.at<float>(k.xmid), C, true);
+        g.bias = p->P[k.projb]; g.rowscale = p->drop_ptr(p->drop_attn[s][i]); g.rows_per_sample = N; g.res = xin; g.ldres = C;
+        RUN(gemm_nt_t(c, &g));
+    }
     RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2), a8, a8s));
     g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
     g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
     RUN(linear_fwd(c, g, k.fc1, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
+    if (p->dmask) {
+        // Mlp.drop after the activation and after fc2 (blocks/mlp.py:63,65); the saved `act` is the dropped one, which is
+        // what fc2 and its weight gradient consume
+        RUN(lnx_dropout_mul(c.at<void>(k.act), c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));
+        g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, c.at<void>(p->o_sD), C, false);
+        g.bias = p->P[k.fc2b];
+        RUN(gemm_nt_t(c, &g));
+        RUN(lnx_dropout_residual(c.at<void>(p->o_sD), c.dt, p->dmask + k.dm_fc2, p->inv_keep, p->drop_ptr(p->drop_mlp[s][i]), N, c.at<float>(k.xmid), xout, M, C, c.st));
+        return 0;
+    }
     g = gemm_base(c, M, C, hid, c.at<void>(k.act), hid, c.wptr(k.fc2), k.fc2.ld, xout, C, true);
     g.bias = p->P[k.fc2b]; g.rowscale = p->drop_ptr(p->drop_mlp[s][i]); g.rows_per_sample = N; g.res = c.at<float>(k.xmid); g.ldres = C;
     RUN(linear_fwd(c, g, k.fc2, p->o_h8, p->o_h8s));
@@ -1231,11 +1281,13 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     void* sD = c.at<void>(p->o_sD);
     // ---- MLP branch ----
     if (!have_dy) RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
+    if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_fc2, p->inv_keep, M, C, c.st));  // through the dropout after fc2
     RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = hid;
     // fp8 plans: dY is quantised once, the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
     RUN(linear_dgrad(c, a, k.fc2, true, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
+    if (p->dmask) RUN(lnx_dropout_mul(sA, c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));  // through the dropout after the activation
     RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C));
     a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.fc1, false, p->o_h8, p->o_h8s));
@@ -1244,6 +1296,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     d2.p = sC; d2.rowscale = p->drop_ptr(p->drop_attn[s][i]); d2.rps = N;
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
+    if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_proj, p->inv_keep, M, C, c.st));  // through proj_drop
     RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.proj, true, p->o_a8, p->o_a8s));

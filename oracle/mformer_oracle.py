@@ -217,19 +217,28 @@ def rope_attention(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int,
     return linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])  # :502
 
 
-def mlp(sd: StateDict, p: str, x: Tensor) -> Tensor:
-    """Mlp.forward with drop=0 (blocks/mlp.py:61-66)."""
-    return linear(gelu_erf(linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"])), sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+def mlp(sd: StateDict, p: str, x: Tensor, drop_hidden: Optional[Tensor] = None, drop_out: Optional[Tensor] = None) -> Tensor:
+    """Mlp.forward (blocks/mlp.py:61-66): fc1 -> act -> drop -> fc2 -> drop.  The two Dropout draws are given as
+    multipliers (keep mask / keep probability), None = no dropout."""
+    h = gelu_erf(linear(x, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+    if drop_hidden is not None:
+        h = h * drop_hidden
+    y = linear(h, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return y if drop_out is None else y * drop_out
 
 
 def rope_block(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: int,
-               drop_attn: Optional[Tensor], drop_mlp: Optional[Tensor]) -> Tensor:
+               drop_attn: Optional[Tensor], drop_mlp: Optional[Tensor], dropout: Optional[Sequence[Tensor]] = None) -> Tensor:
     """RoPE2DMHSABlock.forward (rope_2d_mhsa.py:584-645); LayerNorm eps = 1e-5.
     The same DropPath module is called twice (:630, :643) so the two residual branches draw
-    independent per-sample masks."""
+    independent per-sample masks.  dropout (MODEL.DROP_RATE > 0, training): the multipliers of proj_drop
+    (rope_2d_mhsa.py:503) and of the two Mlp dropouts, [B, N, C], [B, N, hidden], [B, N, C]."""
     a = rope_attention(sd, p + "attn.", layer_norm_last(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5), H, W, heads, E)
+    if dropout is not None:
+        a = a * dropout[0]
     x = x + apply_drop(a, drop_attn)
-    m = mlp(sd, p + "mlp.", layer_norm_last(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5))
+    m = mlp(sd, p + "mlp.", layer_norm_last(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5),
+            None if dropout is None else dropout[1], None if dropout is None else dropout[2])
     return x + apply_drop(m, drop_mlp)
 
 
@@ -255,8 +264,12 @@ def forward_features(
     meta: Optional[Tensor],
     drop_scales: Optional[Sequence[Optional[Tensor]]] = None,
     tap: Optional[Callable[[str, Tensor], None]] = None,
+    dropout: Optional[Sequence[Sequence[Tensor]]] = None,
 ) -> Tensor:
     """mFormerV1.forward_features (models/mFormerV1.py:407-529).
+
+    dropout (MODEL.DROP_RATE > 0 in training): one (proj, hidden, fc2) triple of multipliers per RoPE block, stage-3 blocks
+    first (see rope_block).
 
     drop_scales: one entry per DropPath *call* in execution order: one per ConvNeXt block
     (s0b0.., s1b0..) then two per RoPE block (attn branch, mlp branch) -- 6 + 2*7 = 20 for
@@ -272,6 +285,7 @@ def forward_features(
         raise ValueError("metadata components are configured but meta is None")
     B = x.shape[0]
     bi = 0
+    ri = 0  # RoPE block counter for `dropout`
 
     x = patchify_conv(x, sd["stem.0.weight"], sd["stem.0.bias"], 4)  # :424
     x = layer_norm_channels_first(x, sd["stem.1.weight"], sd["stem.1.bias"], 1e-6)
@@ -297,8 +311,10 @@ def forward_features(
         tok = torch.cat([*extras, tok], 1)
         t(f"tokens{s}", tok)
         for i in range(spec.rope_depths[s]):
-            tok = rope_block(sd, f"stages.{s + 2}.{i}.", tok, H, W, spec.rope_heads[s], E, ds[bi], ds[bi + 1])
+            tok = rope_block(sd, f"stages.{s + 2}.{i}.", tok, H, W, spec.rope_heads[s], E, ds[bi], ds[bi + 1],
+                             None if dropout is None else dropout[ri])
             bi += 2
+            ri += 1
         t(f"rope{s}", tok)
         tok = layer_norm_last(tok, sd[f"norm_{s + 1}.weight"], sd[f"norm_{s + 1}.bias"], 1e-5)
         cls_final.append(tok[:, 0:1, :])
@@ -330,9 +346,9 @@ def head_weight_key(sd: StateDict, task: str) -> str:
     raise KeyError(f"no head weights for task {task}")
 
 
-def forward(sd: StateDict, spec: Spec, x: Tensor, meta: Optional[Tensor], drop_scales=None, tap=None) -> Dict[str, Tensor]:
+def forward(sd: StateDict, spec: Spec, x: Tensor, meta: Optional[Tensor], drop_scales=None, tap=None, dropout=None) -> Dict[str, Tensor]:
     """mFormerV1.forward (models/mFormerV1.py:531-541) with the effective head math (F3)."""
-    feats = forward_features(sd, spec, x, meta, drop_scales, tap)
+    feats = forward_features(sd, spec, x, meta, drop_scales, tap, dropout)
     out = {}
     for task, _ in spec.heads:
         k = head_weight_key(sd, task)

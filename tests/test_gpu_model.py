@@ -969,10 +969,10 @@ def test_device_prefetcher_delivers_batches_in_order():
         DevicePrefetcher(batches, depth=0)
 
 
-def test_dropout_configs_validate_but_do_not_train(golden_dir):
-    """MODEL.DROP_RATE / ATTN_DROP_RATE > 0 (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503): dropout is the identity in eval
-    mode, so such a model builds, loads and evaluates exactly like the same weights without dropout; a training forward
-    raises loudly (the kernels carry no dropout masks; no shipped config sets them)."""
+def test_dropout_configs(golden_dir):
+    """MODEL.DROP_RATE / ATTN_DROP_RATE > 0 (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503).  Dropout is the identity in eval
+    mode, so such a model evaluates exactly like the same weights without dropout.  Training: DROP_RATE runs (next test);
+    ATTN_DROP_RATE -- dropout inside the attention kernels -- raises loudly."""
     spec, z, sd, x, meta, drops = load_case("tiny_a", golden_dir)
     ref = build("tiny_a", spec, sd, "fp32")
     cfg = make_config(spec, IMG["tiny_a"])
@@ -990,5 +990,63 @@ def test_dropout_configs_validate_but_do_not_train(golden_dir):
     for t in a:
         assert torch.equal(a[t], b[t]), t
     model.train()
-    with pytest.raises(NotImplementedError, match="DROP_RATE"):
+    with pytest.raises(NotImplementedError, match="ATTN_DROP_RATE"):
         model(xs, ms)
+
+
+@pytest.mark.parametrize("name,dtype", [("tiny_b", "fp32"), ("tiny_dp", "fp32"), ("tiny_b", "bf16")])
+def test_drop_rate_training_matches_oracle(name, dtype, golden_dir):
+    """MODEL.DROP_RATE = 0.2 in training: the two Mlp dropouts and proj_drop of every RoPE block, with the keep masks
+    injected so that the CPU oracle applies the same ones; logits and gradients as in the dropout-free tests (the recompute
+    plan included: it must replay the same masks).  A fresh draw (no injection) changes the output from call to call."""
+    spec, z, sd, x, meta, drops = load_case(name, golden_dir)
+    cfg = make_config(spec, IMG[name])
+    cfg.MODEL.DROP_RATE = 0.2
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    B = x.shape[0]
+    E = 1 + len(spec.meta)
+    side = IMG[name] // 16
+    gen = torch.Generator().manual_seed(11)
+    bufs, mult = [], []
+    for s in range(2):
+        N = (side >> s) ** 2 + E
+        C, hid = spec.rope_dims[s], int(spec.rope_dims[s] * spec.mlp_ratio[s])
+        for _ in range(spec.rope_depths[s]):
+            trip = []
+            for w in (C, hid, C):
+                m = (torch.rand(B * N, w, generator=gen) < 0.8).to(torch.uint8)
+                bufs.append(m.reshape(-1))
+                trip.append(m.float().reshape(B, N, w) / 0.8)
+            mult.append(trip)
+    model._inject_dropout = torch.cat(bufs)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x, meta, drops, dropout=mult)
+    O.probe_loss(oout).backward()
+    for ck in (False, True):
+        model.zero_grad(set_to_none=True)
+        model.train(True)
+        model._inject_drop = drops
+        out = model(x.cuda(), meta.cuda() if meta is not None else None, force_checkpointing=ck)
+        for t, _ in spec.heads:
+            ref = oout[t].detach()
+            got = out[t].float().cpu()
+            if dtype == "fp32":
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()), msg=t)
+            else:
+                assert (got - ref).abs().max().item() <= 0.05 * max(1.0, ref.abs().max().item()), t
+        O.probe_loss(out).backward()
+        glob, wk = _grad_errors(model, osd)
+        assert glob <= (1e-3 if dtype == "fp32" else 6e-2), (ck, glob, wk)
+    # without injection every training forward draws new masks
+    model._inject_dropout = None
+    a = model(x.cuda(), meta.cuda() if meta is not None else None)
+    b = model(x.cuda(), meta.cuda() if meta is not None else None)
+    assert any(not torch.equal(a[t], b[t]) for t in a)
+    model.eval()
+    with torch.no_grad():
+        c1 = model(x.cuda(), meta.cuda() if meta is not None else None)
+        c2 = model(x.cuda(), meta.cuda() if meta is not None else None)
+    assert all(torch.equal(c1[t], c2[t]) for t in c1)
