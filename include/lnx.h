@@ -251,6 +251,11 @@ typedef struct lnx_attn_args {
     const float* cos_tab;/* [(N-E), heads, 32] */
     void* o;             /* [B*N, heads*64] */
     float* lse;          /* [B, heads, N] log-sum-exp of the scaled scores */
+    const unsigned char* drop_mask; /* optional (training with MODEL.ATTN_DROP_RATE, rope_2d_mhsa.py:497): keep mask of the attention
+                                       probabilities, one byte per (b, head, query, key), [B, heads, N, Np] with Np = N rounded up to
+                                       a multiple of 64; P is multiplied by mask * drop_inv_keep AFTER the softmax normalisation.
+                                       Runs the 64-row tiled kernels (the dropout-free path keeps its own instantiations). */
+    float drop_inv_keep; /* 1 / (1 - ATTN_DROP_RATE) */
 } lnx_attn_args;
 int lnx_attn_fwd(const lnx_attn_args* args, void* stream);
 
@@ -265,6 +270,8 @@ typedef struct lnx_attn_bwd_args {
     void* dqkv;          /* [B*N, 3*heads*64] */
     float* gcos;         /* workspace [2][B, N-E, heads, 32]: per-sample cos gradients of q and k (overwritten) */
     float* delta;        /* workspace [B, heads, N] */
+    const unsigned char* drop_mask; /* the forward's keep mask (see lnx_attn_args), or NULL */
+    float drop_inv_keep;
 } lnx_attn_bwd_args;
 int lnx_attn_bwd(const lnx_attn_bwd_args* args, void* stream);
 
@@ -545,6 +552,10 @@ int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, const float
  * drop_rate = 0 switches dropout off.  Not available on fp8 or inference plans. */
 int64_t lnx_plan_dropout_bytes(const lnx_plan* p);
 int lnx_plan_set_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate);
+/* The same for MODEL.ATTN_DROP_RATE (dropout on the attention probabilities, rope_2d_mhsa.py:497): per RoPE block a keep
+ * mask [B, heads, N, Np] (Np = N rounded up to a multiple of 64), see lnx_attn_args.drop_mask. */
+int64_t lnx_plan_attn_dropout_bytes(const lnx_plan* p);
+int lnx_plan_set_attn_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate);
 /* Backward of the last forward.  dlogits has the logits layout; dfeats [B, dims[3]] is an
  * optional extra gradient on feats (NULL).  Parameter gradients are ACCUMULATED into the bound
  * grads.  segment: -1 = everything, or 0..3 = {tail + RoPE stage 4, RoPE stage 3, ConvNeXt

@@ -112,7 +112,7 @@ def check(rc: int, what: str) -> None:
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus",
-    "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout",
+    "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
@@ -172,6 +172,7 @@ class AttnArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("E", C.c_int), ("heads", C.c_int),
         ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+        ("drop_mask", C.c_void_p), ("drop_inv_keep", C.c_float),
     ]
 
 
@@ -180,6 +181,7 @@ class AttnBwdArgs(C.Structure):
         ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("E", C.c_int), ("heads", C.c_int),
         ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
         ("d_o", C.c_void_p), ("dqkv", C.c_void_p), ("gcos", C.c_void_p), ("delta", C.c_void_p),
+        ("drop_mask", C.c_void_p), ("drop_inv_keep", C.c_float),
     ]
 
 

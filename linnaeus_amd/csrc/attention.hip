@@ -250,6 +250,9 @@ struct AttnP {
     float* delta;
     int B, N, E, heads;
     int qtiles;
+    const unsigned char* amask = nullptr;  // DROP kernels: keep mask [B, heads, N, Np] of the attention probabilities
+    float a_inv_keep = 1.0f;
+    int Np = 0;                            // N rounded up to a multiple of 64
 };
 
 // ---------------------------------------------------------------------------------
@@ -257,7 +260,9 @@ struct AttnP {
 // staged 64-key tile serves 128 queries, i.e. half the staging work, LDS writes and barriers per query of NW = 4.
 // p.qtiles = ceil(N / (16 NW)).
 // ---------------------------------------------------------------------------------
-template <typename T, int NW = 4>
+// DROP: dropout on the attention probabilities (rope_2d_mhsa.py:497), applied after the normalisation: the running sum
+// takes the undropped exponentials, P . V the dropped ones
+template <typename T, int NW = 4, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kimg = smem;                       // K~ row image
@@ -282,9 +287,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    const unsigned char* mrow = nullptr;
+    if constexpr (DROP) mrow = p.amask + (((int64_t)b * p.heads + head) * p.N + min(q, p.N - 1)) * p.Np + 4 * g;
 
     const int nkt = (p.N + BT - 1) / BT;
     for (int kt = 0; kt < nkt; ++kt) {
+        uint32_t mk[4] = {0, 0, 0, 0};
+        if constexpr (DROP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const uint32_t*>(mrow + kt * BT + 16 * t);
+        }
         __syncthreads();
         stage_tile<T, true, true, false, 64 * NW>(kimg, nullptr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
         stage_tile<T, false, false, true, 64 * NW>(nullptr, vimg, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float e = fexp<T>(pv[t][r] - m_new);
-                pv[t][r] = e;
                 psum += e;
+                pv[t][r] = DROP ? (((mk[t] >> (8 * r)) & 0xffu) ? e * p.a_inv_keep : 0.f) : e;
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
 // ---------------------------------------------------------------------------------
 // backward, query side: delta, dq (and the q part of the cos gradient)
 // ---------------------------------------------------------------------------------
-template <typename T, int NW = 4>
+template <typename T, int NW = 4, bool DROP = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kimg = smem;                                        // K~ rows
@@ -382,9 +394,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
     f32x4_t dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* mrow = nullptr;
+    if constexpr (DROP) mrow = p.amask + (((int64_t)b * p.heads + head) * p.N + min(q, p.N - 1)) * p.Np + 4 * g;
 
     const int nkt = (p.N + BT - 1) / BT;
     for (int kt = 0; kt < nkt; ++kt) {
+        uint32_t mk[4] = {0, 0, 0, 0};
+        if constexpr (DROP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const uint32_t*>(mrow + kt * BT + 16 * t);
+        }
         __syncthreads();
         stage_tile<T, true, true, true, 64 * NW>(kimg, ktr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
         stage_tile<T, false, true, false, 64 * NW>(vimg, nullptr, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
@@ -399,7 +418,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * BT + t * 16 + 4 * g + r;
                 const float pr = (key < p.N && q < p.N) ? fexp<T>(sacc[t][r] - lse) : 0.f;
-                ds[t][r] = pr * (dpacc[t][r] - delta);
+                const float dp = DROP ? (((mk[t] >> (8 * r)) & 0xffu) ? dpacc[t][r] * p.a_inv_keep : 0.f) : dpacc[t][r];
+                ds[t][r] = pr * (dp - delta);
             }
         imgT_times_regs<T>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
     }
@@ -432,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
 // ---------------------------------------------------------------------------------
 // NW = 8: at least 4 waves per SIMD (two 8-wave workgroups per CU) -- left to itself the compiler takes 130 registers and
 // only one workgroup fits
-template <typename T, int NW = 4>
+template <typename T, int NW = 4, bool DROP = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* qimg = smem;                                   // Q~ rows
@@ -488,8 +508,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
                 const int ql = t * 16 + 4 * g + r;
                 const int qq = qt * BT + ql;
                 const float pp = (qq < p.N && key < p.N) ? fexp<T>(sacc[t][r] - lse_s[ql]) : 0.f;
-                pr[t][r] = pp;
-                ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
+                float keepf = 1.0f;
+                if constexpr (DROP)  // this lane's key, the tile's queries: one byte per (query, key)
+                    keepf = p.amask[(((int64_t)b * p.heads + head) * p.N + min(qq, p.N - 1)) * p.Np + min(key, p.N - 1)] ? p.a_inv_keep : 0.f;
+                pr[t][r] = pp * keepf;
+                ds[t][r] = pp * (dpacc[t][r] * keepf - del_s[ql]);
             }
         imgT_times_regs<T>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
         imgT_times_regs<T>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
@@ -962,6 +985,17 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
     p.qtiles = cdiv(a->N, BT);
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
+    if (a->drop_mask) {  // attention-probability dropout: the 64-row tiled kernels with the DROP code
+        LNX_CHECK(a->drop_inv_keep >= 1.0f && (((uintptr_t)a->drop_mask) & 3) == 0, "lnx_attn_fwd: drop_inv_keep >= 1 and a 4-byte aligned mask");
+        p.amask = a->drop_mask; p.a_inv_keep = a->drop_inv_keep; p.Np = p.qtiles * BT;
+        if (a->dtype == LNX_BF16) {
+            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, 4, true>), dim3(grid), dim3(256), AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG, st, p);
+        } else {
+            hipLaunchKernelGGL((attn_fwd_kernel<float, 4, true>), dim3(grid), dim3(256), AT<float>::ROW_IMG + AT<float>::TR_IMG, st, p);
+        }
+        LNX_LAUNCH_CHECK();
+        return 0;
+    }
     if (a->dtype == LNX_BF16 && a->N <= 256 && getenv("LNX_ATTN_TILED") == nullptr) {
         typedef bf16_t T;
         const int npad = p.qtiles * BT;
@@ -999,6 +1033,27 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     p.qtiles = cdiv(a->N, BT);
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
+    if (a->drop_mask) {
+        LNX_CHECK(a->drop_inv_keep >= 1.0f && (((uintptr_t)a->drop_mask) & 3) == 0, "lnx_attn_bwd: drop_inv_keep >= 1 and a 4-byte aligned mask");
+        p.amask = a->drop_mask; p.a_inv_keep = a->drop_inv_keep; p.Np = p.qtiles * BT;
+        if (a->dtype == LNX_BF16) {
+            typedef bf16_t T;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4, true>), dim3(grid), dim3(256), 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, true>), dim3(grid), dim3(256), 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float), st, p);
+        } else {
+            typedef float T;
+            const size_t lds_k = 2 * AT<T>::ROW_IMG + 2 * AT<T>::TR_IMG + 2 * BT * sizeof(float);
+            static bool once = false;
+            if (!once) {
+                set_lds(attn_bwd_dkv_kernel<T, 4, true>, lds_k);
+                once = true;
+            }
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4, true>), dim3(grid), dim3(256), 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, true>), dim3(grid), dim3(256), lds_k, st, p);
+        }
+        LNX_LAUNCH_CHECK();
+        return 0;
+    }
     if (a->dtype == LNX_BF16 && a->N <= 256 && getenv("LNX_ATTN_TILED") == nullptr) {
         typedef bf16_t T;
         const int npad = (a->N + 31) & ~31;

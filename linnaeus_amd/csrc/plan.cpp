@@ -65,6 +65,7 @@ struct RopeBlk {
     OpW qkv, proj, fc1, fc2;
     int64_t xin, n1, mean1, rstd1, qkvbuf, cos, o, lse, xmid, n2, mean2, rstd2, hpre, act;
     int64_t dm_proj = 0, dm_hid = 0, dm_fc2 = 0;  // byte offsets of this block's dropout keep masks in the caller's mask buffer
+    int64_t dm_attn = 0;                          // ... and of its attention-probability keep mask in the second buffer
 };
 struct MetaHead {
     int b0, lnw0, lnb0, nf1w, nf1b, nf2w, nf2b, b1, b2;
@@ -138,6 +139,9 @@ struct lnx_plan {
     const unsigned char* dmask = nullptr;
     float inv_keep = 1.0f;
     int64_t dmask_bytes = 0;
+    const unsigned char* amask = nullptr;  // attention-probability dropout (lnx_plan_set_attn_dropout)
+    float a_inv_keep = 1.0f;
+    int64_t amask_bytes = 0;
     // side stream for the tiny M = batch metadata-head chains: they are independent of the image path
     // until token assembly, so they run concurrently with the conv stages (forward) / the downsample
     // backward (backward) instead of serialising ~100 small launches on the main stream
@@ -693,6 +697,9 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.dm_hid = k.dm_proj + M * C;
             k.dm_fc2 = k.dm_hid + M * hid;
             p->dmask_bytes = k.dm_fc2 + M * C;  // M * C and M * hid are multiples of 8: every mask stays 8-byte aligned
+            const int64_t N = s == 0 ? p->N2 : p->N3;
+            k.dm_attn = p->amask_bytes;
+            p->amask_bytes += (int64_t)B * c.rope_heads[s] * N * ((N + 63) / 64 * 64);
         }
     }
     p->ws_bytes = cv.cur;
@@ -701,6 +708,22 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
 }
 
 extern "C" int64_t lnx_plan_dropout_bytes(const lnx_plan* p) { return p ? p->dmask_bytes : 0; }
+extern "C" int64_t lnx_plan_attn_dropout_bytes(const lnx_plan* p) { return p ? p->amask_bytes : 0; }
+
+extern "C" int lnx_plan_set_attn_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate) {
+    if (!p) FAIL("lnx_plan_set_attn_dropout: null plan");
+    if (masks == nullptr || drop_rate == 0.0f) {
+        p->amask = nullptr;
+        p->a_inv_keep = 1.0f;
+        return 0;
+    }
+    if (!(drop_rate > 0.0f && drop_rate < 1.0f)) FAIL("lnx_plan_set_attn_dropout: drop_rate %g must be in [0, 1)", (double)drop_rate);
+    if (p->c.inference) FAIL("lnx_plan_set_attn_dropout: dropout is a training-time operation; this is an inference plan");
+    if ((((uintptr_t)masks) & 3) != 0) FAIL("lnx_plan_set_attn_dropout: the mask buffer must be 4-byte aligned");
+    p->amask = masks;
+    p->a_inv_keep = 1.0f / (1.0f - drop_rate);
+    return 0;
+}
 
 extern "C" int lnx_plan_set_dropout(lnx_plan* p, const unsigned char* masks, float drop_rate) {
     if (!p) FAIL("lnx_plan_set_dropout: null plan");
@@ -1089,6 +1112,9 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     memset(&a, 0, sizeof a);
     a.dtype = c.dt; a.B = B; a.N = N; a.E = E; a.heads = heads;
     a.qkv = c.at<void>(k.qkvbuf); a.cos_tab = c.at<float>(k.cos); a.o = c.at<void>(k.o); a.lse = c.at<float>(k.lse);
+    if (p->amask) {
+        a.drop_mask = p->amask + k.dm_attn; a.drop_inv_keep = p->a_inv_keep;
+    }
     {
         Timed t(c, 2, 4.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_fwd(&a, c.st));
@@ -1305,6 +1331,9 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
     ab.qkv = c.at<void>(k.qkvbuf); ab.cos_tab = c.at<float>(k.cos); ab.o = c.at<void>(k.o); ab.lse = c.at<float>(k.lse);
     ab.d_o = sD; ab.dqkv = sA; ab.gcos = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
+    if (p->amask) {
+        ab.drop_mask = p->amask + k.dm_attn; ab.drop_inv_keep = p->a_inv_keep;
+    }
     {
         Timed t(c, 3, 14.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_bwd(&ab, c.st));

@@ -174,8 +174,8 @@ class mFormerV1(nn.Module):
         self.label_smoothing = M.LABEL_SMOOTHING
         self.only_last_cls = M.ONLY_LAST_CLS
         # Dropout is the identity in eval mode.  In training DROP_RATE (the two Mlp dropouts and proj_drop of every RoPE block,
-        # blocks/mlp.py:61-66, rope_2d_mhsa.py:503) is applied with keep masks drawn per forward (_set_dropout);
-        # ATTN_DROP_RATE (dropout on the attention probabilities, rope_2d_mhsa.py:497) raises in a training forward.
+        # blocks/mlp.py:61-66, rope_2d_mhsa.py:503) and ATTN_DROP_RATE (the attention probabilities, rope_2d_mhsa.py:497) are
+        # applied with keep masks drawn per forward (_set_dropout).
 
         img = M.IMG_SIZE
         self.img_size = (img, img) if isinstance(img, int) else tuple(img)
@@ -277,6 +277,7 @@ class mFormerV1(nn.Module):
         self._active = None
         self._inject_drop = None      # tests: list of per-call [B] multipliers (None entries = no drop)
         self._inject_dropout = None   # tests: uint8 keep-mask buffer in the plan's layout (lnx_plan_set_dropout) instead of a fresh draw
+        self._inject_attn_dropout = None  # tests: the same for the attention probabilities (lnx_plan_set_attn_dropout)
         self._segment_hook = None     # DataParallel: called after each backward segment is enqueued
         self._grad_arena = None
         self._grad_views: Optional[List[torch.Tensor]] = None
@@ -343,7 +344,7 @@ class mFormerV1(nn.Module):
             st["handle"] = None
             st["ws"] = None       # the workspace goes back to the caching allocator
             st["dl_buf"] = st["dl_views"] = None
-            st["dropout_masks"] = None
+            st["dropout_masks"] = st["attn_dropout_masks"] = None
             st["saved_inputs"] = None
 
     def release_plans(self) -> None:
@@ -564,25 +565,30 @@ class mFormerV1(nn.Module):
         return out
 
     def _set_dropout(self, st, train: bool, dev) -> None:
-        """MODEL.DROP_RATE in training mode (blocks/mlp.py:61-66, rope_2d_mhsa.py:503): draw this forward's keep masks and hand
-        them to the plan; they stay alive in `st` until the next forward of this plan (its backward reads them)."""
+        """MODEL.DROP_RATE (the two Mlp dropouts and proj_drop of every RoPE block: blocks/mlp.py:61-66, rope_2d_mhsa.py:503) and
+        MODEL.ATTN_DROP_RATE (the attention probabilities: rope_2d_mhsa.py:497) in training mode: draw this forward's keep
+        masks and hand them to the plan; they stay alive in `st` until the next forward of this plan (its backward reads them)."""
         lib = L.lib()
-        if not (train and self.training and self.drop_rate > 0.0):
-            if st.get("dropout_masks") is not None:
-                L.check(lib.lnx_plan_set_dropout(st["handle"], None, C.c_float(0.0)), "lnx_plan_set_dropout")
-                st["dropout_masks"] = None
-            return
-        if self._fp8:
-            raise NotImplementedError("DROP_RATE > 0 is not available in fp8 mode")
-        lib.lnx_plan_dropout_bytes.restype = C.c_int64
-        nbytes = int(lib.lnx_plan_dropout_bytes(st["handle"]))
-        if self._inject_dropout is not None:
-            masks = self._inject_dropout.to(dev, torch.uint8).contiguous()
-            assert masks.numel() == nbytes, (masks.numel(), nbytes)
-        else:
-            masks = torch.empty(nbytes, dtype=torch.uint8, device=dev).bernoulli_(1.0 - self.drop_rate)
-        L.check(lib.lnx_plan_set_dropout(st["handle"], C.c_void_p(masks.data_ptr()), C.c_float(self.drop_rate)), "lnx_plan_set_dropout")
-        st["dropout_masks"] = masks
+        active = train and self.training
+        for key, rate, inject, nbytes_fn, set_fn in (
+                ("dropout_masks", self.drop_rate, self._inject_dropout, lib.lnx_plan_dropout_bytes, lib.lnx_plan_set_dropout),
+                ("attn_dropout_masks", self.attn_drop_rate, self._inject_attn_dropout, lib.lnx_plan_attn_dropout_bytes, lib.lnx_plan_set_attn_dropout)):
+            if not (active and rate > 0.0):
+                if st.get(key) is not None:
+                    L.check(set_fn(st["handle"], None, C.c_float(0.0)), "lnx_plan_set_dropout")
+                    st[key] = None
+                continue
+            if key == "dropout_masks" and self._fp8:
+                raise NotImplementedError("DROP_RATE > 0 is not available in fp8 mode")
+            nbytes_fn.restype = C.c_int64
+            nbytes = int(nbytes_fn(st["handle"]))
+            if inject is not None:
+                masks = inject.to(dev, torch.uint8).contiguous()
+                assert masks.numel() == nbytes, (key, masks.numel(), nbytes)
+            else:
+                masks = torch.empty(nbytes, dtype=torch.uint8, device=dev).bernoulli_(1.0 - rate)
+            L.check(set_fn(st["handle"], C.c_void_p(masks.data_ptr()), C.c_float(rate)), "lnx_plan_set_dropout")
+            st[key] = masks
 
     def _plan_forward(self, x, meta, drop):
         st = self._active
@@ -658,10 +664,6 @@ class mFormerV1(nn.Module):
         else:
             meta = None
         train = torch.is_grad_enabled() and any(p_.requires_grad for p_ in self.parameters())
-        if self.training and self.attn_drop_rate != 0.0:
-            raise NotImplementedError("training with ATTN_DROP_RATE > 0 (dropout on the attention probabilities, rope_2d_mhsa.py:497) is not "
-                                      "implemented in the HIP attention kernels (no shipped config uses it); DROP_RATE is, and model.eval() "
-                                      "forwards are unaffected (dropout is the identity there)")
         st = self._get_plan(B, H, W, train, self._wants_recompute(force_checkpointing))
         self._active = st
         drop = self._draw_drop_scales(st, B, x.device)

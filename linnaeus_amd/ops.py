@@ -223,18 +223,22 @@ def rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs):
     L.check(L.lib().lnx_rope_freqs_bwd(_p(freqs), _p(gcos), B, freqs.shape[1], H, W, _p(dfreqs), _stream()), "lnx_rope_freqs_bwd")
 
 
-def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads):
+def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads, *, drop_mask=None, drop_rate=0.0):
     a = L.AttnArgs()
     a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
     a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
+    if drop_mask is not None:
+        a.drop_mask, a.drop_inv_keep = _p(drop_mask), 1.0 / (1.0 - drop_rate)
     L.check(L.lib().lnx_attn_fwd(C.byref(a), _stream()), "lnx_attn_fwd")
 
 
-def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads):
+def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads, *, drop_mask=None, drop_rate=0.0):
     a = L.AttnBwdArgs()
     a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
     a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
     a.d_o, a.dqkv, a.gcos, a.delta = _p(d_o), _p(dqkv), _p(gcos), _p(delta)
+    if drop_mask is not None:
+        a.drop_mask, a.drop_inv_keep = _p(drop_mask), 1.0 / (1.0 - drop_rate)
     L.check(L.lib().lnx_attn_bwd(C.byref(a), _stream()), "lnx_attn_bwd")
 
 

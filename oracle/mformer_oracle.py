@@ -199,8 +199,9 @@ def downsample(sd: StateDict, p: str, x: Tensor) -> Tensor:
     return patchify_conv(y, sd[p + "conv.weight"], sd[p + "conv.bias"], 2)
 
 
-def rope_attention(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: int) -> Tensor:
-    """RoPE2DAttention.forward, standard (non-flash) path (rope_2d_mhsa.py:422-505)."""
+def rope_attention(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: int, attn_drop: Optional[Tensor] = None) -> Tensor:
+    """RoPE2DAttention.forward, standard (non-flash) path (rope_2d_mhsa.py:422-505).  attn_drop: the multiplier of
+    self.attn_drop (:497), [B, heads, N, N], or None."""
     B, N, C = x.shape
     d = C // heads
     qkv = linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"])
@@ -212,6 +213,8 @@ def rope_attention(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int,
     q = q * (d**-0.5)  # :456 (scale applied exactly once, F7)
     s = q.float() @ k.float().transpose(-2, -1)  # :495
     a = torch.softmax(s, dim=-1)  # :496
+    if attn_drop is not None:
+        a = a * attn_drop  # :497
     o = a @ v  # :498
     o = o.transpose(1, 2).reshape(B, N, C)  # :501
     return linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])  # :502
@@ -233,12 +236,13 @@ def rope_block(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: 
     The same DropPath module is called twice (:630, :643) so the two residual branches draw
     independent per-sample masks.  dropout (MODEL.DROP_RATE > 0, training): the multipliers of proj_drop
     (rope_2d_mhsa.py:503) and of the two Mlp dropouts, [B, N, C], [B, N, hidden], [B, N, C]."""
-    a = rope_attention(sd, p + "attn.", layer_norm_last(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5), H, W, heads, E)
-    if dropout is not None:
+    a = rope_attention(sd, p + "attn.", layer_norm_last(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5), H, W, heads, E,
+                       dropout[3] if dropout is not None and len(dropout) > 3 else None)
+    if dropout is not None and dropout[0] is not None:
         a = a * dropout[0]
     x = x + apply_drop(a, drop_attn)
     m = mlp(sd, p + "mlp.", layer_norm_last(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5),
-            None if dropout is None else dropout[1], None if dropout is None else dropout[2])
+            None if dropout is None else dropout[1], None if dropout is None else dropout[2])  # a 4th entry = attention-probability multiplier
     return x + apply_drop(m, drop_mlp)
 
 

@@ -971,8 +971,8 @@ def test_device_prefetcher_delivers_batches_in_order():
 
 def test_dropout_configs(golden_dir):
     """MODEL.DROP_RATE / ATTN_DROP_RATE > 0 (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503).  Dropout is the identity in eval
-    mode, so such a model evaluates exactly like the same weights without dropout.  Training: DROP_RATE runs (next test);
-    ATTN_DROP_RATE -- dropout inside the attention kernels -- raises loudly."""
+    mode, so such a model evaluates exactly like the same weights without dropout, and training forwards draw fresh masks
+    (parity with injected masks: next test)."""
     spec, z, sd, x, meta, drops = load_case("tiny_a", golden_dir)
     ref = build("tiny_a", spec, sd, "fp32")
     cfg = make_config(spec, IMG["tiny_a"])
@@ -990,18 +990,22 @@ def test_dropout_configs(golden_dir):
     for t in a:
         assert torch.equal(a[t], b[t]), t
     model.train()
-    with pytest.raises(NotImplementedError, match="ATTN_DROP_RATE"):
-        model(xs, ms)
+    t1, t2 = model(xs, ms), model(xs, ms)
+    assert any(not torch.equal(t1[t], t2[t]) for t in t1)
+    assert any(not torch.equal(t1[t], a[t]) for t in t1)
 
 
-@pytest.mark.parametrize("name,dtype", [("tiny_b", "fp32"), ("tiny_dp", "fp32"), ("tiny_b", "bf16")])
-def test_drop_rate_training_matches_oracle(name, dtype, golden_dir):
+@pytest.mark.parametrize("name,dtype,attn", [("tiny_b", "fp32", False), ("tiny_dp", "fp32", True), ("tiny_b", "bf16", True), ("tiny_a", "fp32", True)])
+def test_drop_rate_training_matches_oracle(name, dtype, attn, golden_dir):
     """MODEL.DROP_RATE = 0.2 in training: the two Mlp dropouts and proj_drop of every RoPE block, with the keep masks
     injected so that the CPU oracle applies the same ones; logits and gradients as in the dropout-free tests (the recompute
-    plan included: it must replay the same masks).  A fresh draw (no injection) changes the output from call to call."""
+    plan included: it must replay the same masks).  `attn`: MODEL.ATTN_DROP_RATE = 0.1 on top -- dropout on the attention
+    probabilities (rope_2d_mhsa.py:497), which runs the 64-row tiled attention kernels with the mask code.  A fresh draw
+    (no injection) changes the output from call to call."""
     spec, z, sd, x, meta, drops = load_case(name, golden_dir)
     cfg = make_config(spec, IMG[name])
     cfg.MODEL.DROP_RATE = 0.2
+    cfg.MODEL.ATTN_DROP_RATE = 0.1 if attn else 0.0
     model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
     model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
     model = model.cuda()
@@ -1010,18 +1014,25 @@ def test_drop_rate_training_matches_oracle(name, dtype, golden_dir):
     E = 1 + len(spec.meta)
     side = IMG[name] // 16
     gen = torch.Generator().manual_seed(11)
-    bufs, mult = [], []
+    bufs, abufs, mult = [], [], []
     for s in range(2):
         N = (side >> s) ** 2 + E
-        C, hid = spec.rope_dims[s], int(spec.rope_dims[s] * spec.mlp_ratio[s])
+        Np = (N + 63) // 64 * 64
+        C, hid, h = spec.rope_dims[s], int(spec.rope_dims[s] * spec.mlp_ratio[s]), spec.rope_heads[s]
         for _ in range(spec.rope_depths[s]):
             trip = []
             for w in (C, hid, C):
                 m = (torch.rand(B * N, w, generator=gen) < 0.8).to(torch.uint8)
                 bufs.append(m.reshape(-1))
                 trip.append(m.float().reshape(B, N, w) / 0.8)
+            if attn:
+                am = (torch.rand(B, h, N, Np, generator=gen) < 0.9).to(torch.uint8)
+                abufs.append(am.reshape(-1))
+                trip.append(am[..., :N].float() / 0.9)
             mult.append(trip)
     model._inject_dropout = torch.cat(bufs)
+    if attn:
+        model._inject_attn_dropout = torch.cat(abufs)
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     oout = O.forward(osd, spec, x, meta, drops, dropout=mult)
     O.probe_loss(oout).backward()
@@ -1041,7 +1052,7 @@ def test_drop_rate_training_matches_oracle(name, dtype, golden_dir):
         glob, wk = _grad_errors(model, osd)
         assert glob <= (1e-3 if dtype == "fp32" else 6e-2), (ck, glob, wk)
     # without injection every training forward draws new masks
-    model._inject_dropout = None
+    model._inject_dropout = model._inject_attn_dropout = None
     a = model(x.cuda(), meta.cuda() if meta is not None else None)
     b = model(x.cuda(), meta.cuda() if meta is not None else None)
     assert any(not torch.equal(a[t], b[t]) for t in a)

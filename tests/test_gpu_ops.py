@@ -172,8 +172,8 @@ def test_dwconv_mfma(B, H, W, C_):
         torch.testing.assert_close(db.double().cpu(), gb, rtol=1e-4, atol=2e-5 * sc)
 
 
-def _attn_ref(qkv, freqs, B, N, E, heads, H, W):
-    """Oracle math of RoPE2DAttention between the qkv Linear and the proj Linear."""
+def _attn_ref(qkv, freqs, B, N, E, heads, H, W, drop=None):
+    """Oracle math of RoPE2DAttention between the qkv Linear and the proj Linear; drop = attn_drop multiplier [B, h, N, N]."""
     C_ = heads * 64
     t = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
     q, k, v = t[0], t[1], t[2]
@@ -181,6 +181,8 @@ def _attn_ref(qkv, freqs, B, N, E, heads, H, W):
     q = torch.cat([q[:, :, :E], O.rope_scale_pairs(q[:, :, E:], cos)], 2) * 0.125
     k = torch.cat([k[:, :, :E], O.rope_scale_pairs(k[:, :, E:], cos)], 2)
     a = torch.softmax(q @ k.transpose(-2, -1), -1)
+    if drop is not None:
+        a = a * drop
     return (a @ v).transpose(1, 2).reshape(B * N, C_)
 
 
@@ -208,6 +210,43 @@ def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
     gcos = torch.zeros(2, B, H * W, heads, 32, device="cuda")
     delta = torch.empty(B, heads, N, device="cuda")
     ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads)
+    dfreqs = torch.zeros(2, heads, 32, device="cuda")
+    ops.rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs)
+    ref.backward(d_o.double().cpu())
+    tolb = 1e-4 if dtype == L.F32 else 4e-2
+    torch.testing.assert_close(dqkv.double().cpu(), qr.grad, rtol=tolb, atol=tolb)
+    scale = fr.grad.abs().max().item()
+    torch.testing.assert_close(dfreqs.double().cpu(), fr.grad, rtol=tolb, atol=tolb * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("B,heads,H,W,E", [(2, 2, 3, 5, 3), (1, 3, 14, 14, 3), (1, 2, 24, 24, 4)])
+@pytest.mark.parametrize("dtype", [L.F32, L.BF16])
+def test_attention_probability_dropout(B, heads, H, W, E, dtype):
+    """attn_drop (rope_2d_mhsa.py:497): the probabilities are multiplied by keep / (1 - p) AFTER the softmax normalisation, in
+    forward and backward, with the caller's keep mask [B, heads, N, Np]; one-, four- and ten-tile sequences."""
+    N = H * W + E
+    Np = (N + 63) // 64 * 64
+    C_ = heads * 64
+    rate = 0.25
+    gen = g(B + heads * 3 + N)
+    qkv = torch.randn(B * N, 3 * C_, generator=gen).cuda().to(DT[dtype])
+    freqs = O.seeded_fill("t.attn.freqs", (2, heads, 32), 7).cuda()
+    cos = ops.rope_cos_table(freqs, H, W)
+    mask = (torch.rand(B, heads, N, Np, generator=gen) >= rate).to(torch.uint8).cuda()
+    o = torch.empty(B * N, C_, device="cuda", dtype=DT[dtype])
+    lse = torch.empty(B, heads, N, device="cuda")
+    ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads, drop_mask=mask, drop_rate=rate)
+    qr = qkv.double().cpu().requires_grad_(True)
+    fr = freqs.double().cpu().requires_grad_(True)
+    mult = mask[..., :N].double().cpu() / (1.0 - rate)
+    ref = _attn_ref(qr, fr, B, N, E, heads, H, W, mult)
+    tol = 3e-5 if dtype == L.F32 else 2e-2
+    torch.testing.assert_close(o.double().cpu(), ref.detach(), rtol=tol, atol=tol)
+    d_o = torch.randn(B * N, C_, generator=gen).cuda().to(DT[dtype])
+    dqkv = torch.full((B * N, 3 * C_), float("nan"), device="cuda", dtype=DT[dtype])
+    gcos = torch.zeros(2, B, H * W, heads, 32, device="cuda")
+    delta = torch.empty(B, heads, N, device="cuda")
+    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads, drop_mask=mask, drop_rate=rate)
     dfreqs = torch.zeros(2, heads, 32, device="cuda")
     ops.rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs)
     ref.backward(d_o.double().cpu())
