@@ -1,4 +1,8 @@
-"""Micro-benchmark of lnx_gemm_nt epilogue variants on the RoPE-stage shapes (B=256): the forms plan.cpp launches."""
+"""Micro-benchmark of lnx_gemm_nt epilogue variants on the RoPE-stage shapes (B=256): the forms plan.cpp launches.
+
+Every case is run under each value of LNX_NT_V5 given on the command line (default "0 1": the 8-wave one-workgroup-per-CU
+kernels against the 4-wave two-workgroups-per-CU kernel), interleaved in one process (the switch is read per launch), and
+the outputs of the variants are compared with each other and with a torch fp32 product."""
 import ctypes as C
 import os
 import sys
@@ -30,10 +34,31 @@ def time_it(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-M = 50944
-cases = [("qkv   bias            ", 1152, 384, "bias"), ("proj  bias+res f32out ", 384, 384, "res"), ("fc1   bias+gelu+c2    ", 1536, 384, "gelu"),
-         ("fc2   bias+res f32out ", 384, 1536, "res"), ("dfc2  gelu_bwd(aux)   ", 1536, 384, "gelu_bwd"), ("dfc1  plain           ", 384, 1536, "plain")]
-for name, N, K, kind in cases:
+modes = sys.argv[1:] or ["0", "1"]  # "v5" or "v5:stagger"
+
+
+def setmode(m):
+    v5, _, sg = m.partition(":")
+    os.environ["LNX_NT_V5"] = v5
+    sg, _, one = sg.partition(":")
+    os.environ["LNX_V5_STAGGER"] = sg or "0"
+    if one:
+        os.environ["LNX_V5_ONE_WG"] = "1"
+    else:
+        os.environ.pop("LNX_V5_ONE_WG", None)
+
+
+M2, M3 = 50944, 13312
+cases = [("r0.qkv   bias            ", M2, 1152, 384, "bias"), ("r0.proj  bias+res f32out ", M2, 384, 384, "res"),
+         ("r0.fc1   bias+gelu+c2    ", M2, 1536, 384, "gelu"), ("r0.fc2   bias+res f32out ", M2, 384, 1536, "res"),
+         ("r0.dfc2  gelu_bwd(aux)   ", M2, 1536, 384, "gelu_bwd"), ("r0.dfc1  plain           ", M2, 384, 1536, "plain"),
+         ("r0.dqkv  plain           ", M2, 384, 1152, "plain"), ("r0.dproj plain           ", M2, 384, 384, "plain"),
+         ("r1.qkv   bias            ", M3, 2304, 768, "bias"), ("r1.proj  bias+res f32out ", M3, 768, 768, "res"),
+         ("r1.fc1   bias+gelu+c2    ", M3, 3072, 768, "gelu"), ("r1.fc2   bias+res f32out ", M3, 768, 3072, "res"),
+         ("r1.dfc2  gelu_bwd(aux)   ", M3, 3072, 768, "gelu_bwd"), ("r1.dfc1  plain           ", M3, 768, 3072, "plain"),
+         ("r1.dqkv  plain           ", M3, 768, 2304, "plain")]
+tot = {m: 0.0 for m in modes}
+for name, M, N, K, kind in cases:
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     bias = torch.randn(N, device="cuda")
@@ -41,23 +66,53 @@ for name, N, K, kind in cases:
     a.dtype, a.M, a.N, a.K = L.BF16, M, N, K
     a.A, a.lda, a.W, a.ldw = ptr(A), K, ptr(W), K
     keep = []
+    ref = A.float() @ W.float().T
+    c2 = None
     if kind == "res":
         out = torch.empty(M, N, device="cuda")
         res = torch.randn(M, N, device="cuda")
         a.out_f32, a.res, a.ldres, a.bias = 1, ptr(res), N, ptr(bias)
         keep += [res]
+        ref = ref + bias + res
     else:
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        if kind != "plain":
+        if kind not in ("plain", "gelu_bwd"):  # the data-gradient products have no bias
             a.bias = ptr(bias)
+            ref = ref + bias
         if kind == "gelu":
             c2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             a.act, a.c2, a.ldc2 = L.ACT_GELU, ptr(c2), N
             keep += [c2]
+            ref = torch.nn.functional.gelu(ref)
         if kind == "gelu_bwd":
             aux = torch.randn(M, N, device="cuda").bfloat16()
             a.act, a.aux, a.ldaux = L.ACT_GELU_BWD, ptr(aux), N
             keep += [aux]
+            x = aux.float()
+            ref = ref * (0.5 * (1 + torch.erf(x * 0.7071067811865476)) + x * torch.exp(-0.5 * x * x) * 0.3989422804014327)
     a.C, a.ldc = ptr(out), N
-    t = time_it(lambda: L.check(L.lib().lnx_gemm_nt(C.byref(a), st()), "nt"))
-    print(f"{name} N={N:5d} K={K:5d}  {t*1e6:8.1f}us {2.0*M*N*K/t/1e12:7.1f} TF/s", flush=True)
+
+    def run():
+        L.check(L.lib().lnx_gemm_nt(C.byref(a), st()), "nt")
+
+    outs, times = {}, {m: [] for m in modes}
+    for m in modes:
+        setmode(m)
+        out.zero_()
+        run()
+        torch.cuda.synchronize()
+        outs[m] = out.float().clone()
+    for _ in range(3):  # interleaved rounds
+        for m in modes:
+            setmode(m)
+            times[m].append(time_it(run))
+    err = (outs[modes[0]] - ref).abs().max().item() / ref.abs().max().item()
+    diff = max((outs[m] - outs[modes[0]]).abs().max().item() for m in modes)
+    line = f"{name} M={M:6d} N={N:5d} K={K:5d} "
+    for m in modes:
+        t = min(times[m])
+        tot[m] += t
+        line += f" | v5={m}: {t*1e6:7.1f}us {2.0*M*N*K/t/1e12:6.1f} TF/s"
+    print(line + f" | rel err vs fp32 {err:.1e}, max diff between variants {diff:.1e}", flush=True)
+    del ref, outs
+print("sum: " + "  ".join(f"v5={m}: {tot[m]*1e6:.1f}us" for m in modes))
