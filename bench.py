@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--host-input", action="store_true",
                     help="every step's batch starts in pinned HOST memory and is moved by linnaeus_amd.prefetch.DevicePrefetcher "
                          "(copy stream, two batches in flight): the PCIe-inclusive rate -- reported in DESIGN.md, never the headline")
+    ap.add_argument("--eval", action="store_true", help="inference throughput in the reference's throughput_test protocol instead of the training step")
+    ap.add_argument("--eval-batches", default="64,128,256,512")
+    ap.add_argument("--eval-iters", type=int, default=100)
+    ap.add_argument("--eval-warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -95,6 +99,52 @@ def make_model(args):
     cfg.TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS = False
     model = build_model(cfg, num_classes={t: c for t, c in TASKS})
     return cfg, model
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (tools/profile_round.sh -> profiles/rNN_<tag>_gemm_nt_traffic.json): the file of the HIGHEST round, its "final" pass if
+    there is one, else the newest by modification time.  Returns (bytes_per_launch, file name)."""
+    import re
+
+    d = os.path.join(REPO, "profiles")
+    best = None
+    for f in os.listdir(d) if os.path.isdir(d) else []:
+        m = re.match(r"r(\d+)_(.*)_gemm_nt_traffic\.json$", f)
+        if m:
+            key = (int(m.group(1)), m.group(2) == "final", os.path.getmtime(os.path.join(d, f)))
+            if best is None or key > best[0]:
+                best = (key, f)
+    if best is None:
+        return None, None
+    with open(os.path.join(d, best[1])) as fh:
+        return json.load(fh)["bytes_per_launch"], "profiles/" + best[1]
+
+
+def eval_throughput(args):
+    """`--eval`: the reference's inference-throughput protocol (evaluation/throughput_tester.py:56-90) on inference plans:
+    eval mode, no_grad, synthetic rand images + metadata, WARM_UP_ITERATIONS untimed, NUM_ITERATIONS timed between device
+    synchronisations, one result per batch size.  Prints one JSON line; `value` is the best batch size's images/sec."""
+    from linnaeus_amd.throughput import throughput_test
+
+    torch.cuda.set_device(0)
+    cfg, model = make_model(args)
+    model = model.cuda()
+    model.set_compute_dtype(args.dtype)
+    ec = type("EvalCfg", (), {})()
+    ec.THROUGHPUT = type("T", (), {})()
+    ec.THROUGHPUT.BATCH_SIZES = [int(b) for b in args.eval_batches.split(",")]
+    ec.THROUGHPUT.NUM_ITERATIONS = args.eval_iters
+    ec.THROUGHPUT.WARM_UP_ITERATIONS = args.eval_warmup
+    res = throughput_test(model, ec, img_size=args.img, in_channels=3, meta_dims=list(model.meta_dims), device=torch.device("cuda", 0))
+    best = max(res, key=lambda r: r["imgs_per_sec"])
+    print(json.dumps({
+        "metric": f"images/sec (eval forward, no_grad) mFormerV1_{args.arch} 3x{args.img}x{args.img}", "value": round(best["imgs_per_sec"], 2),
+        "unit": "images/sec", "n_gpus": 1, "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"throughput_test protocol of the reference (evaluation/throughput_tester.py:56-90): eval mode, no_grad, "
+                               f"{args.eval_warmup} warm-up + {args.eval_iters} timed iterations per batch size, inference plans",
+                   "best_batch": best["batch_size"]},
+        "results": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in res]}), flush=True)
 
 
 def cpu_baseline(args, cfg):
@@ -118,26 +168,73 @@ def cpu_baseline(args, cfg):
         loss = sum(F.cross_entropy(out[t], tg[t]) for t, _ in TASKS)
         loss.backward()
 
-    step()
-    n = 3
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+loss+bwd, batch {B}, 1 warm-up + {n} timed steps, {args.img}x{args.img}"}
+    def fwd():
+        with torch.no_grad():
+            O.forward(sd, spec, x, meta)
+
+    # 3 warm-up + 10 timed steps, forward-only and forward+backward
+    warm, n = 3, 10
+    res = {}
+    for name, fn in (("fwd", fwd), ("fwd_bwd", step)):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        res[name] = B * n / (time.perf_counter() - t0)
+    ref = None
+    rp = os.path.join(REPO, "profiles", "r03_reference_cpu_timing.json")  # the imported reference timed in the build container
+    if os.path.exists(rp):
+        with open(rp) as fh:
+            ref = json.load(fh)
+    return {"value": round(res["fwd_bwd"], 3), "unit": "images/sec", "cores": cores, "kind": "port", "fwd_only_images_per_sec": round(res["fwd"], 3),
+            "sample": f"oracle fp32, batch {B}, {warm} warm-up + {n} timed steps each of forward-only and forward+loss+backward (value = the latter), {args.img}x{args.img}",
+            "reference_in_build_container": ref}
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, one process per GPU, as
+    the driver's own command line does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`).  This parent never touches the GPU (no HIP call, no torch.cuda call) and never execs: it
+    runs the launcher as a CHILD, relays rank 0's JSON line on stdout and exits with the child's return code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this stack
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:  # ranks print nothing else on stdout; keep the last JSON object in case a library does
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    sys.exit(rc if rc != 0 or line is not None else 1)
 
 
 def main():
     args = parse()
     if args.batch is None:
         args.batch = 256 if args.gpus == 1 else 128
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (python bench.py --gpus N starts them itself)")
+    if args.eval:
+        return eval_throughput(args)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # stdout carries the one JSON line and nothing else: anything a library prints on the way (RCCL's version banner goes to
@@ -258,6 +355,12 @@ def main():
     # exposed_allreduce_ms = step time with collectives - without; n1_equiv = what one GPU does alone at this per-GPU
     # batch, so the scaling efficiency value / (n_gpus * n1_equiv) is computable from this one line.
     dp_extra = None
+    rccl_ranks = None
+    if dist:
+        # the world size the communicator itself reports, and proof that a collective saw that many contributions
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = {"world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()), "backend": dist.get_backend()}
     if dist and hasattr(net, "no_sync"):
         k = max(3, min(args.steps, 10))
         with net.no_sync():
@@ -312,15 +415,12 @@ def main():
         a = work[0] / (ms[0] * 1e-3) / 1e12
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure comes
         # from the committed rocprofv3 --pmc passes of this same command (profiles/*_gemm_nt_traffic.json); null otherwise
-        traffic = None
+        traffic = traffic_src = None
         if args.arch == "sm" and args.batch == 256 and args.dtype == "bf16" and args.img == 224:
-            cands = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_gemm_nt_traffic.json")) if os.path.isdir(os.path.join(REPO, "profiles")) else []
-            if cands:
-                with open(os.path.join(REPO, "profiles", cands[-1])) as f:
-                    traffic = json.load(f)["bytes_per_launch"]
+            traffic, traffic_src = committed_traffic()
         roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2/v4_kernel<{args.dtype}> (pipelined forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
                     "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                     "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
                     "flops_per_step": work[0] / args.profile_steps}
 
@@ -352,6 +452,9 @@ def main():
         "loss": round(last_loss, 4),
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }
+    if rccl_ranks:
+        line["rccl_ranks"] = rccl_ranks["world_size"]
+        line["rccl"] = rccl_ranks
     if dp_extra:
         line["data_parallel"] = dp_extra
     if args.recompute:

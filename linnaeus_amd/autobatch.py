@@ -5,9 +5,10 @@ The reference finds the largest per-GPU batch by binary search over REAL trainin
 workspace (every saved activation, the operand arena and all scratch) is computed by the planner without allocating, so
 the memory of a batch size is
 
-    workspace(B) + parameters + gradient arena + optimizer state + one input batch + logits
+    workspace(B) + dropout keep masks (DROP_RATE / ATTN_DROP_RATE > 0) + logits (+ dlogits) + parameters + gradient arena
+    + optimizer state + one input batch
 
-to the byte.  `auto_find_batch_size` keeps the reference's signature and result (largest batch whose footprint stays
+-- every plan-side term exactly as the native planner reports it (`mFormerV1.plan_footprint`).  `auto_find_batch_size` keeps the reference's signature and result (largest batch whose footprint stays
 under `target_memory_fraction` of the device, broadcast from rank 0 under DDP), does the search analytically, and then
 verifies the winner with `steps_per_trial` real steps, backing off if the measured peak is over budget (allocator
 fragmentation, caller-side tensors).  On MI355X the budget is 288 GB per GPU.
@@ -32,10 +33,10 @@ def predicted_bytes(model, batch: int, img_size: Optional[int] = None, *, mode: 
     n_param = sum(p.numel() for p in m.parameters())
     train = mode == "train"
     H = img_size or m.img_size[0]
-    ws = m.workspace_bytes(batch, H, H, train=train)
+    fp = m.plan_footprint(batch, H, H, train=train)
     fixed = 4 * n_param * (1 + ((1 + optimizer_state_per_param) if train else 0))
-    io = batch * (m._in_chans * H * H + sum(m.meta_dims) + 2048) * 4
-    return ws + fixed + io
+    io = batch * (m._in_chans * H * H + sum(m.meta_dims)) * 4
+    return fp["workspace"] + fp["dropout"] + fp["attn_dropout"] + fp["logits"] + fixed + io
 
 
 def foreign_bytes(model) -> int:

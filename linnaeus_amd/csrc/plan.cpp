@@ -985,10 +985,13 @@ const lnx_rowmap IDM = {0, 0, 0};
 // LayerNorm forward for qkv and fc1, the fc1 epilogue for fc2); `out8` / `out8s` ask this product's epilogue for the MXFP8
 // copy of its own output.  The epilogue (bias, GELU + pre-activation copy, fp32 residual with DropPath scale) is the same
 // code either way.
-bool fp8_rows(const lnx_plan* p, int M) { return p->c.fp8 != 0 && M >= 256; }
+// `width` = the narrower side of the block's products (its channel count C: K of qkv / fc1, N of proj / fc2): the MXFP8 kernel
+// needs K >= 256 as well as M >= 256, and a block is all-fp8 or all-bf16 because the producers of one product's operand copy
+// (LayerNorm, the fc1 epilogue) must match the consumer's choice.
+bool fp8_rows(const lnx_plan* p, int M, int width) { return p->c.fp8 != 0 && M >= 256 && width >= 256; }
 int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w, int64_t a8, int64_t a8s, int64_t out8 = 0, int64_t out8s = 0) {
     lnx_plan* p = c.p;
-    if (!fp8_rows(p, g.M) || w.off8s == 0) return gemm_nt_t(c, &g);
+    if (!fp8_rows(p, g.M, g.K < g.N ? g.K : g.N) || w.off8s == 0) return gemm_nt_t(c, &g);
     g.A = c.at<void>(a8);
     g.lda = g.K;
     g.W = c.at<void>(w.off8);
@@ -1004,7 +1007,7 @@ int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w, int64_t a8, int64_t 
 // MXFP8 (`a8` / `a8s`; quantised here from the bf16 `g.A` when `quantise` is set), the weight as its transposed MXFP8 copy.
 int linear_dgrad(const Ctx& c, lnx_gemm_args g, const OpW& w, bool quantise, int64_t a8, int64_t a8s, int64_t out8 = 0, int64_t out8s = 0) {
     lnx_plan* p = c.p;
-    if (!fp8_rows(p, g.M) || w.off8ts == 0) return gemm_nt_t(c, &g);
+    if (!fp8_rows(p, g.M, g.K < g.N ? g.K : g.N) || w.off8ts == 0) return gemm_nt_t(c, &g);
     if (quantise) RUN(lnx_quantize_mxfp8(g.A, LNX_BF16, g.lda, g.M, g.K, c.at<void>(a8), g.K, c.at<void>(a8s), c.st));
     g.A = c.at<void>(a8);
     g.lda = g.K;
@@ -1100,7 +1103,7 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
     const float* xin = c.at<float>(k.xin);
     p->resident[2 + s] = i;
-    const bool f8 = fp8_rows(p, M);
+    const bool f8 = fp8_rows(p, M, C);
     void* a8 = f8 ? c.at<void>(p->o_a8) : nullptr;
     void* a8s = f8 ? c.at<void>(p->o_a8s) : nullptr;
     RUN(ln_fwd(c, M, C, 1e-5f, xin, LNX_F32, C, IDM, k.n1w, k.n1b, c.at<void>(k.n1), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean1), c.at<float>(k.rstd1), a8, a8s));

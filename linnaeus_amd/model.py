@@ -268,11 +268,13 @@ class mFormerV1(nn.Module):
         dt_name = str(kwargs.get("compute_dtype", os.environ.get("LNX_DTYPE", M.get("LNX_DTYPE", "bf16")))).lower()
         self._fp8 = dt_name in ("fp8", "mxfp8")
         self._dtype_code = L.BF16 if self._fp8 else _DTYPES[dt_name]
-        # "direct" (default): parameter gradients are written straight into .grad views of one flat fp32 arena (what
-        # loss.backward() + optimizer.step() callers such as the reference's train.py need; zero-copy).  "autograd": the
-        # autograd Function returns copies, for torch.autograd.grad() callers (GradNorm-style code).
-        self.grad_mode = "direct"
-        self.max_cached_plans = 3     # LRU bound of native plans (each owns a workspace proportional to the batch size)
+        # "autograd" (default): the autograd Function RETURNS the parameter gradients, so AccumulateGrad runs and everything
+        # hooked to it works -- torch DistributedDataParallel (what the reference's launch path wraps the model in,
+        # main.py:982), torch.autograd.grad() (GradNorm), parameter hooks.  "direct" (opt-in: linnaeus_amd.ddp.DataParallel,
+        # bench.py, FusedAdamW loops): gradients are written straight into .grad views of one flat fp32 arena, zero-copy, and
+        # autograd sees None for every parameter -- no hook fires, so it must never be combined with torch DDP.
+        self.grad_mode = str(kwargs.get("grad_mode", "autograd"))
+        self.max_cached_plans = 4     # LRU bound (train, validation, and a tail batch of each) of native plans (each owns a workspace proportional to the batch size)
         self._plans: "OrderedDict[Any, Dict[str, Any]]" = OrderedDict()
         self._active = None
         self._inject_drop = None      # tests: list of per-call [B] multipliers (None entries = no drop)
@@ -418,8 +420,19 @@ class mFormerV1(nn.Module):
         """Bytes of plan workspace (saved activations + operand arena + scratch) a forward[/backward] of this batch shape
         needs -- computed by the native planner WITHOUT allocating anything, which is what lets AutoBatch size a batch
         for 288 GB analytically instead of by out-of-memory trials (utils/autobatch.py:111-265)."""
+        H = img_h or self.img_size[0]
+        W = img_w or img_h or self.img_size[1]
+        return self.plan_footprint(batch, H, W, train, recompute)["workspace"]
+
+    def plan_footprint(self, batch: int, img_h: Optional[int] = None, img_w: Optional[int] = None, train: bool = True,
+                       recompute: Optional[bool] = None) -> Dict[str, int]:
+        """Everything a plan of this shape holds on the device, computed by the native planner without allocating: the
+        workspace, the per-forward dropout keep masks that live OUTSIDE it (`lnx_plan_dropout_bytes` /
+        `lnx_plan_attn_dropout_bytes`; only when MODEL.DROP_RATE / ATTN_DROP_RATE > 0 and in training) and the fp32 logits
+        buffer (the forward's output and, in training, the persistent dlogits buffer of the same size)."""
         lib = L.lib()
-        lib.lnx_plan_workspace_bytes.restype = C.c_int64
+        for fn in (lib.lnx_plan_workspace_bytes, lib.lnx_plan_dropout_bytes, lib.lnx_plan_attn_dropout_bytes, lib.lnx_plan_logits_numel):
+            fn.restype = C.c_int64
         H = img_h or self.img_size[0]
         W = img_w or img_h or self.img_size[1]
         if recompute is None:  # what a training forward would use
@@ -428,7 +441,10 @@ class mFormerV1(nn.Module):
         handle = C.c_void_p()
         L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
         try:
-            return int(lib.lnx_plan_workspace_bytes(handle)) + 256
+            drop = int(lib.lnx_plan_dropout_bytes(handle)) if (train and self.drop_rate > 0.0) else 0
+            adrop = int(lib.lnx_plan_attn_dropout_bytes(handle)) if (train and self.attn_drop_rate > 0.0) else 0
+            logits = int(lib.lnx_plan_logits_numel(handle)) * 4 * (2 if train else 1)
+            return {"workspace": int(lib.lnx_plan_workspace_bytes(handle)) + 256, "dropout": drop, "attn_dropout": adrop, "logits": logits}
         finally:
             lib.lnx_plan_destroy(handle)
 
@@ -481,6 +497,47 @@ class mFormerV1(nn.Module):
         self._ensure_bound(st)
         return st
 
+    @staticmethod
+    def _arena_offsets(numels: List[int], seg_of: List[int]):
+        """Layout of the flat gradient arena: parameters ordered by (backward segment, plan index), 16-byte aligned slices.
+        Returns (offset per plan index, total floats, {segment: (lo, hi)})."""
+        order = sorted(range(len(numels)), key=lambda i: (seg_of[i], i))
+        offs, cur, seg_bounds = {}, 0, {}
+        for i in order:
+            seg = seg_of[i]
+            seg_bounds.setdefault(seg, [cur, cur])
+            offs[i] = cur
+            cur += (numels[i] + 3) // 4 * 4
+            seg_bounds[seg][1] = cur
+        return offs, cur, {s: tuple(b) for s, b in seg_bounds.items()}
+
+    def grad_arena_layout(self, batch: int = 1, img_h: Optional[int] = None, img_w: Optional[int] = None) -> Dict[str, Any]:
+        """Host-only (no GPU, nothing allocated): the gradient-arena geometry the data-parallel reducer works on -- plan
+        parameter names, the module tensor behind each (shared hierarchical-head Linears appear ONCE), its backward segment
+        (`lnx_plan_segment_params`), its slice of the arena, and the four bucket bounds."""
+        lib = L.lib()
+        lib.lnx_plan_param_name.restype = C.c_char_p
+        lib.lnx_plan_param_numel.restype = C.c_int64
+        H = img_h or self.img_size[0]
+        W = img_w or img_h or self.img_size[1]
+        cfg = self._make_cfg(int(batch), int(H), int(W), True, False)
+        handle = C.c_void_p()
+        L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
+        try:
+            n = lib.lnx_plan_num_params(handle)
+            names = [lib.lnx_plan_param_name(handle, i).decode() for i in range(n)]
+            numels = [int(lib.lnx_plan_param_numel(handle, i)) for i in range(n)]
+            seg_of = [3] * n
+            buf = (C.c_int * n)()
+            for seg in range(4):
+                for j in range(lib.lnx_plan_segment_params(handle, seg, buf, n)):
+                    seg_of[buf[j]] = seg
+        finally:
+            lib.lnx_plan_destroy(handle)
+        params = [self._param_for(nm) for nm in names]
+        offs, total, bounds = self._arena_offsets(numels, seg_of)
+        return dict(names=names, params=params, numels=numels, seg_of=seg_of, offsets=[offs[i] for i in range(n)], total=total, bounds=bounds)
+
     def _ensure_grad_arena(self, st) -> None:
         """One flat fp32 gradient arena, ordered by backward segment (so each segment is one
         contiguous all-reduce bucket); every parameter gets a view into it."""
@@ -489,17 +546,10 @@ class mFormerV1(nn.Module):
         dev = params[0].device
         if self._grad_arena is not None and self._arena_layout == (ident, dev):
             return
-        order = sorted(range(st["n"]), key=lambda i: (st["seg_of"][i], i))
-        offs, cur, seg_bounds = {}, 0, {}
-        for i in order:
-            seg = st["seg_of"][i]
-            seg_bounds.setdefault(seg, [cur, cur])
-            offs[i] = cur
-            cur += (params[i].numel() + 3) // 4 * 4  # 16-byte aligned slices
-            seg_bounds[seg][1] = cur
+        offs, cur, seg_bounds = self._arena_offsets([p_.numel() for p_ in params], st["seg_of"])
         self._grad_arena = torch.zeros(cur, dtype=torch.float32, device=dev)
         self._grad_views = [self._grad_arena[offs[i]: offs[i] + params[i].numel()].view(params[i].shape) for i in range(st["n"])]
-        self._segment_bounds = {s: tuple(b) for s, b in seg_bounds.items()}
+        self._segment_bounds = seg_bounds
         self._arena_layout = (ident, dev)
         for s2 in self._plans.values():
             s2["ptrs"] = None
@@ -643,8 +693,11 @@ class mFormerV1(nn.Module):
                 elif not a:
                     p_.grad.add_(v)
             return [None] * len(params)
-        # autograd mode: hand out copies, so nothing a caller holds ever aliases the arena the next backward zeroes
-        return [v.clone() for v in views]
+        # autograd mode: hand out copies (ONE copy of the arena, sliced), so nothing a caller holds ever aliases the arena
+        # the next backward zeroes
+        snap = self._grad_arena.clone()
+        base = self._grad_arena.data_ptr()
+        return [snap[(v.data_ptr() - base) // 4: (v.data_ptr() - base) // 4 + v.numel()].view(v.shape) for v in views]
 
     # ------------------------------------------------------------------ public forward
     def _run(self, x: torch.Tensor, meta: Optional[torch.Tensor], force_checkpointing: Optional[bool] = None):

@@ -246,6 +246,21 @@ def rope_block(sd: StateDict, p: str, x: Tensor, H: int, W: int, heads: int, E: 
     return x + apply_drop(m, drop_mlp)
 
 
+def dropout_multipliers_from_masks(masks: Sequence[Tensor], ps: Sequence[float]):
+    """Keep masks in the order the reference's forward calls nn.Dropout -- per RoPE block: attn_drop on the probabilities
+    [B, h, N, N] (rope_2d_mhsa.py:497; absent when ATTN_DROP_RATE = 0), proj_drop [B, N, C] (:503), Mlp.drop on the hidden and
+    on the output (blocks/mlp.py:63,65) -- to the per-block (proj, hidden, fc2[, attn]) multiplier tuples `forward(dropout=)`
+    takes: mask / (1 - p)."""
+    mult = [m.float() / (1.0 - p) for m, p in zip(masks, ps)]
+    per = 4 if mult and mult[0].dim() == 4 else 3
+    assert len(mult) % per == 0
+    out = []
+    for i in range(0, len(mult), per):
+        blk = mult[i:i + per]
+        out.append((blk[1], blk[2], blk[3], blk[0]) if per == 4 else (blk[0], blk[1], blk[2]))
+    return out
+
+
 def meta_head(sd: StateDict, p: str, m: Tensor) -> Tensor:
     """nn.Sequential(Linear, ReLU, LayerNorm, ResNormLayer) (mFormerV1.py:291-296);
     ResNormLayer.forward = x + LN2(ReLU(W2 LN1(ReLU(W1 x)))) (res_norm_layer.py:23-30)."""

@@ -36,6 +36,43 @@ def load_case(name, golden_dir):
     return spec, z, sd, x, meta, drops
 
 
+def load_dropout_case(golden_dir, name="tiny_drop"):
+    """tiny_drop.npz: the reference model (tiny_a architecture) in training mode with DROP_RATE / ATTN_DROP_RATE > 0 and the
+    keep mask of every nn.Dropout call it made (make_golden.run_dropout_case).  Returns the masks in call order."""
+    import numpy as np
+    import torch
+
+    spec = CASES["tiny_a"]
+    z = np.load(f"{golden_dir}/{name}.npz", allow_pickle=False)
+    x, meta = torch.from_numpy(z["x"]), torch.from_numpy(z["meta"])
+    sd = O.seeded_state_dict(O.param_shapes(spec), SEED)
+    masks, ps = [], []
+    for i in range(int(z["n_masks"])):
+        shape = tuple(int(v) for v in z[f"mask_shape_{i}"])
+        n = int(np.prod(shape))
+        masks.append(torch.from_numpy(np.unpackbits(z[f"mask_{i}"])[:n].reshape(shape).astype(np.bool_)))
+        ps.append(float(z[f"mask_p_{i}"]))
+    return spec, z, sd, x, meta, masks, ps
+
+
+def plan_dropout_buffers(masks):
+    """The recorded masks (per RoPE block: attention [B, h, N, N], proj [B, N, C], hidden [B, N, hid], fc2 [B, N, C]) in the
+    layout lnx_plan_set_dropout / lnx_plan_set_attn_dropout take: per block proj | hidden | fc2 bytes, and per block the
+    attention mask with its key axis padded to a multiple of 64."""
+    import torch
+
+    flat, attn = [], []
+    for i in range(0, len(masks), 4):
+        a, pj, hd, f2 = masks[i:i + 4]
+        flat += [pj.reshape(-1).to(torch.uint8), hd.reshape(-1).to(torch.uint8), f2.reshape(-1).to(torch.uint8)]
+        B, h, N, _ = a.shape
+        Np = (N + 63) // 64 * 64
+        pad = torch.zeros(B, h, N, Np, dtype=torch.uint8)
+        pad[..., :N] = a.to(torch.uint8)
+        attn.append(pad.reshape(-1))
+    return torch.cat(flat), torch.cat(attn)
+
+
 def make_config(spec, img, head_type="Linear", drop_path_rate=None):
     """linnaeus_amd config for a Spec (mirrors apply_spec() of the golden generator)."""
     from linnaeus_amd import default_config

@@ -17,6 +17,7 @@ Cases:
   tiny_b   depths (2,1)/(2,1), E=4 (+ELEVATION), ONLY_LAST_CLS, img 96
   tiny_c   metadata inactive (E=1), ConditionalClassifier heads on a real TaxonomyTree (F3)
   tiny_dp  tiny_a in train mode with DROP_PATH_RATE=0.5 and recorded per-call masks
+  tiny_drop tiny_a in train mode with DROP_RATE=0.2 / ATTN_DROP_RATE=0.1 and the recorded keep mask of every nn.Dropout call
   sm       the real mFormerV1_sm config at 224, B=2, 4 Linear heads (1000/300/80/20)
 plus per-op known answers (cos table, LN variants, dwconv, softmax-attention, aggregate) and
   soft_ce     the reference's TaxonomyAwareLabelSmoothingCE (per-sample losses + logits gradient)
@@ -228,6 +229,75 @@ def run_case(name, spec, img, batch, head_type="Linear", taxonomy=None, train_dr
     assert err < 5e-5, err
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
     return model
+
+
+def run_dropout_case(name, spec, img, batch, drop_rate=0.2, attn_drop_rate=0.1):
+    """MODEL.DROP_RATE / MODEL.ATTN_DROP_RATE > 0 in training mode on the reference model (blocks/mlp.py:61-66,
+    rope_2d_mhsa.py:497,503).  Every nn.Dropout of the reference goes through torch.nn.functional.dropout: for the duration
+    of the run that function is replaced by one that draws its keep mask from a seeded generator, records it and applies
+    x * mask / keep (the definition of dropout), so the fixture holds the masks the reference used, call by call -- per RoPE
+    block: attention probabilities [B, h, N, N], proj_drop [B, N, C], Mlp hidden [B, N, hidden], Mlp output [B, N, C] --
+    next to its logits, loss and gradients."""
+    import torch.nn.functional as F
+
+    cfg = apply_spec(base_cfg(img), spec, "Linear")
+    cfg.MODEL.DROP_RATE = drop_rate
+    cfg.MODEL.ATTN_DROP_RATE = attn_drop_rate
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    ref_sd = load_seeded(model, SEED)
+    model.train()
+    x, meta = O.seeded_inputs(spec, batch, img, SEED + 1)
+    rec = {"x": x.numpy(), "meta": meta.numpy(), "img": np.array(img), "batch": np.array(batch),
+           "drop_rate": np.array(drop_rate), "attn_drop_rate": np.array(attn_drop_rate)}
+    masks = []
+    gen = torch.Generator().manual_seed(SEED + 21)
+    real = F.dropout
+
+    def recorded_dropout(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = 1.0 - p
+        m = torch.rand(input.shape, generator=gen) < keep
+        masks.append((m, float(p)))
+        return input * m.to(input.dtype) / keep
+
+    F.dropout = recorded_dropout
+    try:
+        out = model(x, meta)
+        loss = O.probe_loss(out)
+        model.zero_grad()
+        loss.backward()
+    finally:
+        F.dropout = real
+    n_blocks = sum(spec.rope_depths)
+    assert len(masks) == 4 * n_blocks, (len(masks), n_blocks)
+    for i, (m, p_) in enumerate(masks):
+        rec[f"mask_{i}"] = np.packbits(m.numpy().reshape(-1))
+        rec[f"mask_shape_{i}"] = np.array(m.shape)
+        rec[f"mask_p_{i}"] = np.array(p_)
+    rec["n_masks"] = np.array(len(masks))
+    for t, lg in out.items():
+        rec["logits_" + t] = lg.detach().numpy()
+    rec["loss"] = np.array(loss.item())
+    seen = {canonical_name(k): p_.grad for k, p_ in model.named_parameters() if p_.grad is not None}
+    names = sorted(seen)
+    rec["grad_names"] = np.array(names)
+    rec["grad_norms"] = np.array([seen[k].double().norm().item() for k in names])
+    rec["grad_sums"] = np.array([seen[k].double().sum().item() for k in names])
+    for k in names:
+        rec["gradslice_" + k] = first_slice(seen[k], 8)
+    # pin the oracle's dropout restatement against the live reference, with the recorded masks
+    osd = {canonical_name(k): v.clone().requires_grad_(True) for k, v in ref_sd.items() if "hmatrix" not in k}
+    mult = O.dropout_multipliers_from_masks([m for m, _ in masks], [p_ for _, p_ in masks])
+    oout = O.forward(osd, spec, x, meta, None, dropout=mult)
+    err = max((oout[t].detach() - out[t].detach()).abs().max().item() for t in out)
+    O.probe_loss(oout).backward()
+    gnum = sum((osd[k].grad - seen[k]).double().pow(2).sum().item() for k in names)
+    gden = sum(seen[k].double().pow(2).sum().item() for k in names)
+    gerr = (gnum / gden) ** 0.5  # global relative gradient error (a per-tensor ratio blows up on tensors whose gradient is ~0)
+    print(f"[{name}] {len(masks)} dropout calls recorded; oracle-vs-reference max|dlogits| = {err:.3e}, global relative gradient error {gerr:.3e}")
+    assert err < 5e-5 and gerr < 1e-4, (err, gerr)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
 
 
 def run_train_step(name, spec, img, batch, steps=2):
@@ -570,6 +640,8 @@ def main():
     if want("sm"):
         sm = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20)))
         run_case("sm", sm, 224, 2)
+    if want("tiny_drop"):
+        run_dropout_case("tiny_drop", tiny_a, 64, 2)
     if want("per_op"):
         per_op_known_answers()
     if want("soft_ce"):

@@ -8,6 +8,8 @@ Tolerances (stated per BASELINE.md section 4):
 """
 import numpy as np
 import pytest
+import os
+
 import torch
 
 from linnaeus_amd import build_model
@@ -161,6 +163,45 @@ def test_direct_grad_mode_accumulates():
         torch.testing.assert_close(p_.grad, g1[k], rtol=1e-4, atol=1e-6)
 
 
+def test_torch_ddp_wrap_default_grad_mode():
+    """an untouched model wrapped in torch DistributedDataParallel -- what the reference's launch path does
+    (main.py:982).  The default grad_mode returns gradients through autograd, so DDP's AccumulateGrad hooks fire, the reduction
+    finishes and a second forward is accepted; gradients equal the un-wrapped model's.  One rank over RCCL."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 1)
+    x, meta = O.seeded_inputs(spec, 2, 64, 5)
+    plain = build("tiny_a", spec, sd, "fp32")
+    assert plain.grad_mode == "autograd"
+    plain.train()
+    O.probe_loss(plain(x.cuda(), meta.cuda())).backward()
+    want = {k: p_.grad.clone() for k, p_ in plain.named_parameters()}
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        model = build("tiny_a", spec, sd, "fp32")
+        model.train()
+        ddp = DDP(model, device_ids=[torch.cuda.current_device()], find_unused_parameters=True)  # as main.py:975-982
+        fired = []
+        next(model.parameters()).register_post_accumulate_grad_hook(lambda p_: fired.append(1))
+        for step in range(2):  # the second forward raises "Expected to have finished reduction" if no hook fired in the first
+            ddp.zero_grad(set_to_none=True)
+            O.probe_loss(ddp(x.cuda(), meta.cuda())).backward()
+            for k, p_ in model.named_parameters():
+                torch.testing.assert_close(p_.grad, want[k], rtol=1e-4, atol=1e-6, msg=f"step {step} {k}")
+        assert len(fired) == 2
+        g = torch.autograd.grad(O.probe_loss(model(x.cuda(), meta.cuda())), [model.cls_token_2])[0]  # GradNorm-style caller
+        torch.testing.assert_close(g, want["cls_token_2"], rtol=1e-4, atol=1e-6)
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_train_step_matches_reference(dtype, golden_dir):
     """Caller (ii) of SURVEY 8c on the HIP model: forward -> CE -> backward -> clip_grad_norm_ -> AdamW, two
@@ -208,7 +249,8 @@ def test_large_384_matches_oracle():
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     oout = O.forward(osd, spec, x, meta)
     O.probe_loss(oout).backward()
-    for dtype, ftol, gtol in (("fp32", 2e-4, 2e-3), ("bf16", 0.1, 0.1)):
+    # bf16 bounds = 3x the measured error (the measured values are printed), not a loose 0.10
+    for dtype, ftol, gtol in (("fp32", 2e-4, 2e-3), ("bf16", 0.04, 0.05)):
         model.set_compute_dtype(dtype)
         model.train()
         model.zero_grad()
@@ -216,6 +258,7 @@ def test_large_384_matches_oracle():
         for t, _ in spec.heads:
             ref = oout[t].detach()
             err = (out[t].float().cpu() - ref).abs().max().item()
+            print(f"[lg@384/{dtype}] {t}: max logit error / scale {err / max(1.0, ref.abs().max().item()):.4f}")
             assert err <= ftol * max(1.0, ref.abs().max().item()), (dtype, t, err)
             if dtype == "fp32":
                 assert (out[t].argmax(-1).cpu() == ref.argmax(-1)).all()
@@ -236,8 +279,8 @@ def test_xlarge_224_matches_oracle_and_autobatch():
     blocks have 106 rows and stay bf16) -- conv stages on the plain GEMM path (C = 256 / 512 is beyond the fused conv-MLP),
     LayerNorm at C = 1024 / 2048, 24 RoPE blocks.  Logits and gradients against the CPU oracle on the same seeded
     weights, then AutoBatch (utils/autobatch.py:111-265) sizes the batch for a memory budget from the planner's exact
-    workspace figure.  Stated tolerance for bf16 and fp8 alike: 0.15 of the logit scale and of the global gradient norm
-    (measured: bf16 0.012 / 0.016, fp8 0.068 / 0.085 -- 22 quantised blocks deep on random-init weights)."""
+    workspace figure.  Stated tolerances, as fractions of the logit scale / of the global gradient norm: bf16 0.04 / 0.05 (3x the
+    measured 0.012 / 0.016), fp8 0.10 / 0.12 (measured 0.068 / 0.085 -- 22 quantised blocks deep on random-init weights)."""
     from linnaeus_amd.autobatch import auto_find_batch_size, foreign_bytes, predicted_bytes
 
     spec = O.Spec(conv_dims=(256, 512, 1024, 2048), rope_depths=(22, 2), rope_heads=(16, 32), heads=(("taxa_L10", 40), ("taxa_L20", 9)))
@@ -251,7 +294,7 @@ def test_xlarge_224_matches_oracle_and_autobatch():
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     oout = O.forward(osd, spec, x, meta)
     O.probe_loss(oout).backward()
-    for dtype, ftol, gtol in (("fp32", 3e-4, 3e-3), ("bf16", 0.15, 0.15), ("fp8", 0.15, 0.15)):
+    for dtype, ftol, gtol in (("fp32", 3e-4, 3e-3), ("bf16", 0.04, 0.05), ("fp8", 0.10, 0.12)):
         model.set_compute_dtype(dtype)
         model.train()
         model.zero_grad()
@@ -829,6 +872,28 @@ def test_fp8_mode_rejects_unsupported_widths(golden_dir):
         L.check(L.lib().lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
 
 
+def test_fp8_plan_with_a_narrow_rope_stage_falls_back_to_bf16():
+    """RoPE dims that are multiples of 128 but below the MXFP8 kernel's K >= 256 floor (tiny: C = 128 with
+    16 x 19 = 304 >= 256 rows) used to create a plan that then failed inside lnx_plan_forward; such a stage now runs its bf16
+    products, like a stage with fewer than 256 rows (C = 256 with 112 rows here): fp8 mode == bf16 mode, bit for bit."""
+    spec = CASES["tiny_a"]
+    sd = O.seeded_state_dict(O.param_shapes(spec), 5)
+    x, meta = O.seeded_inputs(spec, 16, 64, 6)
+    outs, grads = {}, {}
+    for dtype in ("bf16", "fp8"):
+        model = build("tiny_a", spec, sd, dtype)
+        model.train()
+        out = model(x.cuda(), meta.cuda())
+        O.probe_loss(out).backward()
+        outs[dtype] = {t: v.detach().clone() for t, v in out.items()}
+        grads[dtype] = {k: p_.grad.clone() for k, p_ in model.named_parameters()}
+    for t in outs["bf16"]:
+        assert torch.equal(outs["bf16"][t], outs["fp8"][t]), t
+    rel = sum((grads["fp8"][k] - grads["bf16"][k]).double().pow(2).sum().item() for k in grads["bf16"]) ** 0.5
+    rel /= sum(grads["bf16"][k].double().pow(2).sum().item() for k in grads["bf16"]) ** 0.5
+    assert rel < 1e-5, rel  # same kernels; the float atomics of the weight-gradient sums are the only run-to-run difference
+
+
 def test_backward_through_features_only_and_a_single_task(golden_dir):
     """autograd may reach the model with gradients for only some of its outputs: forward_features() alone (no logits
     gradient at all) and a loss on one task (the other heads then get exactly zero gradient, the trunk only that task's)."""
@@ -993,6 +1058,55 @@ def test_dropout_configs(golden_dir):
     t1, t2 = model(xs, ms), model(xs, ms)
     assert any(not torch.equal(t1[t], t2[t]) for t in t1)
     assert any(not torch.equal(t1[t], a[t]) for t in t1)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_drop_rate_training_matches_reference(dtype, golden_dir):
+    """the dropout path pinned to the reference.  tiny_drop.npz holds the keep mask of every nn.Dropout
+    call the reference model made in one training forward (DROP_RATE 0.2, ATTN_DROP_RATE 0.1: blocks/mlp.py:61-66,
+    rope_2d_mhsa.py:497,503) and its logits / loss / gradients; the HIP plan gets the same masks (lnx_plan_set_dropout /
+    lnx_plan_set_attn_dropout layout) and must reproduce them -- kept-activation and recompute plans."""
+    from tests.cases import load_dropout_case, plan_dropout_buffers
+
+    spec, z, sd, x, meta, masks, ps = load_dropout_case(golden_dir)
+    cfg = make_config(spec, 64)
+    cfg.MODEL.DROP_RATE = float(z["drop_rate"])
+    cfg.MODEL.ATTN_DROP_RATE = float(z["attn_drop_rate"])
+    model = build_model(cfg, num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    model._inject_dropout, model._inject_attn_dropout = plan_dropout_buffers(masks)
+    names = [str(n) for n in z["grad_names"]]
+    for ck in (False, True):
+        model.zero_grad(set_to_none=True)
+        model.train(True)
+        out = model(x.cuda(), meta.cuda(), force_checkpointing=ck)
+        for t, _ in spec.heads:
+            ref = torch.from_numpy(z["logits_" + t])
+            got = out[t].float().cpu()
+            if dtype == "fp32":
+                torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()), msg=t)
+                assert (got.argmax(-1) == ref.argmax(-1)).all()
+            else:
+                assert (got - ref).abs().max().item() <= 0.05 * max(1.0, ref.abs().max().item()), t
+        loss = O.probe_loss(out)
+        assert abs(loss.item() - float(z["loss"])) <= (1e-4 if dtype == "fp32" else 3e-2) * max(1.0, abs(float(z["loss"])))
+        loss.backward()
+        got = {}
+        for k, p_ in model.named_parameters():
+            parts = k.split(".")
+            got[f"head.{parts[3]}.fc.{parts[4]}" if (parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers") else k] = p_.grad
+        num = den = 0.0
+        for i, k in enumerate(names):
+            ref_norm = float(z["grad_norms"][i])
+            n = got[k].double().norm().item()
+            num += (n - ref_norm) ** 2
+            den += ref_norm ** 2
+            if dtype == "fp32":
+                assert abs(n - ref_norm) <= 1e-3 * max(ref_norm, 1e-3), (ck, k, n, ref_norm)
+                np.testing.assert_allclose(got[k].reshape(-1)[:8].float().cpu().numpy(), z["gradslice_" + k], rtol=5e-3, atol=5e-6, err_msg=k)
+        assert (num / den) ** 0.5 <= (1e-3 if dtype == "fp32" else 5e-2), (ck, (num / den) ** 0.5)
 
 
 @pytest.mark.parametrize("name,dtype,attn", [("tiny_b", "fp32", False), ("tiny_dp", "fp32", True), ("tiny_b", "bf16", True), ("tiny_a", "fp32", True)])

@@ -16,7 +16,11 @@ from tests.cases import TINY_DIMS, TinyTree, make_config
 pytestmark = pytest.mark.gpu
 
 
-def test_training_loop_pieces_compose_and_learn():
+@pytest.mark.parametrize("augment", [False, True])
+def test_training_loop_pieces_compose_and_learn(augment):
+    """augment=False: no mixup, no DropPath -- nothing stochastic is left but the summation order of the float
+    atomics, and 32 separable images must be memorised outright (accuracy >= 0.95, loss below 0.3 of its start).
+    augment=True: selective mixup + DropPath 0.1 on top; the bar there is that the loss falls and the accuracy rises."""
     from linnaeus_amd.collate import GPUSelectiveMixup
     from linnaeus_amd.loss import GradientWeighting, TaxonomyAwareLabelSmoothingCE, build_taxonomy_smoothing_matrix, weighted_hierarchical_loss
     from linnaeus_amd.optim import FusedAdamW
@@ -30,13 +34,14 @@ def test_training_loop_pieces_compose_and_learn():
     tasks = [t for t, _ in heads]
     nc = dict(heads)
     spec = O.Spec(conv_dims=TINY_DIMS, conv_depths=(2, 1), rope_depths=(2, 1), rope_heads=(2, 4), meta=(("TEMPORAL", 2), ("SPATIAL", 3)),
-                  heads=heads, drop_path_rate=0.1)
+                  heads=heads, drop_path_rate=0.1 if augment else 0.0)
     parent = {"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}}
     tree = TinyTree(parent, tasks, nc)
     cfg = make_config(spec, 64, "ConditionalClassifier")
     model = build_model(cfg, num_classes=nc, taxonomy_tree=tree).cuda()
     model.set_compute_dtype("bf16")
     model.use_checkpoint = True   # what train.py sets from TRAIN.GRADIENT_CHECKPOINTING (recompute plan)
+    model.grad_mode = "direct"    # FusedAdamW loop: gradients accumulate in the flat arena
 
     # a fixed data set of 32 images whose label is readable from the image (mean brightness of a class-specific channel pattern)
     n, B = 32, 8
@@ -57,7 +62,7 @@ def test_training_loop_pieces_compose_and_learn():
             onehot = {t: torch.nn.functional.one_hot(labels[t][sl], nc[t]).float() for t in tasks}
             yield images[sl], onehot, aux[sl], torch.ones(B, 5, dtype=torch.bool), torch.zeros(B, dtype=torch.long)
 
-    mix = GPUSelectiveMixup({"PROB": 0.5, "ALPHA": 0.4, "meta_chunk_bounds_list": [(0, 2), (2, 5)]})
+    mix = GPUSelectiveMixup({"PROB": 0.5 if augment else 0.0, "ALPHA": 0.4, "meta_chunk_bounds_list": [(0, 2), (2, 5)]})
     crit = {}
     for t in tasks:
         dist = (1.0 - torch.eye(nc[t])).cuda()
@@ -101,8 +106,12 @@ def test_training_loop_pieces_compose_and_learn():
     acc1 = accuracy()
     print(f"[train loop] loss {epoch_loss[0]:.3f} -> {epoch_loss[-1]:.3f}; taxa_L10 accuracy {acc0:.2f} -> {acc1:.2f}; plans {len(model._plans)}")
     assert all(torch.isfinite(torch.tensor(epoch_loss)))
-    assert epoch_loss[-1] < 0.6 * epoch_loss[0], epoch_loss
-    assert acc1 >= 0.6 and acc1 > acc0 + 0.3, (acc0, acc1)  # run-to-run spread: float atomics in the gradient sums
+    if augment:
+        assert epoch_loss[-1] < 0.6 * epoch_loss[0], epoch_loss
+        assert acc1 >= 0.6 and acc1 > acc0 + 0.3, (acc0, acc1)  # mixup + DropPath draws amplify the summation-order noise of the float atomics
+    else:
+        assert epoch_loss[-1] < 0.3 * epoch_loss[0], epoch_loss
+        assert acc1 >= 0.95, (acc0, acc1)
     # a recompute training plan and an inference plan, nothing else, are alive
     kinds = sorted((k[-2], k[-1]) for k in model._plans)
     assert kinds == [(False, False), (True, True)], kinds

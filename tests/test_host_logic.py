@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's model interface (no GPU needed): registry/build_model
 behaviour, state_dict contract for all four architectures, config plumbing, loud failure on CPU."""
+import os
+
 import pytest
 import torch
 
@@ -100,3 +102,150 @@ def test_drop_path_schedule_matches_reference_linspace():
     probs = [b.drop_prob for s in model.stages for b in s]
     ref = [x.item() for x in torch.linspace(0, 0.2, 13)]
     assert probs == pytest.approx(ref)
+
+
+def test_default_grad_mode_is_autograd():
+    """gradients flow through autograd unless a caller opts into the zero-copy mode -- torch DDP hooks
+    and torch.autograd.grad() need AccumulateGrad to run (test_gpu_model.py::test_torch_ddp_wrap_default_grad_mode runs it)."""
+    from linnaeus_amd.ddp import DataParallel
+
+    model = build_model(make_config(CASES["tiny_a"], 64), num_classes={t: c for t, c in CASES["tiny_a"].heads})
+    assert model.grad_mode == "autograd"
+    DataParallel(model, broadcast=False)
+    assert model.grad_mode == "direct"
+
+
+def test_build_model_loads_local_pretrained(tmp_path):
+    """models/build.py:94-103 + utils/checkpoint.py:513-700 for a local single-source checkpoint: "model" key, `module.` prefix,
+    the target model's drop_params patterns (head., meta_, norm., downsample_layers. are NOT taken from the checkpoint)."""
+    spec = CASES["tiny_a"]
+    nc = {t: c for t, c in spec.heads}
+    torch.manual_seed(1)
+    src = build_model(make_config(spec, 64), num_classes=nc)
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model": {"module." + k: v for k, v in src.state_dict().items()}, "epoch": 3}, path)
+    cfg = make_config(spec, 64)
+    cfg.MODEL.PRETRAINED = str(path)
+    torch.manual_seed(2)
+    dst = build_model(cfg, num_classes=nc)
+    a, b = src.state_dict(), dst.state_dict()
+    dropped = [k for k in a if k.startswith(("head.", "meta_", "downsample_layers.")) or ".norm." in k or k.startswith("norm.")]
+    taken = [k for k in a if k not in dropped]
+    assert taken and dropped
+    for k in taken:
+        if "norm" in k and not torch.equal(a[k], b[k]):
+            continue  # LayerNorm weights initialise to the same constants either way
+        assert torch.equal(a[k], b[k]), k
+    assert any(not torch.equal(a[k], b[k]) for k in dropped if a[k].dtype.is_floating_point and a[k].numel() > 8)
+    for bad in ({"PRETRAINED": "hf://org/repo/model.pth"}, {"PRETRAINED": str(path), "PRETRAINED_SOURCE": "metaformer"}):
+        cfg2 = make_config(spec, 64)
+        for k, v in bad.items():
+            cfg2.MODEL[k] = v
+        with pytest.raises((FileNotFoundError, NotImplementedError)):
+            build_model(cfg2, num_classes=nc)
+
+
+_REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF), reason="build-container only: the reference is not on the GPU box")
+def test_install_into_linnaeus_swaps_the_reference_registry():
+    """the reference-side binding.  In a child process (so that nothing of `linnaeus` stays imported
+    here): import linnaeus.models, build mFormerV1 through the REFERENCE's build_model with its yacs CfgNode and a real
+    TaxonomyTree -> the reference class; call install_into_linnaeus(); build again through the same reference entry point ->
+    the HIP-backed class, whose state_dict has exactly the reference model's keys, shapes and order."""
+    import subprocess
+    import sys
+    import textwrap
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import logging, sys, warnings
+        warnings.filterwarnings("ignore"); logging.disable(logging.CRITICAL)
+        import torch
+        from yacs.config import CfgNode as CN
+        from linnaeus.config import get_default_config
+        from linnaeus.models import build_model
+        from linnaeus.models import model_factory as mf
+        from linnaeus.utils.config_utils import load_config, merge_configs
+        from linnaeus.utils.taxonomy.taxonomy_tree import TaxonomyTree
+
+        def cfg():
+            c = get_default_config()
+            arch = load_config("/root/reference/configs/model/archs/mFormerV1/mFormerV1_sm.yaml")
+            c.MODEL = merge_configs(c.MODEL, arch.MODEL)
+            c.MODEL.IMG_SIZE = 224
+            tasks = ["taxa_L10", "taxa_L20", "taxa_L30"]
+            c.DATA.TASK_KEYS_H5 = tasks
+            c.MODEL.CLASSIFICATION.HEADS = CN({t: {"TYPE": "ConditionalClassifier", "ROUTING_STRATEGY": "soft", "TEMPERATURE": 1.0, "USE_BIAS": True} for t in tasks})
+            return c, tasks
+
+        c, tasks = cfg()
+        nc = {"taxa_L10": 6, "taxa_L20": 3, "taxa_L30": 2}
+        tree = TaxonomyTree({"taxa_L10": {0: 0, 1: 0, 2: 1, 3: 1, 4: 2, 5: 2}, "taxa_L20": {0: 0, 1: 0, 2: 1}}, tasks, nc)
+        ref = build_model(c, num_classes=nc, taxonomy_tree=tree)
+        assert type(ref).__module__.startswith("linnaeus."), type(ref)
+        import linnaeus_amd
+        from linnaeus_amd.registry import install_into_linnaeus
+        assert install_into_linnaeus()
+        ours = build_model(c, num_classes=nc, taxonomy_tree=tree)
+        assert type(ours) is linnaeus_amd.model.mFormerV1 and mf._model_registry["mFormerV1"] is linnaeus_amd.model.mFormerV1, type(ours)
+        a, b = ref.state_dict(), ours.state_dict()
+        assert list(a.keys()) == list(b.keys()), [k for k in a if k not in b][:5] + [k for k in b if k not in a][:5]
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        assert [n for n, _ in ref.named_parameters()] == [n for n, _ in ours.named_parameters()]
+        ours.load_state_dict(a, strict=True)
+        assert ref.parameter_groups_metadata == ours.parameter_groups_metadata
+        assert ref.pretrained_ckpt_handling_metadata == ours.pretrained_ckpt_handling_metadata
+        assert set(ours.head.keys()) == set(ref.head.keys()) and all(hasattr(h, "set_gradnorm_mode") for h in ours.head.values())
+        print("OK", len(a))
+    """)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(repo, "tests", "golden", "gen", "_stubs"), _REF, repo]))
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_plan_footprint_counts_dropout_masks_and_logits():
+    """AutoBatch's predicted bytes include what lives outside the plan workspace -- the per-forward dropout
+    keep masks (one byte per element of three [M, C] / [M, hidden] tensors per RoPE block, B x heads x N x Np for the attention
+    probabilities) and the logits / dlogits buffers."""
+    from linnaeus_amd.autobatch import predicted_bytes
+
+    spec = CASES["tiny_a"]
+    nc = {t: c for t, c in spec.heads}
+    plain = build_model(make_config(spec, 64), num_classes=nc)
+    cfg = make_config(spec, 64)
+    cfg.MODEL.DROP_RATE, cfg.MODEL.ATTN_DROP_RATE = 0.2, 0.1
+    drop = build_model(cfg, num_classes=nc)
+    B = 4
+    f0, f1 = plain.plan_footprint(B, 64), drop.plan_footprint(B, 64)
+    assert f0["dropout"] == f0["attn_dropout"] == 0 and f0["workspace"] == f1["workspace"]
+    want = attn = 0
+    for s in range(2):
+        N = (4 >> s) ** 2 + 3
+        C_, hid, h = spec.rope_dims[s], int(spec.rope_dims[s] * spec.mlp_ratio[s]), spec.rope_heads[s]
+        want += spec.rope_depths[s] * B * N * (2 * C_ + hid)
+        attn += spec.rope_depths[s] * B * h * N * ((N + 63) // 64 * 64)
+    assert f1["dropout"] == want and f1["attn_dropout"] == attn
+    assert f1["logits"] == 2 * 4 * B * sum((c + 7) // 8 * 8 for c in nc.values())
+    assert drop.plan_footprint(B, 64, train=False)["dropout"] == 0
+    assert predicted_bytes(drop, B, 64) - predicted_bytes(plain, B, 64) == want + attn
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the GPU-less failure mode of the self-launcher")
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts the ranks itself (torch.distributed.run as a
+    child process, never exec) before any GPU call in the parent; in a GPU-less container the only failure is
+    torch.cuda.set_device inside the two children, and the parent propagates the launcher's return code."""
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "torch.distributed.run" in r.stderr and r.stderr.count("torch.cuda.set_device(local)") == 2, r.stderr[-3000:]
+    assert "No HIP GPUs are available" in r.stderr

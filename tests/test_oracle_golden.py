@@ -53,6 +53,31 @@ def test_backward_matches_reference(name, golden_dir):
         np.testing.assert_allclose(g.reshape(-1)[:8].numpy(), z["gradslice_" + k], rtol=2e-3, atol=2e-6, err_msg=k)
 
 
+def test_dropout_training_matches_reference(golden_dir):
+    """MODEL.DROP_RATE = 0.2 / ATTN_DROP_RATE = 0.1 in training (blocks/mlp.py:61-66, rope_2d_mhsa.py:497,503): the oracle with
+    the keep masks the reference drew (tiny_drop.npz) against the reference's logits, loss and gradients."""
+    from tests.cases import load_dropout_case
+
+    spec, z, sd, x, meta, masks, ps = load_dropout_case(golden_dir)
+    assert ps == [0.1, 0.2, 0.2, 0.2] * sum(spec.rope_depths)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.forward(sd, spec, x, meta, None, dropout=O.dropout_multipliers_from_masks(masks, ps))
+    for task, _ in spec.heads:
+        np.testing.assert_allclose(out[task].detach().numpy(), z["logits_" + task], rtol=1e-4, atol=2e-5)
+    loss = O.probe_loss(out)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    names = [str(n) for n in z["grad_names"]]
+    for i, k in enumerate(names):
+        ref_norm = z["grad_norms"][i]
+        assert abs(sd[k].grad.double().norm().item() - ref_norm) <= 2e-4 * max(ref_norm, 1e-3), k
+        np.testing.assert_allclose(sd[k].grad.reshape(-1)[:8].numpy(), z["gradslice_" + k], rtol=2e-3, atol=2e-6, err_msg=k)
+    # the masks matter: without them the logits differ
+    with torch.no_grad():
+        plain = O.forward(sd, spec, x, meta, None)
+    assert any(np.abs(plain[t].numpy() - z["logits_" + t]).max() > 1e-3 for t, _ in spec.heads)
+
+
 def test_sm_backward_grad_norms(golden_dir):
     spec, z, sd, x, meta, drops = load_case("sm", golden_dir)
     sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
