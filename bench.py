@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--host-input", action="store_true",
                     help="every step's batch starts in pinned HOST memory and is moved by linnaeus_amd.prefetch.DevicePrefetcher "
                          "(copy stream, two batches in flight): the PCIe-inclusive rate -- reported in DESIGN.md, never the headline")
+    ap.add_argument("--flat-file", action="store_true",
+                    help="with the PCIe-inclusive rate of --host-input, but from the synthetic flat-file reader (linnaeus_amd.flatdata: config 2's "
+                         "'synthetic HDF5' without h5py): memory-mapped uint8 images collated by a background thread, uint8 over PCIe, converted to "
+                         "float NCHW on the device -- reported in DESIGN.md, never the headline")
     ap.add_argument("--eval", action="store_true", help="inference throughput in the reference's throughput_test protocol instead of the training step")
     ap.add_argument("--eval-batches", default="64,128,256,512")
     ap.add_argument("--eval-iters", type=int, default=100)
@@ -293,7 +297,36 @@ def main():
     params = [p_ for p_ in model.parameters() if p_.requires_grad]
 
     feed = None
-    if args.host_input:
+    if args.flat_file:
+        import queue
+        import tempfile
+        import threading
+
+        from linnaeus_amd.aug import u8hwc_to_f32chw
+        from linnaeus_amd.flatdata import FlatBatchLoader, FlatSyntheticDataset, write_synthetic_flat
+        from linnaeus_amd.prefetch import DevicePrefetcher
+
+        path = os.path.join(tempfile.gettempdir(), f"lnx_bench_{os.getpid()}_{rank}.flat")
+        write_synthetic_flat(path, 4 * B, args.img, dict(TASKS), meta=(("TEMPORAL", 2), ("SPATIAL", 3)), seed=42 + rank, null_fraction=0.0)
+        ds = FlatSyntheticDataset(path)
+        q = queue.Queue(maxsize=4)
+
+        def produce():  # the reference's loader workers: read + collate off the training thread
+            for b in FlatBatchLoader(ds, B, shuffle=True, seed=rank, raw_uint8=True, epochs=None):
+                q.put(b)
+
+        threading.Thread(target=produce, daemon=True).start()
+
+        def drain():
+            while True:
+                yield q.get()
+
+        def to_step(it):
+            for raw, onehot, aux, _masks, _gids in it:
+                yield u8hwc_to_f32chw(raw), aux, {t: onehot[t].argmax(-1) for t, _ in TASKS}
+
+        feed = to_step(iter(DevicePrefetcher(drain(), dev)))
+    elif args.host_input:
         from linnaeus_amd.prefetch import DevicePrefetcher
 
         host = [(torch.rand(B, 3, args.img, args.img).pin_memory(), torch.rand(B, 5).pin_memory(),
@@ -462,6 +495,9 @@ def main():
         line["workspace_gb"] = round(model._active["ws"].numel() / 1e9, 2)
     if args.host_input:
         line["config"]["workload"] += "; inputs start in pinned host memory every step (DevicePrefetcher: PCIe-inclusive, NOT the headline)"
+    if args.flat_file:
+        line["config"]["workload"] += ("; inputs read every step from a memory-mapped synthetic flat file by a loader thread, uint8 over PCIe through "
+                                       "DevicePrefetcher, uint8 -> float NCHW on the device (PCIe- and reader-inclusive, NOT the headline)")
     if args.drop_in:
         line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
     sys.stdout.flush()

@@ -388,6 +388,41 @@ int lnx_mix_meta(const float* aux, const unsigned char* mask, const int64_t* per
                  float* out_aux, unsigned char* out_mask, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * GPU-side image augmentations of the input pipeline: the tensor operations of the reference's
+ * GPUAutoAugmentBatch (linnaeus/aug/gpu/autoaug.py:44-168) and GPURandomErasing (aug/gpu/random_erasing.py:24-94), on fp32
+ * [B, C, H, W] batches, each followed by the clamp to [0, 1] the reference applies after every operation; plus the raw-image
+ * conversion of h5data/prefetching_h5_dataset.py:214-220.  Which operation / rectangle is chosen stays on the host (the
+ * Python classes of linnaeus_amd/aug.py draw exactly as the reference does).
+ * -----------------------------------------------------------------------------------*/
+enum {
+    LNX_AUG_CLAMP = 0,
+    LNX_AUG_POSTERIZE = 1,    /* floor(x 255 / p0) p0 / 255, p0 = 2^bits          autoaug.py:117-128 */
+    LNX_AUG_SOLARIZE = 2,     /* x < p0 ? x : 1 - x                               :130-131 */
+    LNX_AUG_SOLARIZE_ADD = 3, /* x < p1 ? clamp(x + p0) : x                       :133-138 */
+    LNX_AUG_INVERT = 4,       /* 1 - x                                            :86 */
+    LNX_AUG_BRIGHTNESS = 5,   /* p0 x (what :83-85 names: adjust_brightness)      */
+    LNX_AUG_CONTRAST = 6      /* p0 x + (1 - p0) s[image] (adjust_contrast, s = mean grey level: lnx_aug_rowstat kind 1) */
+};
+/* in place; per_image_scalar: NULL or a device array with one float per image of `per_image` elements (a multiple of 4) */
+int lnx_aug_pointwise(float* x, int64_t n, int64_t per_image, int op, float p0, float p1, const float* per_image_scalar, void* stream);
+/* in place, three-channel images [B, 3, hw]: c <- clamp(f c + (1 - f) grey)  (Color / Desaturate, autoaug.py:114-115,153-154) */
+int lnx_aug_saturation(float* x, int B, int64_t hw, float factor, void* stream);
+/* kind 0: out[2r], out[2r+1] = min, max of row r of x [rows, cols]; kind 1: out[r] = mean grey level of RGB image r ([rows, 3, cols]) */
+int lnx_aug_rowstat(const float* x, int rows, int64_t cols, int kind, float* out, void* stream);
+/* in place: x[r, :] <- clamp((x - min_r) / (max_r - min_r + 1e-6)), minmax from lnx_aug_rowstat kind 0  (AutoContrast / Equalize, :143-151) */
+int lnx_aug_rescale(float* x, int64_t rows, int64_t cols, const float* minmax, void* stream);
+/* y[., h, w] = x[., round(sy), round(sx)], (sx, sy) = M (w - cx, h - cy) + (cx, cy), M = the host array m6 (2 x 3, output -> source),
+ * nearest neighbour, zero outside: torchvision's affine / rotate on tensors with default interpolation and fill (:52-76) */
+int lnx_aug_affine(const float* x, float* y, int planes, int H, int W, const float* m6, void* stream);
+/* y = clamp(ratio x + (1 - ratio) (x * taps)), taps_dev = device [k, k]; mode 0 reflect padding (GaussianBlurRand, :156-165),
+ * mode 1 borders keep x (Sharpness, :140-141) */
+int lnx_aug_stencil(const float* x, float* y, int planes, int H, int W, const float* taps_dev, int k, int mode, float ratio, void* stream);
+/* rects_dev = device int [n, 5] (image, y0, x0, h, w), values_dev = device float [n, C]: x[image, c, y0:y0+h, x0:x0+w] = value[c] */
+int lnx_erase_rects(float* x, int B, int C, int H, int W, const int* rects_dev, const float* values_dev, int n_rects, void* stream);
+/* raw image batch uint8 [B, H, W, C] -> fp32 [B, C, H, W] / 255 on the device (a quarter of the PCIe bytes of a float batch) */
+int lnx_u8hwc_to_f32chw(const unsigned char* src, float* dst, int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Optimizer + step glue: multi-tensor AdamW with the global-norm clip folded in.
  * Replaces torch.optim.AdamW.step as configured by linnaeus/optimizers/build.py:307-686 (per-group lr / weight
  * decay) and the gradient-norm passes of train.py:282-308 (clip_grad_norm_ semantics:

@@ -109,6 +109,9 @@ def check(rc: int, what: str) -> None:
         raise LnxError(f"{what} failed (rc={rc}): {lib().lnx_last_error().decode()}")
 
 
+# lnx_aug_pointwise operations (include/lnx.h)
+AUG_CLAMP, AUG_POSTERIZE, AUG_SOLARIZE, AUG_SOLARIZE_ADD, AUG_INVERT, AUG_BRIGHTNESS, AUG_CONTRAST = range(7)
+
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus",
@@ -119,6 +122,7 @@ EXPORTS = [
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
+    "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_wgrad", "lnx_convmlp_wgrad_ws_floats",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",

@@ -553,6 +553,96 @@ def collate_known_answers():
     np.savez_compressed(os.path.join(OUT, "collate.npz"), **rec)
 
 
+def aug_known_answers():
+    """SURVEY 8f-3 remainder: outputs of the reference's GPU augmentation classes on CPU tensors, for what of them runs.
+    GPUAutoAugmentBatch._apply_op for Posterize / PosterizeOriginal / PosterizeIncreasing / Solarize / SolarizeAdd / Invert
+    (autoaug.py:86,117-138), the whole __call__ (:88-103, CPU coin flips) on a policy made of those operations, and
+    GPURandomErasing (random_erasing.py:24-94) at B = 1 -- the batch size of its per-sample pipeline and the only one its
+    `torch.randint(0, <tensor>, ...)` accepts -- in all three modes, with the draws it made re-derived from the same seed.  The
+    other AutoAugment operations raise upstream (recorded in `raises`), so there is nothing to record for them."""
+    from linnaeus.aug.gpu.autoaug import GPUAutoAugmentBatch
+    from linnaeus.aug.gpu.random_erasing import GPURandomErasing
+    from oracle import aug_oracle as A
+
+    g = torch.Generator().manual_seed(SEED + 31)
+    img = torch.rand(3, 3, 24, 20, generator=g)
+    rec = {"img": img.numpy()}
+    aa = GPUAutoAugmentBatch("v0r", 0.4)
+    working, raising = [], []
+    for op, mags in (("Posterize", (8, 5)), ("PosterizeOriginal", (7, 6)), ("PosterizeIncreasing", (8, 2, 6)), ("Solarize", (5, 3, 10)), ("SolarizeAdd", (3, 7)),
+                     ("Invert", (4,))):
+        for m in mags:
+            out = aa._apply_op(img.clone(), op, m)
+            rec[f"op_{op}_{m}"] = out.numpy()
+            working.append(f"{op}:{m}")
+    for op in ("ShearX", "ShearY", "TranslateX", "TranslateY", "TranslateYRel", "Rotate", "Color", "Contrast", "Sharpness", "Brightness", "AutoContrast", "Equalize",
+               "Desaturate", "GaussianBlurRand"):
+        try:
+            aa._apply_op(img.clone(), op, 5)
+        except Exception as e:  # AttributeError (torch.nn.functional has no affine / rotate / adjust_* / gaussian_blur) or TypeError (arity)
+            raising.append(f"{op}:{type(e).__name__}")
+    rec["working_ops"] = np.array(working)
+    rec["raising_ops"] = np.array(raising)
+    # pinned restatements
+    for key in working:
+        op, m = key.split(":")
+        mm = int(m) * 0.1
+        want = {"Posterize": lambda: A.posterize(img, mm), "PosterizeOriginal": lambda: A.posterize(img, mm), "PosterizeIncreasing": lambda: A.posterize(img, 8 - mm),
+                "Solarize": lambda: A.solarize(img, mm), "SolarizeAdd": lambda: A.solarize_add(img, mm), "Invert": lambda: A.invert(img)}[op]()
+        assert torch.equal(want, torch.from_numpy(rec[f"op_{op}_{m}"])), key
+    aa.policy = [[("Solarize", 0.6, 5), ("Invert", 0.5, 4)], [("PosterizeIncreasing", 0.7, 6), ("SolarizeAdd", 0.8, 3)], [("Posterize", 0.4, 8), ("Solarize", 0.6, 3)],
+                 [("Invert", 0.2, 1)], [("SolarizeAdd", 0.9, 7), ("PosterizeOriginal", 0.5, 6)]]
+    rec["call_policy"] = np.array([" ".join(f"{o}:{p_}:{m}" for o, p_, m in sub) for sub in aa.policy])
+    for seed in (3, 4, 5):
+        torch.manual_seed(seed)
+        rec[f"call_seed{seed}"] = aa((img * 1.3 - 0.1).clone()).numpy()  # input outside [0, 1]: the initial clamp matters
+    # random erasing, B = 1
+    img1 = torch.rand(1, 3, 40, 36, generator=g)
+    rec["re_img"] = img1.numpy()
+    for mode in ("const", "rand", "pixel"):
+        cfg = {"PROB": 0.9, "AREA_RANGE": [0.02, 0.3], "ASPECT_RATIO": [0.3, 3.3], "COUNT": 2, "MODE": mode}
+        re = GPURandomErasing(cfg)
+        for seed in (11, 12):
+            torch.manual_seed(seed)
+            out = re(img1.clone())
+            # the same draws again (one valid sample: rand(1); per COUNT uniform_, uniform_, randint, randint, uniform_ / randn)
+            torch.manual_seed(seed)
+            H, W = img1.shape[2:]
+            draws = [{"gate": torch.rand(1)}]
+            if float(draws[0]["gate"]) <= cfg["PROB"]:
+                for it in range(cfg["COUNT"]):
+                    d = draws[it] if it == 0 else {}
+                    d["areas"] = torch.empty(1).uniform_(cfg["AREA_RANGE"][0] * H * W, cfg["AREA_RANGE"][1] * H * W)
+                    d["aspects"] = torch.empty(1).uniform_(*cfg["ASPECT_RATIO"])
+                    h = torch.sqrt(d["areas"] * d["aspects"]).round().long()
+                    w = torch.sqrt(d["areas"] / d["aspects"]).round().long()
+                    if bool(((w < W) & (h < H)).any()):
+                        d["x"] = torch.randint(0, int(W - w), (1,))
+                        d["y"] = torch.randint(0, int(H - h), (1,))
+                        d["values"] = torch.randn(1, 3, 1, 1) if mode == "pixel" else torch.empty(1, 3, 1, 1).uniform_(0, 1)
+                    else:
+                        d["x"] = d["y"] = torch.zeros(1, dtype=torch.long)
+                        d["values"] = torch.zeros(1, 3, 1, 1)
+                    if it > 0:
+                        draws.append(d)
+            else:
+                for it in range(cfg["COUNT"]):
+                    d = draws[it] if it == 0 else {}
+                    d.update(areas=torch.ones(1), aspects=torch.ones(1), x=torch.zeros(1, dtype=torch.long), y=torch.zeros(1, dtype=torch.long), values=torch.zeros(1, 3, 1, 1))
+                    if it > 0:
+                        draws.append(d)
+            again = A.random_erasing(img1, draws, cfg)
+            assert torch.equal(again, out), (mode, seed, (again - out).abs().max())
+            rec[f"re_{mode}_{seed}_out"] = out.numpy()
+            rec[f"re_{mode}_{seed}_gate"] = draws[0]["gate"].numpy()
+            for it, d in enumerate(draws):
+                for k in ("areas", "aspects", "x", "y", "values"):
+                    rec[f"re_{mode}_{seed}_{it}_{k}"] = d[k].numpy()
+    rec["re_cfg"] = np.array([0.9, 0.02, 0.3, 0.3, 3.3, 2])
+    print(f"[aug] reference ops that run: {working}; ops that raise upstream: {raising}")
+    np.savez_compressed(os.path.join(OUT, "aug.npz"), **rec)
+
+
 def per_op_known_answers():
     """Small known-answer vectors produced by the reference's own functions/modules."""
     from linnaeus.models.blocks.convnext import ConvNeXtBlock, ConvNeXtDownsampleLayer, LayerNormChannelsFirst
@@ -654,6 +744,8 @@ def main():
         muon_known_answers()
     if want("collate"):
         collate_known_answers()
+    if want("aug"):
+        aug_known_answers()
 
 
 if __name__ == "__main__":

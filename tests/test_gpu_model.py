@@ -249,8 +249,8 @@ def test_large_384_matches_oracle():
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     oout = O.forward(osd, spec, x, meta)
     O.probe_loss(oout).backward()
-    # bf16 bounds = 3x the measured error (the measured values are printed), not a loose 0.10
-    for dtype, ftol, gtol in (("fp32", 2e-4, 2e-3), ("bf16", 0.04, 0.05)):
+    # bf16 bounds = 3x the measured error (0.005 of the logit scale, 0.0084 of the gradient norm; both printed), not a loose 0.10
+    for dtype, ftol, gtol in (("fp32", 2e-4, 2e-3), ("bf16", 0.015, 0.025)):
         model.set_compute_dtype(dtype)
         model.train()
         model.zero_grad()
