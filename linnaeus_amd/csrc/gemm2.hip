@@ -467,6 +467,18 @@ static bool nt_v5_preferred(const GemmP& p, int f, bool out_f32) {
     return false;
 }
 
+// default choice (LNX_NT_V7 unset): from the measurements of tools/bench_gemm_epi.py
+// Measured (profiles/r03_nt_v7.log, sm shapes at B = 256): against the one-shot 256x128 kernel the persistent kernel wins
+// 10-30 % when it has at least two tiles per CU (no pipeline refill per tile, stores spread over the K loop) and the epilogue is
+// light (plain / bias / fp32 residual); it ties with the 256x256 kernel where that one applies (N % 256 == 0) and with the GELU
+// forms (their epilogue arithmetic, not their stores, is what the K loop waits for), and loses a few percent below two tiles
+// per CU.
+static bool nt_v7_preferred(const GemmP& p, int f, bool out_f32) {
+    if (f != 0 && f != F_BIAS && !(out_f32 && f == (F_BIAS | F_RES))) return false;
+    if (p.N % BN4 == 0) return false;  // the 256x256 tile (half the fill traffic per FLOP) is the better kernel there
+    return (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 512;
+}
+
 static bool nt_v4_ok(const GemmP& p, int f) {
     static const bool off = getenv("LNX_NT_V4") && atoi(getenv("LNX_NT_V4")) == 0;  // A/B switch for benchmarking
     if (off || f == (int)F_GENERIC || p.a_mode == LNX_ADDR_PATCH2) return false;
@@ -489,6 +501,12 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     const bool patch = p.a_mode == LNX_ADDR_PATCH2;
     static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
     const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+    // LNX_NT_V7: 1 = every shape the persistent deferred-store kernel can run, 0 = never, unset = the measured choice
+    {
+        const char* e7 = getenv("LNX_NT_V7");
+        const int v7 = e7 ? atoi(e7) : -1;
+        if (v7 != 0 && nt_v7_ok(p, f, out_f32) && (v7 == 1 || nt_v7_preferred(p, f, out_f32))) return launch_nt_v7(p, f, out_f32, st);
+    }
     const int v5 = nt_v5_mode();
     if (v5 != 0 && nt_v5_ok(p, f) && (v5 == 1 || nt_v5_preferred(p, f, out_f32))) {
         p.tiles_m = cdiv(p.M, BM5);

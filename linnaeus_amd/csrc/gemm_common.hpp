@@ -425,6 +425,10 @@ struct WgradP {
     int tiles_n, tiles_k, splits, m_per_split;
 };
 
+// gemm3.hip: persistent 256x128 kernel whose epilogue stores / fetches ride under the next tile's K loop
+bool nt_v7_ok(const GemmP& p, int f, bool out_f32);
+int launch_nt_v7(const GemmP& p, int f, bool out_f32, hipStream_t st);
+
 // gemm2.hip: 256x128 LDS-DMA pipelined kernels (bf16)
 int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);
 bool nt_v2_ok(const GemmP& p, int dtype);

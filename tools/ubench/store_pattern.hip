@@ -4,6 +4,8 @@
 //      (adjacent lanes = different rows; an instruction touches 16 rows x 4 pieces of 16 B at a 32-B stride)
 //   B  row-contiguous: instruction i covers rows 8 i .. 8 i + 7, 8 lanes x 16 B = the row's 128 B
 //   C  quad-contiguous: 4 adjacent lanes = 64 contiguous bytes, 16 rows per instruction
+//   D  the rows of A, but the 4 lanes that share a row (lanes s, s+16, s+32, s+48 -- NOT adjacent) write 64 contiguous bytes per
+//      instruction: what a 4x4 exchange of 16-byte pieces between those lanes (v_permlane16/32_swap) turns pattern A into
 // mode 0 = stores, 1 = loads (summed into a dummy), 2 = load + store (copy in place).
 // Build: hipcc -O3 --offload-arch=gfx950 store_pattern.hip -o store_pattern
 #include <hip/hip_runtime.h>
@@ -28,9 +30,12 @@ __global__ __launch_bounds__(512) void k(unsigned char* buf, int M, int N, int t
         } else if (PAT == 1) {
             row = 8 * i + (lane >> 3);
             colb = (lane & 7) * 16;
-        } else {
+        } else if (PAT == 2) {
             row = (lane >> 2) + 16 * (i >> 1);
             colb = (lane & 3) * 16 + (i & 1) * 64;
+        } else {
+            row = (s >> 2) * 16 + (s & 3) + 4 * (i >> 1);
+            colb = g * 16 + (i & 1) * 64;
         }
         int m = m0 + row;
         if (m >= M) m = M - 1;
@@ -49,9 +54,12 @@ __global__ __launch_bounds__(512) void k(unsigned char* buf, int M, int N, int t
             } else if (PAT == 1) {
                 row = 8 * i + (lane >> 3);
                 colb = (lane & 7) * 16;
-            } else {
+            } else if (PAT == 2) {
                 row = (lane >> 2) + 16 * (i >> 1);
                 colb = (lane & 3) * 16 + (i & 1) * 64;
+            } else {
+                row = (s >> 2) * 16 + (s & 3) + 4 * (i >> 1);
+                colb = g * 16 + (i & 1) * 64;
             }
             const int m = m0 + row;
             if (m < M) *reinterpret_cast<uint4*>(buf + ((size_t)m * N + n0) * 2 + colb) = v[i];
@@ -78,7 +86,7 @@ static void run(unsigned char* buf, int M, int N, unsigned* sink) {
         if (ms / 10 < best) best = ms / 10;
     }
     const double bytes = (double)M * N * 2 * (MODE == 2 ? 2 : 1);
-    printf("pattern %c mode %s  M=%d N=%d: %7.1f us  %5.2f TB/s\n", "ABC"[PAT], MODE == 0 ? "store" : MODE == 1 ? "load " : "copy ", M, N, best * 1e3,
+    printf("pattern %c mode %s  M=%d N=%d: %7.1f us  %5.2f TB/s\n", "ABCD"[PAT], MODE == 0 ? "store" : MODE == 1 ? "load " : "copy ", M, N, best * 1e3,
            bytes / (best * 1e-3) / 1e12);
 }
 
@@ -89,16 +97,19 @@ int main() {
     hipMalloc(&buf, (size_t)M * 3072 * 2);
     hipMalloc(&sink, 4);
     hipMemset(buf, 1, (size_t)M * 3072 * 2);
-    for (int N : {384, 1536}) {
+    for (int N : {384, 768, 1536}) {
         run<0, 0>(buf, M, N, sink);
         run<1, 0>(buf, M, N, sink);
         run<2, 0>(buf, M, N, sink);
+        run<3, 0>(buf, M, N, sink);
         run<0, 1>(buf, M, N, sink);
         run<1, 1>(buf, M, N, sink);
         run<2, 1>(buf, M, N, sink);
+        run<3, 1>(buf, M, N, sink);
         run<0, 2>(buf, M, N, sink);
         run<1, 2>(buf, M, N, sink);
         run<2, 2>(buf, M, N, sink);
+        run<3, 2>(buf, M, N, sink);
     }
     return 0;
 }
