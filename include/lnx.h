@@ -43,7 +43,12 @@ typedef struct lnx_rowmap {
  *   fc1/fc2 blocks/mlp.py:36-39; stem/downsample convs mFormerV1.py:146, convnext.py:110;
  *   heads heads/linear_head.py:27; meta heads mFormerV1.py:291-306.
  * -----------------------------------------------------------------------------------*/
-enum { LNX_ACT_NONE = 0, LNX_ACT_GELU = 1, LNX_ACT_RELU = 2, LNX_ACT_GELU_BWD = 3, LNX_ACT_RELU_BWD = 4 };
+enum { LNX_ACT_NONE = 0, LNX_ACT_GELU = 1, LNX_ACT_RELU = 2, LNX_ACT_GELU_BWD = 3, LNX_ACT_RELU_BWD = 4,
+       /* round 3: the derivative is evaluated ONCE, in the forward, where the pre-activation is at hand in fp32 (the polynomial erf
+        * and the exponential are the dominant VALU cost of both epilogues; the backward GEMM's becomes one multiply):
+        * GELU_D   forward:  C = GELU(v) and c2 = GELU'(v) (instead of v)           -- c2 is required
+        * MUL_AUX  backward: v *= aux                                               -- aux = that c2 */
+       LNX_ACT_GELU_D = 5, LNX_ACT_MUL_AUX = 6 };
 enum { LNX_ADDR_PLAIN = 0, LNX_ADDR_PATCH2 = 1 };
 
 typedef struct lnx_gemm_args {
@@ -238,11 +243,11 @@ int lnx_dwconv7_wgrad(const lnx_dwconv_wgrad_args* args, void* stream);
  * sample are extra (CLS/meta) tokens and are not scaled by cos.
  * -----------------------------------------------------------------------------------*/
 int lnx_rope_cos_table(const float* freqs /* [2,heads,32] */, int heads, int H, int W, float* cos_out /* [H*W,heads,32] */,
+                       float* dsin_out /* optional [2][H*W,heads,32]: -t_x sin(theta), -t_y sin(theta) = d cos(theta) / d freqs[a] (what
+                                          lnx_attn_bwd weights its pair gradients with) */,
                        void* stream);
-/* dfreqs[2,heads,32] += sum_n t_{x,y}[n] * (-sin(theta[n,h,j])) * sum_b (gcos_q + gcos_k)[b,n,h,j]
- * where gcos is the [2][B, H*W, heads, 32] workspace lnx_attn_bwd filled (autograd of
- * compute_mixed_cis / apply_rotary_emb through the real part only, finding F1) */
-int lnx_rope_freqs_bwd(const float* freqs, const float* gcos, int B, int heads, int H, int W, float* dfreqs, void* stream);
+/* floats of lnx_attn_bwd's freqs-gradient workspace (one [2][32] partial per workgroup of its finest tiling) */
+int64_t lnx_attn_bwd_ws_floats(int B, int N, int heads);
 
 typedef struct lnx_attn_args {
     int dtype;
@@ -268,10 +273,15 @@ typedef struct lnx_attn_bwd_args {
     const float* lse;
     const void* d_o;     /* [B*N, heads*64] */
     void* dqkv;          /* [B*N, 3*heads*64] */
-    float* gcos;         /* workspace [2][B, N-E, heads, 32]: per-sample cos gradients of q and k (overwritten) */
+    float* freq_ws;      /* workspace, lnx_attn_bwd_ws_floats(B, N, heads) floats (overwritten): round 3 -- the gradient of the learnable
+                            frequencies (autograd of compute_mixed_cis / apply_rotary_emb through the real part only, finding F1) is
+                            reduced inside the two backward kernels to one [2][32] partial per workgroup; it used to be a
+                            [2][B, N-E, heads, 32] tensor read back by a separate lnx_rope_freqs_bwd */
     float* delta;        /* workspace [B, heads, N] */
     const unsigned char* drop_mask; /* the forward's keep mask (see lnx_attn_args), or NULL */
     float drop_inv_keep;
+    const float* dsin_tab; /* [2][(N-E), heads, 32] from lnx_rope_cos_table */
+    float* dfreqs;         /* [2, heads, 32] fp32, accumulated into (dfreqs += ...) */
 } lnx_attn_bwd_args;
 int lnx_attn_bwd(const lnx_attn_bwd_args* args, void* stream);
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LNX_LIB_PATH") or os.path.join(_HERE, "liblnx_hip.so")  # override: A/B runs against another build
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_GELU_BWD, ACT_RELU_BWD, ACT_GELU_D, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 TN_WS_FLOATS = 256 * (256 * 128 + 256)  # == LNX_TN_WS_FLOATS
 ADDR_PLAIN, ADDR_PATCH2 = 0, 1
 
@@ -118,7 +118,7 @@ EXPORTS = [
     "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
-    "lnx_rope_cos_table", "lnx_rope_freqs_bwd", "lnx_attn_fwd", "lnx_attn_bwd",
+    "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
@@ -184,8 +184,9 @@ class AttnBwdArgs(C.Structure):
     _fields_ = [
         ("dtype", C.c_int), ("B", C.c_int), ("N", C.c_int), ("E", C.c_int), ("heads", C.c_int),
         ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
-        ("d_o", C.c_void_p), ("dqkv", C.c_void_p), ("gcos", C.c_void_p), ("delta", C.c_void_p),
+        ("d_o", C.c_void_p), ("dqkv", C.c_void_p), ("freq_ws", C.c_void_p), ("delta", C.c_void_p),
         ("drop_mask", C.c_void_p), ("drop_inv_keep", C.c_float),
+        ("dsin_tab", C.c_void_p), ("dfreqs", C.c_void_p),
     ]
 
 

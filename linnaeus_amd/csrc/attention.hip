@@ -233,6 +233,45 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// sum over the 16 lanes of a DPP row (lanes s = 0..15 of one g): every lane ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    return v;
+}
+
+// Gradient of the learnable RoPE frequencies, reduced where it is produced (round 3; it used to travel through a
+// [2][B, N-E, heads, 32] fp32 tensor, ~66 MB per block, written 4 bytes at a time and read back by a separate kernel).
+// Autograd of compute_mixed_cis / apply_rotary_emb through the real part only (finding F1):
+//   dfreqs[a, h, j] = sum_{b, n} (d cos(theta[n,h,j]) / d freqs[a,h,j]) * gpair[b, n, h, j],   gpair = dQ~[2j] q[2j] + dQ~[2j+1] q[2j+1] (+ the k term)
+// This lane holds the 8 pair gradients gp[dt][pr] (j = 8 dt + 2 g + pr) of ONE row and the matching table entries
+// dx / dy = -t_x sin(theta), -t_y sin(theta); rows are summed over the 16 lanes of the DPP row, then added to the
+// workgroup's 64 LDS accumulators [a][j] (order of the LDS float adds is not fixed: last-bit differences from run to run).
+__device__ __forceinline__ void freq_accum(float* fl, const float (&gp)[4][2], const float (&dx)[4][2], const float (&dy)[4][2], int s, int g) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const float tx = row16_sum(gp[dt][pr] * dx[dt][pr]);
+            const float ty = row16_sum(gp[dt][pr] * dy[dt][pr]);
+            if (s == 0) {
+                const int j = 8 * dt + 2 * g + pr;
+                atomicAdd(fl + j, tx);
+                atomicAdd(fl + 32 + j, ty);
+            }
+        }
+}
+// after the workgroup's last freq_accum: publish (dq kernel) or add to (dk/dv kernel, same grid, launched after it) the partial
+template <bool ADD> __device__ __forceinline__ void freq_flush(const float* fl, float* fpart) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float* dst = fpart + (int64_t)blockIdx.x * 64 + threadIdx.x;
+        *dst = ADD ? *dst + fl[threadIdx.x] : fl[threadIdx.x];
+    }
+}
+
 // exp of the softmax: the bf16 kernels use the hardware exponential (v_exp_f32, ~1 ulp), the fp32 (strict-parity) ones libm's
 template <typename T> __device__ __forceinline__ float fexp(float x) {
     if constexpr (sizeof(T) == 2) return __expf(x);
@@ -246,7 +285,8 @@ struct AttnP {
     float* lse;
     const void* d_o;
     void* dqkv;
-    float* gcos;   // [2][B, N-E, heads, 32]
+    float* fpart;        // [workgroups][2][32]: per-workgroup partial sums of the freqs gradient (dq kernel writes, dk/dv kernel adds)
+    const float* dsin;   // [2][N-E, heads, 32]: -t_x sin(theta), -t_y sin(theta) = d cos(theta) / d freqs[a]
     float* delta;
     int B, N, E, heads;
     int qtiles;
@@ -369,6 +409,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
     const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
 
+    __shared__ float fl[64];  // this workgroup's freqs-gradient partial [a][j]; zeroed here, published behind the loop's barriers
+    if (threadIdx.x < 64) fl[threadIdx.x] = 0.f;
     const int q = qt * (16 * NW) + wave * 16 + s;
     uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
     load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
@@ -423,13 +465,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
             }
         imgT_times_regs<T>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
     }
-    if (q < p.N) {
-        // dq = dQ~ * cos * scale ; gcos_q[b, n, head, j] = scale * (dQ~[2j] q[2j] + dQ~[2j+1] q[2j+1])
-        T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
-        const T* qraw = qb + (int64_t)q * ld;
-        const bool img = q >= p.E;
-        const float* cp = img ? p.cos_tab + ((int64_t)(q - p.E) * p.heads + head) * 32 : nullptr;
-        float* gq = img ? p.gcos + (((int64_t)b * (p.N - p.E) + (q - p.E)) * p.heads + head) * 32 : nullptr;
+    {
+        // dq = dQ~ * cos * scale ; pair gradient of the cos factor: scale * (dQ~[2j] q[2j] + dQ~[2j+1] q[2j+1])
+        const bool row = q < p.N, img = row && q >= p.E;
+        const int qc = min(q, p.N - 1), ni = max(qc - p.E, 0);
+        T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
+        const T* qraw = qb + (int64_t)qc * ld;
+        const float* cp = p.cos_tab + ((int64_t)ni * p.heads + head) * 32;
+        const float* sx = p.dsin + ((int64_t)ni * p.heads + head) * 32;
+        const float* sy = sx + (int64_t)(p.N - p.E) * p.heads * 32;
+        float gp[4][2], dx[4][2], dy[4][2];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = dt * 16 + 4 * g;
@@ -438,12 +483,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
                 const int d = d0 + 2 * pr;
                 const float c = img ? cp[d >> 1] : 1.0f;
                 const float g0 = dq[dt][2 * pr], g1 = dq[dt][2 * pr + 1];
-                dqp[d] = from_f<T>(g0 * c * scale);
-                dqp[d + 1] = from_f<T>(g1 * c * scale);
-                if (img) gq[d >> 1] = scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1]));
+                if (row) {
+                    dqp[d] = from_f<T>(g0 * c * scale);
+                    dqp[d + 1] = from_f<T>(g1 * c * scale);
+                }
+                gp[dt][pr] = img ? scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1])) : 0.f;
+                dx[dt][pr] = img ? sx[d >> 1] : 0.f;
+                dy[dt][pr] = img ? sy[d >> 1] : 0.f;
             }
         }
+        if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
     }
+    if (p.E < p.N) freq_flush<false>(fl, p.fpart);
 }
 
 // ---------------------------------------------------------------------------------
@@ -475,6 +526,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
     const float scale = 0.125f;
     const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
 
+    __shared__ float fl[64];
+    if (threadIdx.x < 64) fl[threadIdx.x] = 0.f;
     const int key = ktile * (16 * NW) + wave * 16 + s;
     uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
     load_row_frag<T, true>(kf, kb, ld, key, p.N, p.E, g, p.cos_tab, p.heads, head, 1.0f);
@@ -517,13 +570,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
         imgT_times_regs<T>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
         imgT_times_regs<T>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
     }
-    if (key < p.N) {
-        T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
+    {
+        const bool row = key < p.N, img = row && key >= p.E;
+        const int kc = min(key, p.N - 1), ni = max(kc - p.E, 0);
+        T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
         T* dvp = dkp + C;
-        const T* kraw = kb + (int64_t)key * ld;
-        const bool img = key >= p.E;
-        const float* cp = img ? p.cos_tab + ((int64_t)(key - p.E) * p.heads + head) * 32 : nullptr;
-        float* gk = img ? p.gcos + (int64_t)p.B * (p.N - p.E) * p.heads * 32 + (((int64_t)b * (p.N - p.E) + (key - p.E)) * p.heads + head) * 32 : nullptr;
+        const T* kraw = kb + (int64_t)kc * ld;
+        const float* cp = p.cos_tab + ((int64_t)ni * p.heads + head) * 32;
+        const float* sx = p.dsin + ((int64_t)ni * p.heads + head) * 32;
+        const float* sy = sx + (int64_t)(p.N - p.E) * p.heads * 32;
+        float gp[4][2], dx[4][2], dy[4][2];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = dt * 16 + 4 * g;
@@ -532,14 +588,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
                 const int d = d0 + 2 * pq;
                 const float c = img ? cp[d >> 1] : 1.0f;
                 const float g0 = dk[dt][2 * pq], g1 = dk[dt][2 * pq + 1];
-                dkp[d] = from_f<T>(g0 * c);
-                dkp[d + 1] = from_f<T>(g1 * c);
-                dvp[d] = from_f<T>(dv[dt][2 * pq]);
-                dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
-                if (img) gk[d >> 1] = g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]);
+                if (row) {
+                    dkp[d] = from_f<T>(g0 * c);
+                    dkp[d + 1] = from_f<T>(g1 * c);
+                    dvp[d] = from_f<T>(dv[dt][2 * pq]);
+                    dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
+                }
+                gp[dt][pq] = img ? g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]) : 0.f;
+                dx[dt][pq] = img ? sx[d >> 1] : 0.f;
+                dy[dt][pq] = img ? sy[d >> 1] : 0.f;
             }
         }
+        if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
     }
+    if (p.E < p.N) freq_flush<true>(fl, p.fpart);
 }
 
 // ---------------------------------------------------------------------------------
@@ -666,6 +728,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
     const T* ob = reinterpret_cast<const T*>(p.o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
+    __shared__ float fl[64];  // freqs-gradient partial of this (sample, head)
+    if (threadIdx.x < 64) fl[threadIdx.x] = 0.f;
     stage_all<T, true, false, true>(nullptr, kimg, kb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
     stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
@@ -742,22 +806,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             imgT_times_regs<T>(dq, kimg + kt * BT * AT<T>::TRB, s, g, ds, nt);
         }
-        if (q < p.N) {
-            T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + q) * ld + head * HD;
-            const bool img = q >= p.E;
-            float* gq = img ? p.gcos + (((int64_t)b * (p.N - p.E) + (q - p.E)) * p.heads + head) * 32 : nullptr;
+        {
+            // the d cos / d freqs table entries of this row: fetched here (after the key loop: held across it they would spill)
+            const float* sxp = p.dsin + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
+            const float* syp = sxp + (int64_t)(p.N - p.E) * p.heads * 32;
+            float gp[4][2], dx[4][2], dy[4][2];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const float2 a = *reinterpret_cast<const float2*>(sxp + ((dt * 16 + 4 * g) >> 1));
+                const float2 c = *reinterpret_cast<const float2*>(syp + ((dt * 16 + 4 * g) >> 1));
+                dx[dt][0] = a.x; dx[dt][1] = a.y;
+                dy[dt][0] = c.x; dy[dt][1] = c.y;
+            }
+            const bool row = q < p.N, img = row && q >= p.E;
+            T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
                 const float c0 = img ? cr[dt][0] * scale : scale, c1 = img ? cr[dt][1] * scale : scale;
-                store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
-                if (img) {
-                    gq[d0 >> 1] = scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]);
-                    gq[(d0 >> 1) + 1] = scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]);
-                }
+                if (row) store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
+                gp[dt][0] = img ? scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]) : 0.f;
+                gp[dt][1] = img ? scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]) : 0.f;
             }
+            if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
         }
     }
+    if (p.E < p.N) freq_flush<false>(fl, p.fpart);
 }
 
 // Diagnostic build only (-DATT_STAMP, tools/build_stamp.sh): per-phase s_memtime sums of wave 0 of one workgroup
@@ -793,6 +867,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const T* dob = reinterpret_cast<const T*>(p.d_o) + (int64_t)b * p.N * C + head * HD;
     const float scale = 0.125f;
     const int64_t statbase = ((int64_t)b * p.heads + head) * p.N;
+    __shared__ float fl[64];  // freqs-gradient partial of this (sample, head)
+    if (threadIdx.x < 64) fl[threadIdx.x] = 0.f;
     stage_all<T, true, false, true>(nullptr, qimg, qb, ld, npad, p.N, p.E, p.cos_tab, p.heads, head, scale);
     stage_all<T, false, false, true>(nullptr, doimg, dob, C, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     ATT_T(0);
@@ -851,7 +927,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // raw k values and cos factors of the epilogue: one batch of loads here (held across the query loop they spill)
         const T* kraw = kb + (int64_t)kc * ld;
         const float* cpr = p.cos_tab + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
-        float kr[4][4], cr[4][2];
+        const float* sxp = p.dsin + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
+        const float* syp = sxp + (int64_t)(p.N - p.E) * p.heads * 32;
+        float kr[4][4], cr[4][2], gp[4][2], dx[4][2], dy[4][2];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const int d0 = dt * 16 + 4 * g;
@@ -866,26 +944,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
             cr[dt][0] = c2.x; cr[dt][1] = c2.y;
+            const float2 a2 = *reinterpret_cast<const float2*>(sxp + (d0 >> 1));
+            const float2 b2 = *reinterpret_cast<const float2*>(syp + (d0 >> 1));
+            dx[dt][0] = a2.x; dx[dt][1] = a2.y;
+            dy[dt][0] = b2.x; dy[dt][1] = b2.y;
         }
-        if (key < p.N) {
-            T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + key) * ld + C + head * HD;
+        {
+            const bool row = key < p.N, img = row && key >= p.E;
+            T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
             T* dvp = dkp + C;
-            const bool img = key >= p.E;
-            float* gk = img ? p.gcos + (int64_t)p.B * (p.N - p.E) * p.heads * 32 + (((int64_t)b * (p.N - p.E) + (key - p.E)) * p.heads + head) * 32 : nullptr;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int d0 = dt * 16 + 4 * g;
                 const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
-                store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
-                store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-                if (img) {
-                    gk[d0 >> 1] = dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1];
-                    gk[(d0 >> 1) + 1] = dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3];
+                if (row) {
+                    store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
+                    store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
                 }
+                gp[dt][0] = img ? dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1] : 0.f;
+                gp[dt][1] = img ? dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3] : 0.f;
             }
+            if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
         }
         ATT_T(4);
     }
+    if (p.E < p.N) freq_flush<true>(fl, p.fpart);
 #ifdef ATT_STAMP
     if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
         for (int i = 0; i < 8; ++i) g_att_stamp[i] = tsum[i];
@@ -898,7 +981,8 @@ extern "C" int lnx_dbg_attn_stamps(unsigned long long* out8) { return (int)hipMe
 // ---------------------------------------------------------------------------------
 // cos table and its backward to the learnable freqs
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out,
+                                                       float* __restrict__ dsin) {
     const int total = H * W * heads * 32;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -910,34 +994,41 @@ __global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__
     // rope_2d_mhsa.py:136-142) -- keep them un-fused so the angle matches the reference bit for bit
     const float ax = __fmul_rn(tx, freqs[h * 32 + j]);
     const float ay = __fmul_rn(ty, freqs[(heads + h) * 32 + j]);
-    out[i] = cosf(__fadd_rn(ax, ay));
+    const float th = __fadd_rn(ax, ay);
+    out[i] = cosf(th);
+    if (dsin) {  // d cos(theta) / d freqs[a, h, j] = -t_a sin(theta): what the attention backward weights its pair gradients with
+        const float ms = -sinf(th);
+        dsin[i] = tx * ms;
+        dsin[total + i] = ty * ms;
+    }
 }
 
-// dfreqs[a,h,j] += sum_n t_a[n] * (-sin theta) * sum_b (gq + gk)[b,n,h,j]
-// one workgroup per (n, head): 32 columns x 8 batch slices
-__global__ __launch_bounds__(256) void rope_freqs_bwd_kernel(const float* __restrict__ freqs, const float* __restrict__ gcos, int B, int heads, int H, int W,
-                                                             float* __restrict__ dfreqs) {
-    __shared__ float red[8][32];
-    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int NI = H * W;
-    const int64_t half = (int64_t)B * NI * heads * 32;
-    float acc = 0.f;
-    for (int b = sl; b < B; b += 8) {
-        const int64_t off = (((int64_t)b * NI + n) * heads + h) * 32 + j;
-        acc += gcos[off] + gcos[half + off];
+// dfreqs[a, h, j] += sum over the workgroups of head h of their partial [a][j]   (fixed order: deterministic given the partials)
+// one 1024-thread workgroup per head: 16 slices of the partial list x 64 entries, four loads in flight per thread, LDS tree
+__global__ __launch_bounds__(1024) void rope_freqs_reduce_kernel(const float* __restrict__ fpart, int B, int heads, int per_bh, float* __restrict__ dfreqs) {
+    __shared__ float red[16][64];
+    const int h = blockIdx.x, t = threadIdx.x & 63, sl = threadIdx.x >> 6;  // t = a * 32 + j
+    const int n = B * per_bh;  // partials of this head: (b, k) -> ((b * heads + h) * per_bh + k)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    auto at = [&](int i) -> float {
+        const int ii = min(i, n - 1);
+        const int b = ii / per_bh, k = ii - b * per_bh;
+        const float v = fpart[(((int64_t)b * heads + h) * per_bh + k) * 64 + t];
+        return i < n ? v : 0.f;
+    };
+    for (int i = sl; i < n; i += 64) {
+        a0 += at(i);
+        a1 += at(i + 16);
+        a2 += at(i + 32);
+        a3 += at(i + 48);
     }
-    red[sl][j] = acc;
+    red[sl][t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (sl == 0) {
-        float t = 0.f;
+        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][j];
-        const float tx = (float)(n % W), ty = (float)(n / W);
-        const float th = __fadd_rn(__fmul_rn(tx, freqs[h * 32 + j]), __fmul_rn(ty, freqs[(heads + h) * 32 + j]));
-        const float dth = -sinf(th) * t;
-        atomicAdd(dfreqs + h * 32 + j, tx * dth);
-        atomicAdd(dfreqs + (heads + h) * 32 + j, ty * dth);
+        for (int k = 0; k < 16; ++k) acc += red[k][t];
+        dfreqs[((t >> 5) * heads + h) * 32 + (t & 31)] += acc;
     }
 }
 
@@ -953,20 +1044,16 @@ int check_attn(int dtype, int B, int N, int E, int heads, const char* who) {
 
 }  // namespace
 
-extern "C" int lnx_rope_cos_table(const float* freqs, int heads, int H, int W, float* cos_out, void* stream) {
+extern "C" int lnx_rope_cos_table(const float* freqs, int heads, int H, int W, float* cos_out, float* dsin_out, void* stream) {
     LNX_CHECK(freqs && cos_out && heads > 0 && H > 0 && W > 0, "lnx_rope_cos_table: bad arguments");
     const int total = H * W * heads * 32;
-    hipLaunchKernelGGL(rope_cos_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, freqs, heads, H, W, cos_out);
+    hipLaunchKernelGGL(rope_cos_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, freqs, heads, H, W, cos_out, dsin_out);
     LNX_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int lnx_rope_freqs_bwd(const float* freqs, const float* gcos, int B, int heads, int H, int W, float* dfreqs, void* stream) {
-    LNX_CHECK(freqs && gcos && dfreqs && B > 0 && heads > 0 && H > 0 && W > 0, "lnx_rope_freqs_bwd: bad arguments");
-    hipLaunchKernelGGL(rope_freqs_bwd_kernel, dim3(H * W * heads), dim3(256), 0, (hipStream_t)stream, freqs, gcos, B, heads, H, W, dfreqs);
-    LNX_LAUNCH_CHECK();
-    return 0;
-}
+// floats of lnx_attn_bwd's freqs-gradient workspace: one [2][32] partial per workgroup of its finest tiling
+extern "C" int64_t lnx_attn_bwd_ws_floats(int B, int N, int heads) { return (int64_t)B * heads * cdiv(N, BT) * 64; }
 
 // tiled bf16 kernels: 8 waves (128 rows) per workgroup for sequences beyond the resident kernels' reach, where every staged
 // tile is then shared by twice the rows; 4 waves for short ones (more workgroups) and with LNX_ATTN_NW=4 (A/B switch)
@@ -1025,14 +1112,18 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
 extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     LNX_CHECK(a && a->qkv && a->o && a->lse && a->d_o && a->dqkv && a->delta, "lnx_attn_bwd: null operand");
     if (check_attn(a->dtype, a->B, a->N, a->E, a->heads, "lnx_attn_bwd")) return 1;
-    LNX_CHECK(a->E == a->N || (a->cos_tab && a->gcos), "lnx_attn_bwd: cos table / gcos workspace missing");
+    LNX_CHECK(a->E == a->N || (a->cos_tab && a->dsin_tab && a->freq_ws && a->dfreqs), "lnx_attn_bwd: cos / d-cos tables, freqs-gradient workspace or dfreqs missing");
     AttnP p{};
     p.qkv = a->qkv; p.cos_tab = a->cos_tab; p.o = const_cast<void*>(a->o); p.lse = const_cast<float*>(a->lse);
-    p.d_o = a->d_o; p.dqkv = a->dqkv; p.gcos = a->gcos; p.delta = a->delta;
+    p.d_o = a->d_o; p.dqkv = a->dqkv; p.fpart = a->freq_ws; p.dsin = a->dsin_tab; p.delta = a->delta;
     p.B = a->B; p.N = a->N; p.E = a->E; p.heads = a->heads;
     p.qtiles = cdiv(a->N, BT);
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
+    // after the two kernels: the per-workgroup partials of the freqs gradient -> dfreqs (per_bh = workgroups per (sample, head))
+    auto reduce_freqs = [&](int per_bh) {
+        if (a->E < a->N) hipLaunchKernelGGL(rope_freqs_reduce_kernel, dim3(a->heads), dim3(1024), 0, st, p.fpart, a->B, a->heads, per_bh, a->dfreqs);
+    };
     if (a->drop_mask) {
         LNX_CHECK(a->drop_inv_keep >= 1.0f && (((uintptr_t)a->drop_mask) & 3) == 0, "lnx_attn_bwd: drop_inv_keep >= 1 and a 4-byte aligned mask");
         p.amask = a->drop_mask; p.a_inv_keep = a->drop_inv_keep; p.Np = p.qtiles * BT;
@@ -1051,6 +1142,7 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
             hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 4, true>), dim3(grid), dim3(256), 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG, st, p);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 4, true>), dim3(grid), dim3(256), lds_k, st, p);
         }
+        reduce_freqs(p.qtiles);
         LNX_LAUNCH_CHECK();
         return 0;
     }
@@ -1067,6 +1159,7 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
         }
         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_q, st, p);
         hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_k, st, p);
+        reduce_freqs(1);
     } else if (a->dtype == LNX_BF16) {
         typedef bf16_t T;
         const size_t lds_q = 2 * AT<T>::ROW_IMG + AT<T>::TR_IMG;
@@ -1076,9 +1169,11 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
             const int g8 = a->B * a->heads * p.qtiles;
             hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 8>), dim3(g8), dim3(512), lds_q, st, p);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 8>), dim3(g8), dim3(512), lds_k, st, p);
+            reduce_freqs(p.qtiles);
         } else {
             hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+            reduce_freqs(p.qtiles);
         }
     } else {
         typedef float T;
@@ -1091,6 +1186,7 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
         }
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(grid), dim3(256), lds_q, st, p);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(grid), dim3(256), lds_k, st, p);
+        reduce_freqs(p.qtiles);
     }
     LNX_LAUNCH_CHECK();
     return 0;

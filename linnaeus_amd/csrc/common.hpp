@@ -258,6 +258,14 @@ template <typename T> struct Gelu {
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(x[j]);
     }
+    // v <- GELU(v), d <- GELU'(v)
+    static __device__ __forceinline__ void fwd_grad16(float (&v)[16], float (&d)[16]) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d[j] = gelu_grad_f(v[j]);
+            v[j] = gelu_f(v[j]);
+        }
+    }
     static __device__ __forceinline__ float fwd(float x) { return gelu_f(x); }
     static __device__ __forceinline__ float grad(float x) { return gelu_grad_f(x); }
 };
@@ -287,6 +295,22 @@ template <> struct Gelu<bf16_t> {
             for (int i = 0; i < 4; ++i) {
                 v[g + 2 * i] *= d[i].x;
                 v[g + 2 * i + 1] *= d[i].y;
+            }
+        }
+    }
+    static __device__ __forceinline__ void fwd_grad16(float (&v)[16], float (&d)[16]) {
+#pragma unroll
+        for (int g = 0; g < 16; g += 8) {
+            f32x2_t xx[4], a[4], dd[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xx[i] = f32x2_t{v[g + 2 * i], v[g + 2 * i + 1]};
+            gelu_lean_grad2_n<4>(xx, a, dd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[g + 2 * i] = a[i].x;
+                v[g + 2 * i + 1] = a[i].y;
+                d[g + 2 * i] = dd[i].x;
+                d[g + 2 * i + 1] = dd[i].y;
             }
         }
     }

@@ -352,7 +352,9 @@ extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
         LNX_CHECK(a->N == 4 * a->Cin, "lnx_gemm_nt: PATCH2 output needs N == 4*Cin");
         LNX_CHECK(a->a_mode == LNX_ADDR_PLAIN, "lnx_gemm_nt: PATCH2 on both sides is not supported");
     }
-    if (a->act == LNX_ACT_GELU_BWD || a->act == LNX_ACT_RELU_BWD) LNX_CHECK(a->aux != nullptr, "lnx_gemm_nt: act %d needs aux", a->act);
+    LNX_CHECK(a->act >= LNX_ACT_NONE && a->act <= LNX_ACT_MUL_AUX, "lnx_gemm_nt: unknown act %d", a->act);
+    if (a->act == LNX_ACT_GELU_BWD || a->act == LNX_ACT_RELU_BWD || a->act == LNX_ACT_MUL_AUX) LNX_CHECK(a->aux != nullptr, "lnx_gemm_nt: act %d needs aux", a->act);
+    if (a->act == LNX_ACT_GELU_D) LNX_CHECK(a->c2 != nullptr, "lnx_gemm_nt: GELU_D writes the derivative to c2, which is NULL");
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_gemm_nt: rowscale needs rows_per_sample");
 
     GemmP p;

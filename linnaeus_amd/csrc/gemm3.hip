@@ -301,7 +301,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[h * 8 + j] = t.get(j);
                 }
-                Gelu<T>::mulgrad16(v, x);
+                if (p.act == LNX_ACT_MUL_AUX) {  // the forward saved GELU'(pre-activation): one multiply
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] *= x[j];
+                } else {
+                    Gelu<T>::mulgrad16(v, x);
+                }
             }
             if (F & F_RES) {
 #pragma unroll
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
 
 bool nt_v7_ok(const GemmP& p, int f, bool out_f32) {
     if (f == (int)F_GENERIC || p.a_mode == LNX_ADDR_PATCH2) return false;
+    if (p.act == LNX_ACT_GELU_D) return false;  // this kernel's fc1 form keeps ONE tensor per tile; the derivative form needs two
     if (p.K % BK7 != 0 || p.K / BK7 < 6) return false;
     if (p.N % 64 != 0) return false;  // a wave's 64 columns are all inside or all outside N
     const int64_t lim = (int64_t)1 << 31;  // 32-bit byte offsets of the LDS-DMA sources

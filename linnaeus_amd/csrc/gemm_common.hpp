@@ -116,7 +116,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
     // Phase 1: every global load of the epilogue (aux, residual, row scale) for all four row slots, before
     // the first store.  C / C2 may alias res or aux as far as the compiler knows, so loads issued between
     // stores would each wait for the previous store: one memory round trip per row slot.
-    const bool has_aux = (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD);
+    const bool has_aux = (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_RELU_BWD || p.act == LNX_ACT_MUL_AUX);
     // one staging buffer: aux when the activation needs it, else the residual (a launch with both loads
     // the residual late, in phase 2)
     const bool res_early = p.res && !has_aux;
@@ -179,6 +179,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[ni * 4 + r] = acc[ni][mi][r] + bias[ni * 4 + r];
+        float d2[16];  // what goes to the second output: the pre-activation, or (GELU_D) the derivative of the activation
+        if (p.act == LNX_ACT_GELU_D) {
+            Gelu<T>::fwd_grad16(v, d2);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d2[j] = v[j];
+        }
         if (p.C2) {
             T* c2 = reinterpret_cast<T*>(p.C2) + (int64_t)m * p.ldc2 + nb;
             if (nvalid == 16 && ((((uintptr_t)c2) & 15) == 0)) {
@@ -186,14 +193,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
 #pragma unroll
                 for (int h = 0; h < 16 / EPV; ++h) {
 #pragma unroll
-                    for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                    for (int j = 0; j < EPV; ++j) o.set(j, d2[h * EPV + j]);
                     st16(c2 + h * EPV, o.raw);
                 }
             } else {
-                for (int j = 0; j < nvalid; ++j) c2[j] = from_f<T>(v[j]);
+                for (int j = 0; j < nvalid; ++j) c2[j] = from_f<T>(d2[j]);
             }
         }
-        if (p.act == LNX_ACT_GELU) {
+        if (p.act == LNX_ACT_MUL_AUX) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] *= av[mi][j];
+        } else if (p.act == LNX_ACT_GELU) {
             Gelu<T>::fwd16(v);
         } else if (p.act == LNX_ACT_RELU) {
 #pragma unroll
@@ -313,21 +323,34 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[ni * 4 + r] = (F & F_BIAS) ? acc[ni][mi][r] + bias[ni * 4 + r] : acc[ni][mi][r];
+        const bool deriv = (F & F_GELU) && (F & F_C2) && p.act == LNX_ACT_GELU_D;  // kernel-uniform: c2 = GELU'(v) instead of v
         if (F & F_C2) {
+            float d2[16];
+            if (deriv) {
+                Gelu<T>::fwd_grad16(v, d2);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) d2[j] = v[j];
+            }
             T* c2 = reinterpret_cast<T*>(p.C2) + (m * (int)p.ldc2 + nb);
             Vec16<T> o;
 #pragma unroll
             for (int h = 0; h < 16 / EPV; ++h) {
 #pragma unroll
-                for (int j = 0; j < EPV; ++j) o.set(j, v[h * EPV + j]);
+                for (int j = 0; j < EPV; ++j) o.set(j, d2[h * EPV + j]);
                 st16(c2 + h * EPV, o.raw);
             }
         }
-        if (F & F_GELU) {
+        if ((F & F_GELU) && !deriv) {
             Gelu<T>::fwd16(v);
         }
         if (F & F_GELU_BWD) {
-            Gelu<T>::mulgrad16(v, ld[mi]);
+            if (p.act == LNX_ACT_MUL_AUX) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] *= ld[mi][j];
+            } else {
+                Gelu<T>::mulgrad16(v, ld[mi]);
+            }
         }
         if (F & F_RES) {
 #pragma unroll
@@ -395,7 +418,10 @@ static inline int fast_epilogue_mask(const GemmP& p, bool out_f32) {
         f |= F_C2;
     }
     if (p.act == LNX_ACT_GELU) f |= F_GELU;
-    else if (p.act == LNX_ACT_GELU_BWD) {
+    else if (p.act == LNX_ACT_GELU_D) {
+        if (!p.C2) return F_GENERIC;
+        f |= F_GELU;
+    } else if (p.act == LNX_ACT_GELU_BWD || p.act == LNX_ACT_MUL_AUX) {
         if (!al16(p.aux) || (p.ldaux * esz) % 16 != 0 || (int64_t)p.M * p.ldaux >= lim) return F_GENERIC;
         f |= F_GELU_BWD;
     } else if (p.act != LNX_ACT_NONE) return F_GENERIC;

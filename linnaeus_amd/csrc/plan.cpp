@@ -63,7 +63,7 @@ struct ConvBlk {
 struct RopeBlk {
     int n1w, n1b, n2w, n2b, freqs, qkvb, projb, fc1b, fc2b;
     OpW qkv, proj, fc1, fc2;
-    int64_t xin, n1, mean1, rstd1, qkvbuf, cos, o, lse, xmid, n2, mean2, rstd2, hpre, act;
+    int64_t xin, n1, mean1, rstd1, qkvbuf, cos, dsin, o, lse, xmid, n2, mean2, rstd2, hpre, act;
     int64_t dm_proj = 0, dm_hid = 0, dm_fc2 = 0;  // byte offsets of this block's dropout keep masks in the caller's mask buffer
     int64_t dm_attn = 0;                          // ... and of its attention-probability keep mask in the second buffer
 };
@@ -125,7 +125,7 @@ struct lnx_plan {
     int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_cmws = 0, cmws_floats = 0;  // row-range partials of the fused conv-MLP weight gradients
-    int64_t o_gcos, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
+    int64_t o_gcos /* freqs-gradient partials of lnx_attn_bwd */, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     // fp8 plans, forward scratch: MXFP8 copy (+ block scales) of the LayerNorm output feeding qkv / fc1, and of the MLP hidden
     // feeding fc2 (two buffers: fc1 reads the first while its epilogue writes the second)
     int64_t o_a8 = 0, o_a8s = 0, o_h8 = 0, o_h8s = 0;
@@ -582,6 +582,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.rstd1 = share ? f.rstd1 : cv.take(M * 4);
             k.qkvbuf = share ? f.qkvbuf : cv.take(M * 3 * C * esz);
             k.cos = cv.take((int64_t)p->HW[2 + s] * heads * 32 * 4);
+            k.dsin = inf ? 0 : cv.take((int64_t)2 * p->HW[2 + s] * heads * 32 * 4);  // d cos / d freqs, for the attention backward
             k.o = share ? f.o : cv.take(M * C * esz);
             k.lse = share ? f.lse : cv.take((int64_t)B * heads * N * 4);
             k.xmid = share ? f.xmid : cv.take(M * C * 4);
@@ -682,7 +683,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         int64_t gmax = 0, dmax = 0;
         for (int s = 0; s < 2; ++s) {
             const int N = s == 0 ? p->N2 : p->N3;
-            const int64_t gsz = (int64_t)2 * B * p->HW[2 + s] * c.rope_heads[s] * 32 * 4;
+            const int64_t gsz = lnx_attn_bwd_ws_floats(B, N, c.rope_heads[s]) * 4;  // per-workgroup partials of the freqs gradient
             const int64_t dsz = (int64_t)B * c.rope_heads[s] * N * 4;
             if (gsz > gmax) gmax = gsz;
             if (dsz > dmax) dmax = dsz;
@@ -1110,7 +1111,7 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
     RUN(linear_fwd(c, g, k.qkv, p->o_a8, p->o_a8s));
-    RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), c.st));
+    RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), p->c.inference ? nullptr : c.at<float>(k.dsin), c.st));
     lnx_attn_args a;
     memset(&a, 0, sizeof a);
     a.dtype = c.dt; a.B = B; a.N = N; a.E = E; a.heads = heads;
@@ -1135,7 +1136,9 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     }
     RUN(ln_fwd(c, M, C, 1e-5f, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<void>(k.n2), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean2), c.at<float>(k.rstd2), a8, a8s));
     g = gemm_base(c, M, hid, C, c.at<void>(k.n2), C, c.wptr(k.fc1), k.fc1.ld, c.at<void>(k.act), hid, false);
-    g.bias = p->P[k.fc1b]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
+    // k.hpre holds GELU'(fc1 output) on bf16 / fp32 plans (evaluated here, once, from the fp32 pre-activation: the data-gradient
+    // product's epilogue is then one multiply), the pre-activation itself in blocks that run their products in fp8 (those epilogue forms predate this)
+    g.bias = p->P[k.fc1b]; g.act = f8 ? LNX_ACT_GELU : LNX_ACT_GELU_D; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
     RUN(linear_fwd(c, g, k.fc1, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     if (p->dmask) {
         // Mlp.drop after the activation and after fc2 (blocks/mlp.py:63,65); the saved `act` is the dropped one, which is
@@ -1313,7 +1316,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_fc2, p->inv_keep, M, C, c.st));  // through the dropout after fc2
     RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
-    a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = hid;
+    a.act = fp8_rows(p, M, C) ? LNX_ACT_GELU_BWD : LNX_ACT_MUL_AUX; a.aux = c.at<void>(k.hpre); a.ldaux = hid;  // what the forward left in hpre
     // fp8 plans: dY is quantised once, the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
     RUN(linear_dgrad(c, a, k.fc2, true, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     if (p->dmask) RUN(lnx_dropout_mul(sA, c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));  // through the dropout after the activation
@@ -1333,7 +1336,8 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     memset(&ab, 0, sizeof ab);
     ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
     ab.qkv = c.at<void>(k.qkvbuf); ab.cos_tab = c.at<float>(k.cos); ab.o = c.at<void>(k.o); ab.lse = c.at<float>(k.lse);
-    ab.d_o = sD; ab.dqkv = sA; ab.gcos = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
+    ab.d_o = sD; ab.dqkv = sA; ab.freq_ws = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
+    ab.dsin_tab = c.at<float>(k.dsin); ab.dfreqs = p->G[k.freqs];
     if (p->amask) {
         ab.drop_mask = p->amask + k.dm_attn; ab.drop_inv_keep = p->a_inv_keep;
     }
@@ -1341,7 +1345,6 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
         Timed t(c, 3, 14.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_bwd(&ab, c.st));
     }
-    RUN(lnx_rope_freqs_bwd(p->P[k.freqs], c.at<float>(p->o_gcos), B, heads, p->H[2 + s], p->W[2 + s], p->G[k.freqs], c.st));
     RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C));
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
     RUN(gemm_nt_t(c, &a));

@@ -211,16 +211,19 @@ def dwconv7_wgrad(x, dy, dw, db):
     L.check(L.lib().lnx_dwconv7_wgrad(C.byref(a), _stream()), "lnx_dwconv7_wgrad")
 
 
-def rope_cos_table(freqs, H, W, out=None):
+def rope_cos_table(freqs, H, W, out=None, dsin=None):
+    """cos(theta) table [H*W, heads, 32]; `dsin` (optional, [2, H*W, heads, 32]) receives -t_x sin(theta), -t_y sin(theta)."""
     heads = freqs.shape[1]
     if out is None:
         out = torch.empty(H * W, heads, 32, device=freqs.device, dtype=torch.float32)
-    L.check(L.lib().lnx_rope_cos_table(_p(freqs), heads, H, W, _p(out), _stream()), "lnx_rope_cos_table")
+    L.check(L.lib().lnx_rope_cos_table(_p(freqs), heads, H, W, _p(out), _p(dsin) if dsin is not None else None, _stream()), "lnx_rope_cos_table")
     return out
 
 
-def rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs):
-    L.check(L.lib().lnx_rope_freqs_bwd(_p(freqs), _p(gcos), B, freqs.shape[1], H, W, _p(dfreqs), _stream()), "lnx_rope_freqs_bwd")
+def attn_bwd_ws_floats(B, N, heads):
+    fn = L.lib().lnx_attn_bwd_ws_floats
+    fn.restype = C.c_int64
+    return int(fn(B, N, heads))
 
 
 def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads, *, drop_mask=None, drop_rate=0.0):
@@ -232,11 +235,16 @@ def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads, *, drop_mask=None, drop_rate=
     L.check(L.lib().lnx_attn_fwd(C.byref(a), _stream()), "lnx_attn_fwd")
 
 
-def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads, *, drop_mask=None, drop_rate=0.0):
+def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, delta, B, N, E, heads, *, dsin=None, dfreqs=None, drop_mask=None, drop_rate=0.0):
+    """dq/dk/dv into dqkv; with image tokens (E < N) also dfreqs [2, heads, 32] += the gradient of the RoPE frequencies
+    (`dsin` = the second table of rope_cos_table)."""
     a = L.AttnBwdArgs()
     a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
     a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
-    a.d_o, a.dqkv, a.gcos, a.delta = _p(d_o), _p(dqkv), _p(gcos), _p(delta)
+    ws = torch.empty(max(attn_bwd_ws_floats(B, N, heads), 1), device=qkv.device, dtype=torch.float32)
+    a.d_o, a.dqkv, a.freq_ws, a.delta = _p(d_o), _p(dqkv), _p(ws), _p(delta)
+    if dsin is not None:
+        a.dsin_tab, a.dfreqs = _p(dsin), _p(dfreqs)
     if drop_mask is not None:
         a.drop_mask, a.drop_inv_keep = _p(drop_mask), 1.0 / (1.0 - drop_rate)
     L.check(L.lib().lnx_attn_bwd(C.byref(a), _stream()), "lnx_attn_bwd")

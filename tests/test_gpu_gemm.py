@@ -102,6 +102,14 @@ def test_nt_epilogues(dtype):
     x = aux.double().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
     torch.testing.assert_close(out.double(), (z - b.double()) * x.grad, rtol=1e-4, atol=1e-4)
+    # round 3: GELU_D (C = GELU(v), c2 = GELU'(v)) and its backward partner MUL_AUX (v *= aux)
+    out, c2 = run_nt(A, W, dtype, True, bias=b, act=L.ACT_GELU_D, want_c2=True)
+    zz = z.clone().requires_grad_(True)
+    torch.nn.functional.gelu(zz).sum().backward()
+    torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **gtol)
+    torch.testing.assert_close(c2.double(), zz.grad, rtol=1e-5 if dtype == L.F32 else 8e-3, atol=1e-4 if dtype == L.F32 else 8e-3)
+    out, _ = run_nt(A, W, dtype, True, act=L.ACT_MUL_AUX, aux=aux)
+    torch.testing.assert_close(out.double(), (z - b.double()) * aux.double(), rtol=1e-4, atol=1e-4)
     # ReLU / ReLU backward
     out, _ = run_nt(A, W, dtype, True, bias=b, act=L.ACT_RELU)
     torch.testing.assert_close(out.double(), z.clamp_min(0), **tol)
@@ -272,12 +280,19 @@ def test_nt_specialised_epilogues(kind, N):
         out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU, want_c2=True)
         torch.testing.assert_close(c2.float(), z.float(), rtol=8e-3, atol=8e-3)
         torch.testing.assert_close(out.float(), torch.nn.functional.gelu(z).float(), rtol=8e-3, atol=8e-3)
+        out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU_D, want_c2=True)  # derivative as the second output
+        zz = z.clone().requires_grad_(True)
+        torch.nn.functional.gelu(zz).sum().backward()
+        torch.testing.assert_close(c2.float(), zz.grad.float(), rtol=8e-3, atol=8e-3)
+        torch.testing.assert_close(out.float(), torch.nn.functional.gelu(z).float(), rtol=8e-3, atol=8e-3)
     elif kind == "gelu_bwd":
         aux = torch.randn(M, N, generator=g).cuda().bfloat16()
         out, _ = run_nt(A, W, L.BF16, False, act=L.ACT_GELU_BWD, aux=aux)
         x = aux.double().requires_grad_(True)
         torch.nn.functional.gelu(x).sum().backward()
         torch.testing.assert_close(out.float(), ((z - b.double()) * x.grad).float(), rtol=1e-2, atol=1e-2)
+        out, _ = run_nt(A, W, L.BF16, False, act=L.ACT_MUL_AUX, aux=aux)
+        torch.testing.assert_close(out.float(), ((z - b.double()) * aux.double()).float(), rtol=1e-2, atol=1e-2)
     else:
         res = torch.randn(M, N, generator=g).cuda()
         rs = (torch.rand(523, generator=g) > 0.3).float().cuda() / 0.7

@@ -194,8 +194,12 @@ def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
     gen = g(B + heads * 5 + N)
     qkv = torch.randn(B * N, 3 * C_, generator=gen).cuda().to(DT[dtype])
     freqs = O.seeded_fill("t.attn.freqs", (2, heads, 32), 7).cuda()
-    cos = ops.rope_cos_table(freqs, H, W)
+    dsin = torch.empty(2, H * W, heads, 32, device="cuda")
+    cos = ops.rope_cos_table(freqs, H, W, dsin=dsin)
     torch.testing.assert_close(cos.cpu(), O.rope_cos_table(freqs.cpu(), H, W), rtol=0, atol=2e-6)
+    fd = freqs.double().cpu().requires_grad_(True)  # the second table is d cos(theta) / d freqs[a, h, j], entry by entry
+    O.rope_cos_table(fd, H, W).sum().backward()
+    torch.testing.assert_close(dsin.double().cpu().sum(1), fd.grad, rtol=1e-5, atol=1e-4)
     o = torch.empty(B * N, C_, device="cuda", dtype=DT[dtype])
     lse = torch.empty(B, heads, N, device="cuda")
     ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads)
@@ -207,11 +211,10 @@ def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
     # backward
     d_o = torch.randn(B * N, C_, generator=gen).cuda().to(DT[dtype])
     dqkv = torch.full((B * N, 3 * C_), float("nan"), device="cuda", dtype=DT[dtype])
-    gcos = torch.zeros(2, B, H * W, heads, 32, device="cuda")
     delta = torch.empty(B, heads, N, device="cuda")
-    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads)
-    dfreqs = torch.zeros(2, heads, 32, device="cuda")
-    ops.rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs)
+    dfreqs = torch.ones(2, heads, 32, device="cuda")  # accumulated into: starts at 1
+    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, delta, B, N, E, heads, dsin=dsin, dfreqs=dfreqs)
+    dfreqs -= 1.0
     ref.backward(d_o.double().cpu())
     tolb = 1e-4 if dtype == L.F32 else 4e-2
     torch.testing.assert_close(dqkv.double().cpu(), qr.grad, rtol=tolb, atol=tolb)
@@ -231,7 +234,8 @@ def test_attention_probability_dropout(B, heads, H, W, E, dtype):
     gen = g(B + heads * 3 + N)
     qkv = torch.randn(B * N, 3 * C_, generator=gen).cuda().to(DT[dtype])
     freqs = O.seeded_fill("t.attn.freqs", (2, heads, 32), 7).cuda()
-    cos = ops.rope_cos_table(freqs, H, W)
+    dsin = torch.empty(2, H * W, heads, 32, device="cuda")
+    cos = ops.rope_cos_table(freqs, H, W, dsin=dsin)
     mask = (torch.rand(B, heads, N, Np, generator=gen) >= rate).to(torch.uint8).cuda()
     o = torch.empty(B * N, C_, device="cuda", dtype=DT[dtype])
     lse = torch.empty(B, heads, N, device="cuda")
@@ -244,11 +248,9 @@ def test_attention_probability_dropout(B, heads, H, W, E, dtype):
     torch.testing.assert_close(o.double().cpu(), ref.detach(), rtol=tol, atol=tol)
     d_o = torch.randn(B * N, C_, generator=gen).cuda().to(DT[dtype])
     dqkv = torch.full((B * N, 3 * C_), float("nan"), device="cuda", dtype=DT[dtype])
-    gcos = torch.zeros(2, B, H * W, heads, 32, device="cuda")
     delta = torch.empty(B, heads, N, device="cuda")
-    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, gcos, delta, B, N, E, heads, drop_mask=mask, drop_rate=rate)
     dfreqs = torch.zeros(2, heads, 32, device="cuda")
-    ops.rope_freqs_bwd(freqs, gcos, B, H, W, dfreqs)
+    ops.attn_bwd(qkv, cos, o, lse, d_o, dqkv, delta, B, N, E, heads, dsin=dsin, dfreqs=dfreqs, drop_mask=mask, drop_rate=rate)
     ref.backward(d_o.double().cpu())
     tolb = 1e-4 if dtype == L.F32 else 4e-2
     torch.testing.assert_close(dqkv.double().cpu(), qr.grad, rtol=tolb, atol=tolb)

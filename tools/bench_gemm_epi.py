@@ -53,6 +53,7 @@ M2, M3 = 50944, 13312
 cases = [("r0.qkv   bias            ", M2, 1152, 384, "bias"), ("r0.proj  bias+res f32out ", M2, 384, 384, "res"),
          ("r0.fc1   bias+gelu+c2    ", M2, 1536, 384, "gelu"), ("r0.fc2   bias+res f32out ", M2, 384, 1536, "res"),
          ("r0.dfc2  gelu_bwd(aux)   ", M2, 1536, 384, "gelu_bwd"), ("r0.dfc1  plain           ", M2, 384, 1536, "plain"),
+         ("r0.fc1d  bias+gelu+c2=d  ", M2, 1536, 384, "gelu_d"), ("r0.dfc2m mul_aux         ", M2, 1536, 384, "mul_aux"),
          ("r0.dqkv  plain           ", M2, 384, 1152, "plain"), ("r0.dproj plain           ", M2, 384, 384, "plain"),
          ("r1.qkv   bias            ", M3, 2304, 768, "bias"), ("r1.proj  bias+res f32out ", M3, 768, 768, "res"),
          ("r1.fc1   bias+gelu+c2    ", M3, 3072, 768, "gelu"), ("r1.fc2   bias+res f32out ", M3, 768, 3072, "res"),
@@ -79,9 +80,19 @@ for name, M, N, K, kind in cases:
         ref = (ref + bias) * rsc[torch.arange(M, device="cuda") // 199, None] + res
     else:
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-        if kind not in ("plain", "gelu_bwd"):  # the data-gradient products have no bias
+        if kind not in ("plain", "gelu_bwd", "mul_aux"):  # the data-gradient products have no bias
             a.bias = ptr(bias)
             ref = ref + bias
+        if kind == "gelu_d":
+            c2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            a.act, a.c2, a.ldc2 = L.ACT_GELU_D, ptr(c2), N
+            keep += [c2]
+            ref = torch.nn.functional.gelu(ref)
+        if kind == "mul_aux":
+            aux = torch.randn(M, N, device="cuda").bfloat16()
+            a.act, a.aux, a.ldaux = L.ACT_MUL_AUX, ptr(aux), N
+            keep += [aux]
+            ref = ref * aux.float()
         if kind == "gelu":
             c2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             a.act, a.c2, a.ldc2 = L.ACT_GELU, ptr(c2), N

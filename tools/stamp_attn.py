@@ -14,15 +14,15 @@ lse = torch.empty(B * heads * N, device="cuda")
 ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads)
 do = torch.randn_like(o)
 dqkv = torch.empty_like(qkv)
-gcos = torch.zeros(2 * B * (N - E) * heads * 32, device="cuda")
+dsin = torch.empty(2, H * W, heads, 32, device="cuda"); cos = ops.rope_cos_table(freqs, H, W, dsin=dsin); dfreqs = torch.zeros(2, heads, 32, device="cuda")
 delta = torch.empty_like(lse)
 for _ in range(3):
-    ops.attn_bwd(qkv, cos, o, lse, do, dqkv, gcos, delta, B, N, E, heads)
+    ops.attn_bwd(qkv, cos, o, lse, do, dqkv, delta, B, N, E, heads, dsin=dsin, dfreqs=dfreqs)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    ops.attn_bwd(qkv, cos, o, lse, do, dqkv, gcos, delta, B, N, E, heads)
+    ops.attn_bwd(qkv, cos, o, lse, do, dqkv, delta, B, N, E, heads, dsin=dsin, dfreqs=dfreqs)
 e1.record(); torch.cuda.synchronize()
 print("attn_bwd (dq + dkv) us:", e0.elapsed_time(e1) * 100)
 out = (C.c_ulonglong * 8)()
