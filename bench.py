@@ -422,7 +422,7 @@ def main():
 
         lib = L.lib()
         st = model._active
-        NC = 9
+        NC = 8
         L.check(lib.lnx_plan_profile_begin(st["handle"]), "profile_begin")
         hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
         for _ in range(args.profile_steps):
@@ -434,7 +434,7 @@ def main():
         work = (C.c_double * NC)()
         cnt = (C.c_int * NC)()
         L.check(lib.lnx_plan_profile_end(st["handle"], ms, work, cnt), "profile_end")
-        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd", "convmlp_wgrad"]
+        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
         for i, nm in enumerate(names):
             if cnt[i] == 0:
                 continue

@@ -506,29 +506,10 @@ typedef struct lnx_convmlp_bwd_args {
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
 
-/* Weight and bias gradients of the same branch WITHOUT materialising the 4C-wide hidden tensors (round 2; the plan
- * uses it only under LNX_CONVMLP_FUSED_WGRAD=1: it removes 16 B/element of HBM traffic but the GELU recompute makes it
- * VALU-bound and slower than the two weight-gradient GEMMs on MI355X):
- *   dW1[4C,C] += dH^T . ln,  db1 += colsum(dH),  dW2[C,4C] += dz^T . act,  db2 += colsum(dz)
- * act = GELU(ln . W1^T + b1) and dH = (dz . W2) * GELU'(.) are recomputed per 32-row tile on chip (autograd's weight
- * gradients of pwconv1 / pwconv2, blocks/convnext.py:60-64).  With this entry lnx_convmlp_bwd is called with
- * act = dh = NULL.  Row ranges are summed through `ws` in a fixed order (bit-reproducible; no float atomics). */
-typedef struct lnx_convmlp_wgrad_args {
-    int dtype, M, C;
-    const void* ln;   /* [M, C] bf16 */
-    const void* dz;   /* [M, C] bf16 (output of lnx_convmlp_bwd) */
-    const void* w1;   /* [4C, C] bf16 pwconv1.weight */
-    const void* w2t;  /* [4C, C] bf16 pwconv2.weight^T */
-    const float* b1;  /* [4C] */
-    float* dw1;       /* [4C, C] fp32, += */
-    float* db1;       /* [4C], += */
-    float* dw2;       /* [C, 4C] fp32 (torch layout), += */
-    float* db2;       /* [C], += */
-    float* ws;        /* workspace of lnx_convmlp_wgrad_ws_floats(C, M) floats */
-    int64_t ws_floats;
-} lnx_convmlp_wgrad_args;
-int64_t lnx_convmlp_wgrad_ws_floats(int C, int M);
-int lnx_convmlp_wgrad(const lnx_convmlp_wgrad_args* args, void* stream);
+/* (round 2 had lnx_convmlp_wgrad here: both weight gradients from ln / dz with the hidden recomputed on chip, so that act / dH
+ * never reached HBM.  Correct, but slower end to end on MI355X -- 302 + 207 us per block at C = 96 against 317 us for the two
+ * weight-gradient GEMMs it replaced, because a single launch cannot hold the 288 KB of dW1 + dW2 accumulators and each of the two
+ * launches re-evaluates the GELU -- and removed in round 3; DESIGN.md records the numbers.) */
 
 /* ------------------------------------------------------------------------------------
  * Whole-model plan: mFormerV1 forward and backward as one native call each.
@@ -613,7 +594,7 @@ int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, in
  * 4 depthwise conv fwd / data-grad, 5 depthwise conv weight-grad, 6 fused conv-MLP forward,
  * 7 fused conv-MLP backward (data side), 8 fused conv-MLP weight gradients.  work = FLOPs for 0-3 and 6-8,
  * algorithmic HBM bytes for 4-5. */
-#define LNX_PROFILE_CLASSES 9 /* class 8: fused conv-MLP weight gradients (lnx_convmlp_wgrad), work = FLOPs */
+#define LNX_PROFILE_CLASSES 8
 int lnx_plan_profile_begin(lnx_plan* p);
 int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
 /* indices of the parameters whose gradient is final after `segment`; returns their count.  The metadata heads' backward

@@ -123,7 +123,7 @@ EXPORTS = [
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
     "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
-    "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_wgrad", "lnx_convmlp_wgrad_ws_floats",
+    "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",
     "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end",
@@ -216,15 +216,6 @@ class ConvMlpBwdArgs(C.Structure):
         ("g", C.c_void_p), ("ln", C.c_void_p), ("z", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
         ("w2t", C.c_void_p), ("w1t", C.c_void_p), ("gamma", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
         ("act", C.c_void_p), ("dh", C.c_void_p), ("dz", C.c_void_p), ("dln", C.c_void_p), ("dgamma", C.c_void_p),
-    ]
-
-
-class ConvMlpWgradArgs(C.Structure):
-    _fields_ = [
-        ("dtype", C.c_int), ("M", C.c_int), ("C", C.c_int),
-        ("ln", C.c_void_p), ("dz", C.c_void_p), ("w1", C.c_void_p), ("w2t", C.c_void_p), ("b1", C.c_void_p),
-        ("dw1", C.c_void_p), ("db1", C.c_void_p), ("dw2", C.c_void_p), ("db2", C.c_void_p),
-        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

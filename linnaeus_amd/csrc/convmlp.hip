@@ -384,8 +384,8 @@ extern "C" int lnx_dbg_convmlp_stamps(unsigned long long* out8) { return (int)hi
 // ------------------------------------------------------------------------------------
 // backward (data side): act, dH, dz, dln, dgamma
 // ------------------------------------------------------------------------------------
-// ST: also store act = GELU(h) and dH ([M, 4C] each) for separate weight-gradient GEMMs (round-1 path, kept for A/B);
-// the plan now calls with ST = false and lnx_convmlp_wgrad recomputes them on chip.
+// ST: also store act = GELU(h) and dH ([M, 4C] each), the operands of the two weight-gradient GEMMs the plan launches after
+// this kernel (ST = false: a caller that only wants the data gradient)
 template <int NK, int MT, int NW, bool ST>
 __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;

@@ -124,7 +124,6 @@ struct lnx_plan {
     int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
     int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
-    int64_t o_cmws = 0, cmws_floats = 0;  // row-range partials of the fused conv-MLP weight gradients
     int64_t o_gcos /* freqs-gradient partials of lnx_attn_bwd */, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     // fp8 plans, forward scratch: MXFP8 copy (+ block scales) of the LayerNorm output feeding qkv / fc1, and of the MLP hidden
     // feeding fc2 (two buffers: fc1 reads the first while its epilogue writes the second)
@@ -660,22 +659,10 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_lnws = cv.take(p->lnws_floats * 4);
         p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
         p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
-        // Fused conv-MLP blocks: the backward materialises act / dH ([M, 4C] each) for two weight-gradient GEMMs.
-        // LNX_CONVMLP_FUSED_WGRAD=1 switches to lnx_convmlp_wgrad, which recomputes them on chip instead (11 GB/step
-        // less HBM traffic and 1.2 GB less workspace at sm / B = 256) -- measured SLOWER on MI355X (the GELU recompute
-        // makes it VALU-bound: 530 vs 317 us per block at C = 96), so it is opt-in.
-        const bool store_hidden = getenv("LNX_CONVMLP_FUSED_WGRAD") == nullptr;
+        // Fused conv-MLP blocks: the backward materialises act / dH ([M, 4C] each) for the two weight-gradient GEMMs (a
+        // recomputing weight-gradient kernel existed in round 2 and was slower: DESIGN.md)
         p->o_sA = cv.take(maxM4C * esz);
-        if (any_fused && store_hidden) p->o_sB = cv.take(maxM4C * esz);
-        if (any_fused && !store_hidden) {
-            for (int s = 0; s < 2; ++s)
-                for (auto& k : p->conv[s])
-                    if (k.fused) {
-                        const int64_t n = lnx_convmlp_wgrad_ws_floats(D[s], (int)((int64_t)B * p->HW[s]));
-                        if (n > p->cmws_floats) p->cmws_floats = n;
-                    }
-            p->o_cmws = cv.take(p->cmws_floats * 4);
-        }
+        if (any_fused) p->o_sB = cv.take(maxM4C * esz);
         p->o_sC = cv.take(maxMC * esz);
         p->o_sD = cv.take(maxMC * esz);
     }
@@ -1374,25 +1361,13 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         f.g = g; f.ln = c.at<void>(k.ln); f.z = c.at<void>(k.z); f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1];
         f.w2t = c.wtptr(k.w2); f.w1t = c.wtptr(k.w1); f.gamma = p->P[k.gamma];
         f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
-        const bool store_hidden = p->o_sB != 0;
-        f.act = store_hidden ? sB : nullptr; f.dh = store_hidden ? sA : nullptr; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
+        f.act = sB; f.dh = sA; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
         {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
         }
-        if (store_hidden) {
-            RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C));
-            RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
-        } else {
-            lnx_convmlp_wgrad_args w;
-            memset(&w, 0, sizeof w);
-            w.dtype = c.dt; w.M = M; w.C = C;
-            w.ln = c.at<void>(k.ln); w.dz = sC; w.w1 = c.wptr(k.w1); w.w2t = c.wtptr(k.w2); w.b1 = p->P[k.b1];
-            w.dw1 = p->G[k.w1.param]; w.db1 = p->G[k.b1]; w.dw2 = p->G[k.w2.param]; w.db2 = p->G[k.b2];
-            w.ws = c.at<float>(p->o_cmws); w.ws_floats = p->cmws_floats;
-            Timed t(c, 8, 2.0 * M * C * 4 * C * 4);  // two recomputed products + two weight-gradient products
-            RUN(lnx_convmlp_wgrad(&w, c.st));
-        }
+        RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C));
+        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));

@@ -301,18 +301,3 @@ def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, 
     a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
     a.act, a.dh, a.dz, a.dln, a.dgamma = _p(act), _p(dh), _p(dz), _p(dln), _p(dgamma)
     L.check(L.lib().lnx_convmlp_bwd(C.byref(a), _stream()), "lnx_convmlp_bwd")
-
-
-def convmlp_wgrad(ln, dz, w1, w2t, b1, dw1, db1, dw2, db2):
-    """dW1 += dH^T ln, db1 += colsum(dH), dW2 += dz^T act, db2 += colsum(dz) with act / dH recomputed on chip."""
-    import torch
-
-    lib = L.lib()
-    lib.lnx_convmlp_wgrad_ws_floats.restype = C.c_int64
-    a = L.ConvMlpWgradArgs()
-    a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
-    n = lib.lnx_convmlp_wgrad_ws_floats(a.C, a.M)
-    ws = torch.empty(max(int(n), 1), device=ln.device, dtype=torch.float32)
-    a.ln, a.dz, a.w1, a.w2t, a.b1 = _p(ln), _p(dz), _p(w1), _p(w2t), _p(b1)
-    a.dw1, a.db1, a.dw2, a.db2, a.ws, a.ws_floats = _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), n
-    L.check(lib.lnx_convmlp_wgrad(C.byref(a), _stream()), "lnx_convmlp_wgrad")

@@ -608,25 +608,6 @@ def test_switch_autograd_to_direct_grad_mode():
         torch.testing.assert_close(p_.grad, 2 * want[k], rtol=1e-4, atol=1e-6, msg=k)
 
 
-def test_fused_convmlp_wgrad_path_in_plan(golden_dir, monkeypatch):
-    """LNX_CONVMLP_FUSED_WGRAD=1: the plan calls lnx_convmlp_bwd without materialising act / dH and gets the pointwise
-    weight gradients from lnx_convmlp_wgrad (recompute on chip).  Same gradients as the oracle, bf16 tolerances."""
-    monkeypatch.setenv("LNX_CONVMLP_FUSED_WGRAD", "1")
-    spec, z, sd, x, meta, drops = load_case("tiny_b", golden_dir)
-    model = build("tiny_b", spec, sd, "bf16")
-    out = run(model, x, meta, drops, train=True)
-    O.probe_loss(out).backward()
-    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    O.probe_loss(O.forward(osd, spec, x, meta, drops)).backward()
-    glob, wk = _grad_errors(model, osd)
-    assert glob <= 5e-2, (glob, wk)
-    for k, p_ in model.named_parameters():
-        if "pwconv" in k:
-            ref = osd[k].grad
-            rel = ((p_.grad.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-6)).item()
-            assert rel <= 0.05, (k, rel)
-
-
 def test_autobatch_analytic_matches_measured():
     """AutoBatch (utils/autobatch.py:111-265): the planner's analytic footprint predicts the measured peak of a real
     training step within a few percent, the search result is the largest batch under the budget, and a tight budget

@@ -391,22 +391,6 @@ def test_convmlp_fused_fwd_bwd(C_, M):
     ops.convmlp_bwd(gout, ln, z, w1, b1, w2.t().contiguous(), w1.t().contiguous(), gam, None, None, dz2, dln2, dgam2, rowscale=rs, rows_per_sample=rps)
     assert torch.equal(dz2, dz) and torch.equal(dln2, dln)
     torch.testing.assert_close(dgam2, dgam, rtol=2e-3, atol=2e-3)  # float atomics: summation order differs between launches
-    # fused weight gradients (act / dH recomputed on chip, row ranges summed through the workspace) vs fp64 on the same
-    # bf16 operands: dW1 = dH^T ln, db1 = colsum dH, dW2 = dz^T act, db2 = colsum dz; += semantics on pre-filled gradients
-    dw1 = torch.full((4 * C_, C_), 0.5, device="cuda")
-    db1 = torch.full((4 * C_,), -0.25, device="cuda")
-    dw2 = torch.full((C_, 4 * C_), 0.125, device="cuda")
-    db2 = torch.full((C_,), 1.0, device="cuda")
-    ops.convmlp_wgrad(ln, dz, w1, w2.t().contiguous(), b1, dw1, db1, dw2, db2)
-    act64 = torch.nn.functional.gelu(h).to(bf).double()
-    dh64 = ((dz.double() @ w2d) * hg.grad).to(bf).double()
-    scale1 = (dh64.abs().T @ lnd.abs()).clamp_min(1.0)
-    scale2 = (dz.double().abs().T @ act64.abs()).clamp_min(1.0)
-    e1 = ((dw1.double() - 0.5) - dh64.T @ lnd).abs() / scale1
-    e2 = ((dw2.double() - 0.125) - dz.double().T @ act64).abs() / scale2
-    assert e1.max().item() < 3e-3 and e2.max().item() < 3e-3, (e1.max().item(), e2.max().item())  # fp32 accumulation of bf16 products
-    torch.testing.assert_close(db1.double() + 0.25, dh64.sum(0), rtol=2e-3, atol=2e-3 * M**0.5)
-    torch.testing.assert_close(db2.double() - 1.0, dz.double().sum(0), rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): kernel-trace stats + the two PMC passes (HBM read / write bytes) of the default bench.
+# Run on the GPU box (gpurun): kernel-trace stats + three PMC passes (HBM read bytes, HBM write bytes, MFMA-pipe busy cycles)
+# of the default bench, each in its own run (no --pmc together with other trace domains).
 # Outputs under gpurun_out/prof_round/; tools/summarise_profile.py turns them into the files kept in profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -8,7 +9,11 @@ mkdir -p $O
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/bench.py $ARGS > $O/trace.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o r -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o r -- python3 $R/bench.py $ARGS > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o r -- python3 $R/bench.py $ARGS > $O/write.log 2>&1 &&
+# matrix-core utilisation and the clock the chip holds: busy cycles of the MFMA pipe against the busy cycles of
+# the shader engines, and GRBM_GUI_ACTIVE (summed over the 8 XCDs) against the kernel's duration
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o r -- python3 $R/bench.py $ARGS > $O/mfma.log 2>&1
 echo rc=$?
+rm -f $O/mfma/r_kernel_trace.csv.keep; cp $O/mfma/r_kernel_trace.csv $O/mfma_kernel_trace.csv 2>/dev/null
 rm -f $O/trace/r_kernel_trace.csv  # large; the stats file is what is kept
 ls -la $O/*

@@ -59,9 +59,9 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as f:
     f.write("kernel,launches_per_step,hbm_read_bytes_per_launch,hbm_write_bytes_per_launch\n")
     for k, n, rd, wr in rows:
         f.write(f"\"{k}\",{n:.2f},{rd:.0f},{wr:.0f}\n")
-nt = [(n, rd, wr) for k, n, rd, wr in rows if k.startswith("gemm_nt_v2_kernel") or k.startswith("gemm_nt_v4_kernel")]
+nt = [(n, rd, wr) for k, n, rd, wr in rows if k.startswith(("gemm_nt_v2_kernel", "gemm_nt_v4_kernel", "gemm_nt_v7_kernel"))]
 tot_n = sum(n for n, _, _ in nt)
-summary = {"kernel": "gemm_nt_v2_kernel + gemm_nt_v4_kernel (the pipelined bf16 NT GEMM, all tile shapes and epilogue forms)", "launches_per_step": round(tot_n, 2),
+summary = {"kernel": "gemm_nt_v2 / v4 / v7 kernels (the pipelined bf16 NT GEMM, all tile shapes and epilogue forms)", "launches_per_step": round(tot_n, 2),
            "hbm_read_bytes_per_launch": round(sum(n * rd for n, rd, _ in nt) / tot_n), "hbm_write_bytes_per_launch": round(sum(n * wr for n, _, wr in nt) / tot_n),
            "source": f"profiles/{tag}_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)",
            "config": "bench.py --steps 10 --warmup 3, mFormerV1_sm bf16 batch 256"}
@@ -69,6 +69,34 @@ summary["bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hb
 with open(os.path.join(dst, f"{tag}_gemm_nt_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1))
+# ---- MFMA utilisation pass (optional): per kernel, matrix-pipe busy cycles / (4 SIMDs x 256 CUs x kernel cycles at the held clock)
+mf = os.path.join(src, "mfma", "r_counter_collection.csv")
+if os.path.exists(mf):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    with open(mf) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_BUSY_CYCLES":
+                cnt[k] += 1
+    dur = collections.defaultdict(float)
+    tr = os.path.join(src, "mfma", "r_kernel_trace.csv")
+    if os.path.exists(tr):
+        with open(tr) as f:
+            for r in csv.DictReader(f):
+                dur[short(r["Kernel_Name"])] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    with open(os.path.join(dst, f"{tag}_mfma_util.csv"), "w") as f:
+        f.write("kernel,launches_per_step,mfma_busy_cycles_per_launch,gui_active_cycles_per_launch_sum8xcd,avg_duration_us,effective_clock_ghz,"
+                "mfma_pipe_util\n")
+        for k in sorted(acc, key=lambda k: -acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"]):
+            n = max(cnt[k], 1)
+            busy = acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / n
+            gui = acc[k]["GRBM_GUI_ACTIVE"] / n
+            d_us = dur[k] / n / 1e3 if dur[k] else 0.0
+            clk = gui / 8 / (d_us * 1e3) if d_us else 0.0          # cycles per ns = GHz (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+            util = busy / (4 * 256 * gui / 8) if gui else 0.0       # busy cycles of all matrix pipes / (1024 pipes x kernel cycles)
+            f.write(f"\"{k}\",{n / steps:.2f},{busy:.0f},{gui:.0f},{d_us:.1f},{clk:.3f},{util:.4f}\n")
 tot_r = sum(n * rd for _, n, rd, _ in rows)
 tot_w = sum(n * wr for _, n, _, wr in rows)
 print(f"whole step: {tot_r/1e9:.2f} GB read + {tot_w/1e9:.2f} GB written per step")
