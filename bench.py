@@ -311,8 +311,8 @@ def main():
         ds = FlatSyntheticDataset(path)
         q = queue.Queue(maxsize=4)
 
-        def produce():  # the reference's loader workers: read + collate off the training thread
-            for b in FlatBatchLoader(ds, B, shuffle=True, seed=rank, raw_uint8=True, epochs=None):
+        def produce():  # the reference's loader workers: read + collate off the training thread, straight into pinned memory
+            for b in FlatBatchLoader(ds, B, shuffle=True, seed=rank, raw_uint8=True, epochs=None, workers=4, pin=True):
                 q.put(b)
 
         threading.Thread(target=produce, daemon=True).start()
@@ -451,7 +451,7 @@ def main():
         traffic = traffic_src = None
         if args.arch == "sm" and args.batch == 256 and args.dtype == "bf16" and args.img == 224:
             traffic, traffic_src = committed_traffic()
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2/v4_kernel<{args.dtype}> (pipelined forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
+        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2 / v4 / v7 kernels <{args.dtype}> (LDS-DMA pipelined forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
                     "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                     "launches_per_step": kernels["gemm_nt"]["launches_per_step"],

@@ -102,40 +102,60 @@ class FlatSyntheticDataset(torch.utils.data.Dataset):
 
 class FlatBatchLoader:
     """Sequential (optionally shuffled per epoch) batches of a FlatSyntheticDataset, collated on the host:
-    (images, {task: [B, C] one-hot}, aux_info [B, D], meta_validity_masks [B, D] bool, group_ids [B] int64)."""
+    (images, {task: [B, C] one-hot}, aux_info [B, D], meta_validity_masks [B, D] bool, group_ids [B] int64).
+    `workers` threads collate whole batches ahead of the consumer (the reference's DataLoader workers; numpy's gathers release the
+    GIL), in order; `pin=True` gathers the images straight into pinned memory, so that DevicePrefetcher copies without re-staging."""
 
     def __init__(self, ds: FlatSyntheticDataset, batch_size: int, shuffle: bool = False, seed: int = 0, raw_uint8: bool = False, drop_last: bool = True,
-                 epochs: Optional[int] = 1):
+                 epochs: Optional[int] = 1, workers: int = 0, pin: bool = False):
         self.ds, self.B, self.shuffle, self.raw, self.drop_last, self.epochs = ds, int(batch_size), shuffle, raw_uint8, drop_last, epochs
+        self.workers, self.pin = int(workers), bool(pin)
         self._rng = np.random.default_rng(seed)
 
     def _collate(self, idx: np.ndarray):
         a = self.ds._a
-        order = np.sort(idx)  # ascending offsets for the memory map; samples keep the order of `idx` through `inv`
-        inv = np.argsort(np.argsort(idx))
-        raw = torch.from_numpy(np.ascontiguousarray(a["images"][order]))[inv]
+        B = len(idx)
+        img = a["images"]
+        raw = torch.empty((B,) + img.shape[1:], dtype=torch.uint8, pin_memory=self.pin)
+        np.take(img, idx, axis=0, out=raw.numpy(), mode="clip")  # one gather, in the order of `idx` (mode='raise' would buffer `out`)
         images = raw if self.raw else raw.permute(0, 3, 1, 2).float().div_(255.0)
         targets = {}
         for t in self.ds.tasks:
-            lab = torch.from_numpy(np.ascontiguousarray(a["label/" + t][order]).astype(np.int64))[inv]
+            lab = torch.from_numpy(np.take(a["label/" + t], idx).astype(np.int64))
             targets[t] = torch.nn.functional.one_hot(lab, self.ds.num_classes[t]).float()
         aux, valid = [], []
         for nm, dim in self.ds.meta:
-            v = torch.from_numpy(np.ascontiguousarray(a["meta/" + nm][order]))[inv]
+            v = torch.from_numpy(np.take(a["meta/" + nm], idx, axis=0))
             ok = ~(v == 0).all(dim=1, keepdim=True)
             aux.append(v * ok)
             valid.append(ok.expand(-1, dim))
-        B = len(idx)
         aux_info = torch.cat(aux, 1) if aux else torch.zeros(B, 0)
         masks = torch.cat(valid, 1) if valid else torch.zeros(B, 0, dtype=torch.bool)
-        gids = torch.from_numpy(np.ascontiguousarray(a["group_ids"][order]))[inv]
+        gids = torch.from_numpy(np.take(a["group_ids"], idx))
         return images, targets, aux_info, masks.contiguous(), gids
 
-    def __iter__(self) -> Iterator:
+    def _index_batches(self) -> Iterator[np.ndarray]:
         n = len(self.ds)
         ep = 0
         while self.epochs is None or ep < self.epochs:
             perm = self._rng.permutation(n) if self.shuffle else np.arange(n)
             for i in range(0, n - (self.B - 1 if self.drop_last else 0), self.B):
-                yield self._collate(perm[i:i + self.B])
+                yield perm[i:i + self.B]
             ep += 1
+
+    def __iter__(self) -> Iterator:
+        if self.workers <= 0:
+            for idx in self._index_batches():
+                yield self._collate(idx)
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(self.workers) as pool:
+            pending = deque()
+            for idx in self._index_batches():
+                pending.append(pool.submit(self._collate, idx))
+                if len(pending) > 2 * self.workers:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
