@@ -209,6 +209,86 @@ __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigne
     }
 }
 
+// ---- the same two products with the number of live 16-row groups as a compile-time constant -------------------------------
+// With a run-time `nt` every group sits under its own branch: hipcc then emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per
+// group -- one exposed LDS round trip per pair of MFMAs (round 3: the resident backward kernels spent most of their key /
+// query loop that way).  The images are staged in units of 32 rows, so two bodies cover every sequence length: NT = 4 for a
+// tile with more than 32 live rows (a fourth group of pure padding costs two MFMAs), NT = 2 for the last tile otherwise.
+// PHASE_FENCE keeps the products of one tile step apart: left free, the scheduler hoists the fragment loads of all of them to
+// the top and the 128-register budget (two workgroups per CU) spills.
+#define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int V> struct IC { static constexpr int value = V; };
+template <typename T, int NT>
+__device__ __forceinline__ void rows_times_frag_pad_n(f32x4_t (&acc)[4], const unsigned char* img, int s, int g, const uint4 (&frag)[AT<T>::NKK]) {
+    uint4 a[NT][AT<T>::NKK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) a[t][kk] = ld16(img + (t * 16 + s) * AT<T>::TRB + ((kk * 4 + g) << 4));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) mfma_chunk<T>(acc[t], a[t][kk], frag[kk]);
+}
+template <typename T, int NT>
+__device__ __forceinline__ void rows_times_frag_n(f32x4_t (&acc)[4], const unsigned char* rowimg, int s, int g, const uint4 (&frag)[AT<T>::NKK]) {
+    uint4 a[NT][AT<T>::NKK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) a[t][kk] = ld16(rowimg + (t * 16 + s) * AT<T>::ROWB + (((kk * 4 + g) ^ ((t * 16 + s) & 7)) << 4));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < AT<T>::NKK; ++kk) mfma_chunk<T>(acc[t], a[t][kk], frag[kk]);
+}
+// p[t] of the groups t >= NT must be zero (the image rows behind them may lie beyond the staged part only for t >= 2 ceil(NT / 2))
+template <typename T, int NT>
+__device__ __forceinline__ void imgT_times_regs_n(f32x4_t (&out)[4], const unsigned char* trimg, int s, int g, const float (&p)[4][4]) {
+    if constexpr (sizeof(T) == 2) {
+        constexpr int NKS = (NT + 1) / 2;
+        uint4 pf[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            Vec16<bf16_t> v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.set(j, p[2 * ks + (j >> 2)][j & 3]);
+            pf[ks] = v.raw;
+        }
+        uint2 a0[NKS][4], a1[NKS][4];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int r0 = ks * 32 + 4 * g + (s >> 2);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int col = (dt * 16 + 4 * (s & 3)) * 2;
+                a0[ks][dt] = tr_read(trimg + r0 * AT<T>::TRB + col);
+                a1[ks][dt] = tr_read(trimg + (r0 + 16) * AT<T>::TRB + col);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) mfma_bf16(out[dt], make_uint4(a0[ks][dt].x, a0[ks][dt].y, a1[ks][dt].x, a1[ks][dt].y), pf[ks]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + 4 * g + r;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float a = *reinterpret_cast<const float*>(trimg + row * AT<T>::TRB + (dt * 16 + s) * 4);
+                    mfma_f32(out[dt], a, p[t][r]);
+                }
+            }
+    }
+}
+
 // four consecutive elements in one store (8 bytes of bf16 / 16 bytes of fp32); p is 8-/16-byte aligned
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d) {
     if constexpr (sizeof(T) == 2) {
@@ -277,6 +357,24 @@ template <typename T> __device__ __forceinline__ float fexp(float x) {
     if constexpr (sizeof(T) == 2) return __expf(x);
     else return expf(x);
 }
+// exp(x - m) with m fixed along a row.  bf16 kernels: log2(e) folded into the subtraction, one FMA in front of v_exp_f32
+// (prep(m) = m log2(e) once per row) instead of subtract + multiply; fp32 (strict parity) kernels: libm.  `clamped` bounds the
+// argument by 0 -- a no-op for real (query, key) pairs of the backward (x <= lse), it keeps padding entries finite.
+template <typename T> struct RowExp {
+    static constexpr float L2E = 1.44269504088896340736f;
+    static __device__ __forceinline__ float prep(float m) {
+        if constexpr (sizeof(T) == 2) return m * L2E;
+        else return m;
+    }
+    static __device__ __forceinline__ float sub(float x, float mp) {
+        if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(fmaf(x, L2E, -mp));
+        else return expf(x - mp);
+    }
+    static __device__ __forceinline__ float clamped(float x, float mp) {
+        if constexpr (sizeof(T) == 2) return __builtin_amdgcn_exp2f(fminf(fmaf(x, L2E, -mp), 0.f));
+        else return expf(fminf(x - mp, 0.f));
+    }
+};
 
 struct AttnP {
     const void* qkv;
@@ -665,29 +763,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
-        for (int kt = 0; kt < nkt; ++kt) {
+        // NT live 16-key groups, MASK = the tile holds padding keys (only the last tile of a sequence can)
+        auto kstep = [&](const int kt, auto ntc, auto maskc) __attribute__((always_inline)) {
+            constexpr int NT = decltype(ntc)::value;
+            constexpr bool MASK = decltype(maskc)::value != 0;
             f32x4_t sacc[4];
-            rows_times_frag<T>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf);
+            rows_times_frag_n<T, NT>(sacc, kimg + kt * BT * AT<T>::ROWB, s, g, qf);
             float pv[4][4];
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * BT + t * 16 + 4 * g + r;
-                    const float v = key < p.N ? sacc[t][r] : -INFINITY;
+                    float v = sacc[t][r];
+                    if constexpr (MASK) v = kt * BT + t * 16 + 4 * g + r < p.N ? v : -INFINITY;
                     pv[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
             mx = group_max(mx);
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __expf(m_run - m_new);
+            const float mp = RowExp<T>::prep(m_new);
+            const float alpha = RowExp<T>::sub(m_run, mp);
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(pv[t][r] - m_new);
+                    const float e = t < NT ? RowExp<T>::sub(pv[t][r], mp) : 0.f;
                     pv[t][r] = e;
                     psum += e;
                 }
@@ -697,7 +799,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-            imgT_times_regs<T>(oacc, vimg + kt * BT * AT<T>::TRB, s, g, pv);
+            imgT_times_regs_n<T, NT>(oacc, vimg + kt * BT * AT<T>::TRB, s, g, pv);
+        };
+        const int nf = p.N / BT;  // tiles of 64 real keys
+        for (int kt = 0; kt < nf; ++kt) kstep(kt, IC<4>{}, IC<0>{});
+        if (nf < nkt) {
+            if (p.N - nf * BT > 32) kstep(nf, IC<4>{}, IC<1>{});
+            else kstep(nf, IC<2>{}, IC<1>{});
         }
         const float l_tot = group_sum(l_run);
         const float inv = 1.0f / l_tot;
@@ -734,9 +842,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
+    const int n4 = (p.N + 31) / BT;  // key tiles with more than 32 live rows; at most one shorter tile follows
     for (int qt = wave; qt < nq16; qt += 8) {
         const int q = qt * 16 + s;
-        // every fetch of this q tile in one batch (unconditional, clamped rows): q~, dO and O fragments, the raw q values
+        // every fetch of a q tile in one batch (unconditional, clamped rows): q~, dO and O fragments, the raw q values
         // and cos factors of the epilogue, the row's LSE -- instead of one memory round trip per operand
         const int qc = min(q, p.N - 1);
         uint4 qf[AT<T>::NKK], dof[AT<T>::NKK];
@@ -785,27 +894,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         const float delta = group_sum(dl);
-        const float lse = q < p.N ? lse_raw : 0.f;
+        const float lse = RowExp<T>::prep(q < p.N ? lse_raw : 0.f);
         if (q < p.N && g == 0) p.delta[((int64_t)b * p.heads + head) * p.N + q] = delta;
         f32x4_t dq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nkt; ++kt) {
+        // No masks in the loop: the image rows of the padding keys (N <= key < npad) are zero, so whatever finite dS they
+        // get multiplies a zero row of K~; lanes of padding queries are not stored.  exp's argument is <= 0 for every real
+        // (query, key) pair, the clamp only keeps the padding ones finite.
+        auto kstep = [&](const int kt, auto ntc) __attribute__((always_inline)) {
+            constexpr int NT = decltype(ntc)::value;
             f32x4_t sacc[4], dpacc[4];
-            const int nt = min(4, (p.N - kt * BT + 15) >> 4);  // 16-key groups of this tile that are not padding
-            rows_times_frag_pad<T>(sacc, kimg + kt * BT * AT<T>::TRB, s, g, qf, nt);
-            rows_times_frag_pad<T>(dpacc, vimg + kt * BT * AT<T>::TRB, s, g, dof, nt);
+            rows_times_frag_pad_n<T, NT>(sacc, kimg + kt * BT * AT<T>::TRB, s, g, qf);
+            PHASE_FENCE();
+            rows_times_frag_pad_n<T, NT>(dpacc, vimg + kt * BT * AT<T>::TRB, s, g, dof);
+            PHASE_FENCE();
             float ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kt * BT + t * 16 + 4 * g + r;
-                    const float pr = (key < p.N && q < p.N) ? __expf(sacc[t][r] - lse) : 0.f;
-                    ds[t][r] = pr * (dpacc[t][r] - delta);
+                    const float pr = RowExp<T>::clamped(sacc[t][r], lse);
+                    ds[t][r] = t < NT ? pr * (dpacc[t][r] - delta) : 0.f;
                 }
-            imgT_times_regs<T>(dq, kimg + kt * BT * AT<T>::TRB, s, g, ds, nt);
-        }
+            PHASE_FENCE();
+            imgT_times_regs_n<T, NT>(dq, kimg + kt * BT * AT<T>::TRB, s, g, ds);
+            PHASE_FENCE();
+        };
+        for (int kt = 0; kt < n4; ++kt) kstep(kt, IC<4>{});
+        if (n4 < nkt) kstep(n4, IC<2>{});
         {
             // the d cos / d freqs table entries of this row: fetched here (after the key loop: held across it they would spill)
             const float* sxp = p.dsin + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
@@ -874,16 +991,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     ATT_T(0);
     for (int i = threadIdx.x; i < nqt * BT; i += blockDim.x) {  // unconditional loads (clamped), zero by select
         const float l = p.lse[statbase + min(i, p.N - 1)], d = p.delta[statbase + min(i, p.N - 1)];
-        lse_s[i] = i < p.N ? l : 0.f;
+        lse_s[i] = RowExp<T>::prep(i < p.N ? l : 0.f);
         del_s[i] = i < p.N ? d : 0.f;
     }
     __syncthreads();
     ATT_T(1);
     const int nk16 = (p.N + 15) / 16;
+    const int n4 = (p.N + 31) / BT;  // query tiles with more than 32 live rows; at most one shorter tile follows
     for (int ktile = wave; ktile < nk16; ktile += 8) {
         const int key = ktile * 16 + s;
         const int kc = min(key, p.N - 1);
-        // every fetch of this key tile in one batch (see the dq kernel)
+        // every fetch of this key tile in one batch (see the dq kernel).  (Requesting the first tile's fragments before the
+        // staging loads was tried in round 3: the chunks held across the staging spill, 212 -> 290 us for the pair of kernels.)
         uint4 kf[AT<T>::NKK], vf[AT<T>::NKK];
         Chunk<T, true> ck[AT<T>::NKK];
         Chunk<T, false> cv[AT<T>::NKK];
@@ -905,24 +1024,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             dv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         ATT_T(2);
-        for (int qt = 0; qt < nqt; ++qt) {
+        // No masks in the loop (see the dq kernel): padding queries have zero rows in both images and finite statistics (0).
+        auto qstep = [&](const int qt, auto ntc) __attribute__((always_inline)) {
+            constexpr int NT = decltype(ntc)::value;
             f32x4_t sacc[4], dpacc[4];
-            const int nt = min(4, (p.N - qt * BT + 15) >> 4);  // 16-query groups of this tile that are not padding
-            rows_times_frag_pad<T>(sacc, qimg + qt * BT * AT<T>::TRB, s, g, kf, nt);
-            rows_times_frag_pad<T>(dpacc, doimg + qt * BT * AT<T>::TRB, s, g, vf, nt);
+            rows_times_frag_pad_n<T, NT>(sacc, qimg + qt * BT * AT<T>::TRB, s, g, kf);
+            PHASE_FENCE();
+            rows_times_frag_pad_n<T, NT>(dpacc, doimg + qt * BT * AT<T>::TRB, s, g, vf);
+            PHASE_FENCE();
             float pr[4][4], ds[4][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                if (t < NT) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * BT + t * 16 + 4 * g);
+                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + qt * BT + t * 16 + 4 * g);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ql = qt * BT + t * 16 + 4 * g + r;
-                    const float pp = (ql < p.N && key < p.N) ? __expf(sacc[t][r] - lse_s[ql]) : 0.f;
-                    pr[t][r] = pp;
-                    ds[t][r] = pp * (dpacc[t][r] - del_s[ql]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float pp = RowExp<T>::clamped(sacc[t][r], lv[r]);
+                        pr[t][r] = pp;
+                        ds[t][r] = pp * (dpacc[t][r] - dvv[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[t][r] = ds[t][r] = 0.f;
                 }
-            imgT_times_regs<T>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr, nt);
-            imgT_times_regs<T>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds, nt);
-        }
+            }
+            PHASE_FENCE();
+            imgT_times_regs_n<T, NT>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr);
+            PHASE_FENCE();
+            imgT_times_regs_n<T, NT>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds);
+            PHASE_FENCE();
+        };
+        for (int qt = 0; qt < n4; ++qt) qstep(qt, IC<4>{});
+        if (n4 < nqt) qstep(n4, IC<2>{});
         ATT_T(3);
         // raw k values and cos factors of the epilogue: one batch of loads here (held across the query loop they spill)
         const T* kraw = kb + (int64_t)kc * ld;
