@@ -120,6 +120,33 @@ __device__ __forceinline__ void stage_tile(unsigned char* rowimg, unsigned char*
     }
 }
 
+// The same staging split in two, for the tiled kernels' software pipeline: fetch() requests a 64-row tile into registers
+// (unconditional, clamped rows -- call it for min(next, last) rather than under `if (more)`), commit() writes it to the LDS
+// images one loop trip later, after the products of the current tile have been issued in between.
+template <typename T, bool COS, int NT>
+struct TileFetch {
+    static constexpr int NCH = AT<T>::NCH, EPV = AT<T>::EPV, PER = BT * NCH / NT;
+    Chunk<T, COS> ch[PER];
+    __device__ __forceinline__ void fetch(const T* __restrict__ base, int64_t ld, int n0, int N, int E, const float* __restrict__ cos_tab, int heads, int head) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = threadIdx.x + u * NT;
+            ch[u].fetch(base, ld, n0 + i / NCH, N, E, (i % NCH) * EPV, cos_tab, heads, head);
+        }
+    }
+    template <bool ROWIMG, bool TRIMG>
+    __device__ __forceinline__ void commit(unsigned char* rowimg, unsigned char* trimg, int n0, int N, int E, float scale) const {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = threadIdx.x + u * NT;
+            const int r = i / NCH, c = i % NCH;
+            const uint4 v = ch[u].value(n0 + r, N, E, scale);
+            if constexpr (ROWIMG) st16(rowimg + r * AT<T>::ROWB + ((c ^ (r & 7)) << 4), v);
+            if constexpr (TRIMG) st16(trimg + r * AT<T>::TRB + c * 16, v);
+        }
+    }
+};
+
 // fragment of a row operand held in registers: lane (s, g) <- token row, chunks kk*4 + g
 template <typename T, bool COS>
 __device__ __forceinline__ void load_row_frag(uint4 (&f)[AT<T>::NKK], const T* __restrict__ base, int64_t ld, int n, int N, int E, int g,
@@ -393,6 +420,104 @@ struct AttnP {
     int Np = 0;                            // N rounded up to a multiple of 64
 };
 
+// dk / dv epilogue of one 16-key wave tile: every load in one batch (clamped rows, unconditional), 8-/16-byte stores, the k part
+// of the freqs gradient.  Shared by the resident and the tiled kernel.
+template <typename T>
+__device__ __forceinline__ void dkv_epilogue(const AttnP& p, const f32x4_t (&dk)[4], const f32x4_t (&dv)[4], const T* __restrict__ kb, int64_t ld, int C,
+                                             int b, int head, int key, int s, int g, float* fl) {
+    const int kc = min(key, p.N - 1);
+    const T* kraw = kb + (int64_t)kc * ld;
+    const float* cpr = p.cos_tab + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
+    const float* sxp = p.dsin + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
+    const float* syp = sxp + (int64_t)(p.N - p.E) * p.heads * 32;
+    float kr[4][4], cr[4][2], gp[4][2], dx[4][2], dy[4][2];
+    const bool rope = p.E < p.N;  // uniform: without image tokens there are no tables
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int d0 = dt * 16 + 4 * g;
+        if constexpr (sizeof(T) == 2) {
+            const uint2 r = *reinterpret_cast<const uint2*>(kraw + d0);
+            const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kr[dt][j] = (float)h[j];
+        } else {
+            const float4 r = *reinterpret_cast<const float4*>(kraw + d0);
+            kr[dt][0] = r.x; kr[dt][1] = r.y; kr[dt][2] = r.z; kr[dt][3] = r.w;
+        }
+        cr[dt][0] = cr[dt][1] = 1.0f;
+        dx[dt][0] = dx[dt][1] = dy[dt][0] = dy[dt][1] = 0.f;
+        if (rope) {
+            const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
+            cr[dt][0] = c2.x; cr[dt][1] = c2.y;
+            const float2 a2 = *reinterpret_cast<const float2*>(sxp + (d0 >> 1));
+            const float2 b2 = *reinterpret_cast<const float2*>(syp + (d0 >> 1));
+            dx[dt][0] = a2.x; dx[dt][1] = a2.y;
+            dy[dt][0] = b2.x; dy[dt][1] = b2.y;
+        }
+    }
+    const bool row = key < p.N, img = row && key >= p.E;
+    T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
+    T* dvp = dkp + C;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int d0 = dt * 16 + 4 * g;
+        const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
+        if (row) {
+            store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
+            store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+        }
+        gp[dt][0] = img ? dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1] : 0.f;
+        gp[dt][1] = img ? dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3] : 0.f;
+    }
+    if (rope) freq_accum(fl, gp, dx, dy, s, g);
+}
+// dq epilogue of one 16-query wave tile (the tiled kernel; the resident one fetches its operands ahead of the key loop)
+template <typename T>
+__device__ __forceinline__ void dq_epilogue(const AttnP& p, const f32x4_t (&dq)[4], const T* __restrict__ qb, int64_t ld, int b, int head, int q, int s, int g,
+                                            float scale, float* fl) {
+    const int qc = min(q, p.N - 1);
+    const T* qraw = qb + (int64_t)qc * ld;
+    const float* cpr = p.cos_tab + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
+    const float* sxp = p.dsin + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
+    const float* syp = sxp + (int64_t)(p.N - p.E) * p.heads * 32;
+    float qr[4][4], cr[4][2], gp[4][2], dx[4][2], dy[4][2];
+    const bool rope = p.E < p.N;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int d0 = dt * 16 + 4 * g;
+        if constexpr (sizeof(T) == 2) {
+            const uint2 r = *reinterpret_cast<const uint2*>(qraw + d0);
+            const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qr[dt][j] = (float)h[j];
+        } else {
+            const float4 r = *reinterpret_cast<const float4*>(qraw + d0);
+            qr[dt][0] = r.x; qr[dt][1] = r.y; qr[dt][2] = r.z; qr[dt][3] = r.w;
+        }
+        cr[dt][0] = cr[dt][1] = 1.0f;
+        dx[dt][0] = dx[dt][1] = dy[dt][0] = dy[dt][1] = 0.f;
+        if (rope) {
+            const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
+            cr[dt][0] = c2.x; cr[dt][1] = c2.y;
+            const float2 a2 = *reinterpret_cast<const float2*>(sxp + (d0 >> 1));
+            const float2 b2 = *reinterpret_cast<const float2*>(syp + (d0 >> 1));
+            dx[dt][0] = a2.x; dx[dt][1] = a2.y;
+            dy[dt][0] = b2.x; dy[dt][1] = b2.y;
+        }
+    }
+    const bool row = q < p.N, img = row && q >= p.E;
+    T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const int d0 = dt * 16 + 4 * g;
+        const float c0 = img ? cr[dt][0] * scale : scale, c1 = img ? cr[dt][1] * scale : scale;
+        if (row) store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
+        gp[dt][0] = img ? scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]) : 0.f;
+        gp[dt][1] = img ? scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]) : 0.f;
+    }
+    if (rope) freq_accum(fl, gp, dx, dy, s, g);
+}
+
 // ---------------------------------------------------------------------------------
 // forward: one workgroup = 16 NW queries of one (b, head); wave = 16 queries (lane s).  NW = 8 (bf16, long sequences): every
 // staged 64-key tile serves 128 queries, i.e. half the staging work, LDS writes and barriers per query of NW = 4.
@@ -429,6 +554,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
     if constexpr (DROP) mrow = p.amask + (((int64_t)b * p.heads + head) * p.N + min(q, p.N - 1)) * p.Np + 4 * g;
 
     const int nkt = (p.N + BT - 1) / BT;
+    TileFetch<T, true, 64 * NW> fk;   // the next key tile travels in registers while this one is multiplied
+    TileFetch<T, false, 64 * NW> fv;
+    fk.fetch(kb, ld, 0, p.N, p.E, p.cos_tab, p.heads, head);
+    fv.fetch(vb, ld, 0, p.N, p.E, nullptr, p.heads, head);
     for (int kt = 0; kt < nkt; ++kt) {
         uint32_t mk[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
@@ -436,31 +565,45 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
             for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const uint32_t*>(mrow + kt * BT + 16 * t);
         }
         __syncthreads();
-        stage_tile<T, true, true, false, 64 * NW>(kimg, nullptr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
-        stage_tile<T, false, false, true, 64 * NW>(nullptr, vimg, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        fk.template commit<true, false>(kimg, nullptr, kt * BT, p.N, p.E, 1.0f);
+        fv.template commit<false, true>(nullptr, vimg, kt * BT, p.N, p.E, 1.0f);
+        const int nxt = min(kt + 1, nkt - 1) * BT;
+        fk.fetch(kb, ld, nxt, p.N, p.E, p.cos_tab, p.heads, head);
+        fv.fetch(vb, ld, nxt, p.N, p.E, nullptr, p.heads, head);
         __syncthreads();
         f32x4_t sacc[4];
-        rows_times_frag<T>(sacc, kimg, s, g, qf);  // S^T[key = 16t + 4g + r][query = s]
+        rows_times_frag_n<T, 4>(sacc, kimg, s, g, qf);  // S^T[key = 16t + 4g + r][query = s]
         float pv[4][4];
         float mx = -INFINITY;
+        if (kt * BT + BT <= p.N) {  // uniform: only the last tile of a sequence can hold padding keys
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * BT + t * 16 + 4 * g + r;
-                const float v = key < p.N ? sacc[t][r] : -INFINITY;
-                pv[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    pv[t][r] = sacc[t][r];
+                    mx = fmaxf(mx, sacc[t][r]);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * BT + t * 16 + 4 * g + r;
+                    const float v = key < p.N ? sacc[t][r] : -INFINITY;
+                    pv[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = group_max(mx);
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = fexp<T>(m_run - m_new);
+        const float mp = RowExp<T>::prep(m_new);
+        const float alpha = RowExp<T>::sub(m_run, mp);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = fexp<T>(pv[t][r] - m_new);
+                const float e = RowExp<T>::sub(pv[t][r], mp);
                 psum += e;
                 pv[t][r] = DROP ? (((mk[t] >> (8 * r)) & 0xffu) ? e * p.a_inv_keep : 0.f) : e;
             }
@@ -470,16 +613,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-        imgT_times_regs<T>(oacc, vimg, s, g, pv);  // O^T[d = 16dt + 4g + r][query = s]
+        imgT_times_regs_n<T, 4>(oacc, vimg, s, g, pv);  // O^T[d = 16dt + 4g + r][query = s]
     }
     const float l_tot = group_sum(l_run);
     const float inv = 1.0f / l_tot;
     if (q < p.N) {
         T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) op[dt * 16 + 4 * g + r] = from_f<T>(oacc[dt][r] * inv);
+        for (int dt = 0; dt < 4; ++dt) store4<T>(op + dt * 16 + 4 * g, oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
         if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
     }
 }
@@ -528,7 +669,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
         }
     }
     const float delta = group_sum(dl);
-    const float lse = q < p.N ? p.lse[((int64_t)b * p.heads + head) * p.N + q] : 0.f;
+    const float lse_raw = p.lse[((int64_t)b * p.heads + head) * p.N + min(q, p.N - 1)];  // unconditional load, select after
+    const float lse = RowExp<T>::prep(q < p.N ? lse_raw : 0.f);
     if (q < p.N && g == 0) p.delta[((int64_t)b * p.heads + head) * p.N + q] = delta;
 
     f32x4_t dq[4];
@@ -538,6 +680,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
     if constexpr (DROP) mrow = p.amask + (((int64_t)b * p.heads + head) * p.N + min(q, p.N - 1)) * p.Np + 4 * g;
 
     const int nkt = (p.N + BT - 1) / BT;
+    TileFetch<T, true, 64 * NW> fk;   // the next key tile travels in registers while this one is multiplied
+    TileFetch<T, false, 64 * NW> fv;
+    fk.fetch(kb, ld, 0, p.N, p.E, p.cos_tab, p.heads, head);
+    fv.fetch(vb, ld, 0, p.N, p.E, nullptr, p.heads, head);
     for (int kt = 0; kt < nkt; ++kt) {
         uint32_t mk[4] = {0, 0, 0, 0};
         if constexpr (DROP) {
@@ -545,53 +691,32 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
             for (int t = 0; t < 4; ++t) mk[t] = *reinterpret_cast<const uint32_t*>(mrow + kt * BT + 16 * t);
         }
         __syncthreads();
-        stage_tile<T, true, true, true, 64 * NW>(kimg, ktr, kb, ld, kt * BT, p.N, p.E, p.cos_tab, p.heads, head, 1.0f);
-        stage_tile<T, false, true, false, 64 * NW>(vimg, nullptr, vb, ld, kt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        fk.template commit<true, true>(kimg, ktr, kt * BT, p.N, p.E, 1.0f);
+        fv.template commit<true, false>(vimg, nullptr, kt * BT, p.N, p.E, 1.0f);
+        const int nxt = min(kt + 1, nkt - 1) * BT;
+        fk.fetch(kb, ld, nxt, p.N, p.E, p.cos_tab, p.heads, head);
+        fv.fetch(vb, ld, nxt, p.N, p.E, nullptr, p.heads, head);
         __syncthreads();
+        // no masks: padding keys have zero rows in all three images (their finite dS meets a zero row of K~), padding queries
+        // are not stored; the clamp keeps exp finite where (query, key) is not a real pair
         f32x4_t sacc[4], dpacc[4];
-        rows_times_frag<T>(sacc, kimg, s, g, qf);    // S^T[key][q]
-        rows_times_frag<T>(dpacc, vimg, s, g, dof);  // dP^T[key][q] = V[key] . dO[q]
+        rows_times_frag_n<T, 4>(sacc, kimg, s, g, qf);    // S^T[key][q]
+        PHASE_FENCE();
+        rows_times_frag_n<T, 4>(dpacc, vimg, s, g, dof);  // dP^T[key][q] = V[key] . dO[q]
+        PHASE_FENCE();
         float ds[4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * BT + t * 16 + 4 * g + r;
-                const float pr = (key < p.N && q < p.N) ? fexp<T>(sacc[t][r] - lse) : 0.f;
+                const float pr = RowExp<T>::clamped(sacc[t][r], lse);
                 const float dp = DROP ? (((mk[t] >> (8 * r)) & 0xffu) ? dpacc[t][r] * p.a_inv_keep : 0.f) : dpacc[t][r];
                 ds[t][r] = pr * (dp - delta);
             }
-        imgT_times_regs<T>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
+        PHASE_FENCE();
+        imgT_times_regs_n<T, 4>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
     }
-    {
-        // dq = dQ~ * cos * scale ; pair gradient of the cos factor: scale * (dQ~[2j] q[2j] + dQ~[2j+1] q[2j+1])
-        const bool row = q < p.N, img = row && q >= p.E;
-        const int qc = min(q, p.N - 1), ni = max(qc - p.E, 0);
-        T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
-        const T* qraw = qb + (int64_t)qc * ld;
-        const float* cp = p.cos_tab + ((int64_t)ni * p.heads + head) * 32;
-        const float* sx = p.dsin + ((int64_t)ni * p.heads + head) * 32;
-        const float* sy = sx + (int64_t)(p.N - p.E) * p.heads * 32;
-        float gp[4][2], dx[4][2], dy[4][2];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d0 = dt * 16 + 4 * g;
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int d = d0 + 2 * pr;
-                const float c = img ? cp[d >> 1] : 1.0f;
-                const float g0 = dq[dt][2 * pr], g1 = dq[dt][2 * pr + 1];
-                if (row) {
-                    dqp[d] = from_f<T>(g0 * c * scale);
-                    dqp[d + 1] = from_f<T>(g1 * c * scale);
-                }
-                gp[dt][pr] = img ? scale * (g0 * to_f(qraw[d]) + g1 * to_f(qraw[d + 1])) : 0.f;
-                dx[dt][pr] = img ? sx[d >> 1] : 0.f;
-                dy[dt][pr] = img ? sy[d >> 1] : 0.f;
-            }
-        }
-        if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
-    }
+    dq_epilogue<T>(p, dq, qb, ld, b, head, q, s, g, scale, fl);
     if (p.E < p.N) freq_flush<false>(fl, p.fpart);
 }
 
@@ -638,67 +763,59 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
         dv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     const int nqt = (p.N + BT - 1) / BT;
+    TileFetch<T, true, 64 * NW> fq;   // the next query tile (and its statistics) travel in registers while this one is multiplied
+    TileFetch<T, false, 64 * NW> fdo;
+    const int stl = threadIdx.x & (BT - 1);  // every thread fetches a statistic (unconditional load); the first 64 commit
+    float l_n, d_n;
+    fq.fetch(qb, ld, 0, p.N, p.E, p.cos_tab, p.heads, head);
+    fdo.fetch(dob, C, 0, p.N, p.E, nullptr, p.heads, head);
+    l_n = p.lse[statbase + min(stl, p.N - 1)];
+    d_n = p.delta[statbase + min(stl, p.N - 1)];
     for (int qt = 0; qt < nqt; ++qt) {
         __syncthreads();
-        stage_tile<T, true, true, true, 64 * NW>(qimg, qtr, qb, ld, qt * BT, p.N, p.E, p.cos_tab, p.heads, head, scale);
-        stage_tile<T, false, true, true, 64 * NW>(doimg, dotr, dob, C, qt * BT, p.N, p.E, nullptr, p.heads, head, 1.0f);
+        fq.template commit<true, true>(qimg, qtr, qt * BT, p.N, p.E, scale);
+        fdo.template commit<true, true>(doimg, dotr, qt * BT, p.N, p.E, 1.0f);
         if (threadIdx.x < BT) {
             const int qq = qt * BT + threadIdx.x;
-            lse_s[threadIdx.x] = qq < p.N ? p.lse[statbase + qq] : 0.f;
-            del_s[threadIdx.x] = qq < p.N ? p.delta[statbase + qq] : 0.f;
+            lse_s[threadIdx.x] = RowExp<T>::prep(qq < p.N ? l_n : 0.f);
+            del_s[threadIdx.x] = qq < p.N ? d_n : 0.f;
         }
+        const int nxt = min(qt + 1, nqt - 1) * BT;
+        fq.fetch(qb, ld, nxt, p.N, p.E, p.cos_tab, p.heads, head);
+        fdo.fetch(dob, C, nxt, p.N, p.E, nullptr, p.heads, head);
+        l_n = p.lse[statbase + min(nxt + stl, p.N - 1)];
+        d_n = p.delta[statbase + min(nxt + stl, p.N - 1)];
         __syncthreads();
+        // no masks (see the dq kernel): padding queries have zero rows in the four images and finite statistics
         f32x4_t sacc[4], dpacc[4];
-        rows_times_frag<T>(sacc, qimg, s, g, kf);     // S[q = 16t + 4g + r][key = s]
-        rows_times_frag<T>(dpacc, doimg, s, g, vf);   // dP[q][key]
+        rows_times_frag_n<T, 4>(sacc, qimg, s, g, kf);     // S[q = 16t + 4g + r][key = s]
+        PHASE_FENCE();
+        rows_times_frag_n<T, 4>(dpacc, doimg, s, g, vf);   // dP[q][key]
+        PHASE_FENCE();
         float pr[4][4], ds[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + t * 16 + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(del_s + t * 16 + 4 * g);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ql = t * 16 + 4 * g + r;
-                const int qq = qt * BT + ql;
-                const float pp = (qq < p.N && key < p.N) ? fexp<T>(sacc[t][r] - lse_s[ql]) : 0.f;
+                const float pp = RowExp<T>::clamped(sacc[t][r], lv[r]);
                 float keepf = 1.0f;
-                if constexpr (DROP)  // this lane's key, the tile's queries: one byte per (query, key)
+                if constexpr (DROP) {  // this lane's key, the tile's queries: one byte per (query, key)
+                    const int qq = qt * BT + t * 16 + 4 * g + r;
                     keepf = p.amask[(((int64_t)b * p.heads + head) * p.N + min(qq, p.N - 1)) * p.Np + min(key, p.N - 1)] ? p.a_inv_keep : 0.f;
-                pr[t][r] = pp * keepf;
-                ds[t][r] = pp * (dpacc[t][r] * keepf - del_s[ql]);
-            }
-        imgT_times_regs<T>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
-        imgT_times_regs<T>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
-    }
-    {
-        const bool row = key < p.N, img = row && key >= p.E;
-        const int kc = min(key, p.N - 1), ni = max(kc - p.E, 0);
-        T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
-        T* dvp = dkp + C;
-        const T* kraw = kb + (int64_t)kc * ld;
-        const float* cp = p.cos_tab + ((int64_t)ni * p.heads + head) * 32;
-        const float* sx = p.dsin + ((int64_t)ni * p.heads + head) * 32;
-        const float* sy = sx + (int64_t)(p.N - p.E) * p.heads * 32;
-        float gp[4][2], dx[4][2], dy[4][2];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d0 = dt * 16 + 4 * g;
-#pragma unroll
-            for (int pq = 0; pq < 2; ++pq) {
-                const int d = d0 + 2 * pq;
-                const float c = img ? cp[d >> 1] : 1.0f;
-                const float g0 = dk[dt][2 * pq], g1 = dk[dt][2 * pq + 1];
-                if (row) {
-                    dkp[d] = from_f<T>(g0 * c);
-                    dkp[d + 1] = from_f<T>(g1 * c);
-                    dvp[d] = from_f<T>(dv[dt][2 * pq]);
-                    dvp[d + 1] = from_f<T>(dv[dt][2 * pq + 1]);
                 }
-                gp[dt][pq] = img ? g0 * to_f(kraw[d]) + g1 * to_f(kraw[d + 1]) : 0.f;
-                dx[dt][pq] = img ? sx[d >> 1] : 0.f;
-                dy[dt][pq] = img ? sy[d >> 1] : 0.f;
+                pr[t][r] = pp * keepf;
+                ds[t][r] = pp * (dpacc[t][r] * keepf - dvv[r]);
             }
         }
-        if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
+        PHASE_FENCE();
+        imgT_times_regs_n<T, 4>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
+        PHASE_FENCE();
+        imgT_times_regs_n<T, 4>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
     }
+    dkv_epilogue<T>(p, dk, dv, kb, ld, C, b, head, key, s, g, fl);
     if (p.E < p.N) freq_flush<true>(fl, p.fpart);
 }
 
@@ -735,8 +852,8 @@ __device__ __forceinline__ void stage_all(unsigned char* rowimg, unsigned char* 
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_res_kernel(const AttnP p) {
+template <typename T, int NW = 8>  // NW = 4: sequences of at most 64 tokens (4 tiles of 16: half of an 8-wave workgroup would idle)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkt = (p.N + BT - 1) / BT;
     const int npad = nkt * BT;
@@ -755,7 +872,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
-    for (int qt = wave; qt < nq16; qt += 8) {
+    for (int qt = wave; qt < nq16; qt += NW) {
         const int q = qt * 16 + s;
         uint4 qf[AT<T>::NKK];
         load_row_frag<T, true>(qf, qb, ld, q, p.N, p.E, g, p.cos_tab, p.heads, head, scale);
@@ -818,8 +935,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_res_kernel(const AttnP p) {
+template <typename T, int NW = 8>  // NW = 4: sequences of at most 64 tokens (4 tiles of 16: half of an 8-wave workgroup would idle)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dq_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nkt = (p.N + BT - 1) / BT;
     const int npad = (p.N + 31) & ~31;  // image rows: padding groups beyond it are never read (nt below)
@@ -843,7 +960,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
     const int n4 = (p.N + 31) / BT;  // key tiles with more than 32 live rows; at most one shorter tile follows
-    for (int qt = wave; qt < nq16; qt += 8) {
+    for (int qt = wave; qt < nq16; qt += NW) {
         const int q = qt * 16 + s;
         // every fetch of a q tile in one batch (unconditional, clamped rows): q~, dO and O fragments, the raw q values
         // and cos factors of the epilogue, the row's LSE -- instead of one memory round trip per operand
@@ -960,8 +1077,8 @@ __device__ unsigned long long g_att_stamp[8];
 #define ATT_T(i) do { } while (0)
 #endif
 
-template <typename T>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dkv_res_kernel(const AttnP p) {
+template <typename T, int NW = 8>  // NW = 4: sequences of at most 64 tokens (4 tiles of 16: half of an 8-wave workgroup would idle)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_bwd_dkv_res_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef ATT_STAMP
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
@@ -998,7 +1115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     ATT_T(1);
     const int nk16 = (p.N + 15) / 16;
     const int n4 = (p.N + 31) / BT;  // query tiles with more than 32 live rows; at most one shorter tile follows
-    for (int ktile = wave; ktile < nk16; ktile += 8) {
+    for (int ktile = wave; ktile < nk16; ktile += NW) {
         const int key = ktile * 16 + s;
         const int kc = min(key, p.N - 1);
         // every fetch of this key tile in one batch (see the dq kernel).  (Requesting the first tile's fragments before the
@@ -1059,48 +1176,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int qt = 0; qt < n4; ++qt) qstep(qt, IC<4>{});
         if (n4 < nqt) qstep(n4, IC<2>{});
         ATT_T(3);
-        // raw k values and cos factors of the epilogue: one batch of loads here (held across the query loop they spill)
-        const T* kraw = kb + (int64_t)kc * ld;
-        const float* cpr = p.cos_tab + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
-        const float* sxp = p.dsin + ((int64_t)max(kc - p.E, 0) * p.heads + head) * 32;
-        const float* syp = sxp + (int64_t)(p.N - p.E) * p.heads * 32;
-        float kr[4][4], cr[4][2], gp[4][2], dx[4][2], dy[4][2];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d0 = dt * 16 + 4 * g;
-            if constexpr (sizeof(T) == 2) {
-                const uint2 r = *reinterpret_cast<const uint2*>(kraw + d0);
-                const bf16_t* h = reinterpret_cast<const bf16_t*>(&r);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) kr[dt][j] = (float)h[j];
-            } else {
-                const float4 r = *reinterpret_cast<const float4*>(kraw + d0);
-                kr[dt][0] = r.x; kr[dt][1] = r.y; kr[dt][2] = r.z; kr[dt][3] = r.w;
-            }
-            const float2 c2 = *reinterpret_cast<const float2*>(cpr + (d0 >> 1));
-            cr[dt][0] = c2.x; cr[dt][1] = c2.y;
-            const float2 a2 = *reinterpret_cast<const float2*>(sxp + (d0 >> 1));
-            const float2 b2 = *reinterpret_cast<const float2*>(syp + (d0 >> 1));
-            dx[dt][0] = a2.x; dx[dt][1] = a2.y;
-            dy[dt][0] = b2.x; dy[dt][1] = b2.y;
-        }
-        {
-            const bool row = key < p.N, img = row && key >= p.E;
-            T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
-            T* dvp = dkp + C;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int d0 = dt * 16 + 4 * g;
-                const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
-                if (row) {
-                    store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
-                    store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-                }
-                gp[dt][0] = img ? dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1] : 0.f;
-                gp[dt][1] = img ? dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3] : 0.f;
-            }
-            if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
-        }
+        dkv_epilogue<T>(p, dk, dv, kb, ld, C, b, head, key, s, g, fl);
         ATT_T(4);
     }
     if (p.E < p.N) freq_flush<true>(fl, p.fpart);
@@ -1227,7 +1303,8 @@ extern "C" int lnx_attn_fwd(const lnx_attn_args* a, void* stream) {
             set_lds(attn_fwd_res_kernel<T>, 256 * (AT<T>::ROWB + AT<T>::TRB));
             once = true;
         }
-        hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds, st, p);
+        if (a->N <= 64) hipLaunchKernelGGL((attn_fwd_res_kernel<T, 4>), dim3(a->B * a->heads), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((attn_fwd_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds, st, p);
     } else if (a->dtype == LNX_BF16) {
         const size_t lds = AT<bf16_t>::ROW_IMG + AT<bf16_t>::TR_IMG;
         if (tiled_nw8(a->N)) {  // 128 queries per workgroup
@@ -1292,8 +1369,13 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
             set_lds(attn_bwd_dkv_res_kernel<T>, 256 * (2 * AT<T>::TRB + 2 * sizeof(float)));
             once = true;
         }
-        hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_q, st, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_k, st, p);
+        if (a->N <= 64) {
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T, 4>), dim3(a->B * a->heads), dim3(256), lds_q, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<T, 4>), dim3(a->B * a->heads), dim3(256), lds_k, st, p);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_q, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<T>), dim3(a->B * a->heads), dim3(512), lds_k, st, p);
+        }
         reduce_freqs(1);
     } else if (a->dtype == LNX_BF16) {
         typedef bf16_t T;

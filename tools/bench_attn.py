@@ -1,4 +1,4 @@
-"""Attention forward / backward at the mFormerV1_sm stage-3 / stage-4 shapes (B = 256); run it under
+"""Attention forward / backward at the mFormerV1_sm stage-3 / stage-4 shapes (B = 256) and the lg @384 stage-3 shape (B = 64); run it under
 `rocprofv3 --kernel-trace --stats` for per-kernel times (the backward is two kernels + the freqs-gradient reduce)."""
 import os
 import sys
@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from linnaeus_amd import ops
 
-for B, H, W, E, heads in ((256, 14, 14, 3, 6), (256, 7, 7, 3, 12)):
+for B, H, W, E, heads in ((256, 14, 14, 3, 6), (256, 7, 7, 3, 12), (64, 24, 24, 4, 12)):
     N = H * W + E
     Cc = heads * 64
     qkv = torch.randn(B * N, 3 * Cc, device="cuda").bfloat16()
