@@ -642,8 +642,16 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
 
     const unsigned char* src[NINS];
     int64_t step[NINS];
+    // PATCH: the patch origin of contraction row m = (b, ho, wo) of a 2x2 / stride-2 gather from [B, Hin, Win, Cin] is
+    // 2 Cin (m + (m / Wo) Wo) elements into the source (Hin = 2 Ho, Win = 2 Wo), so a piece keeps r = m % Wo and
+    // po = m + (m / Wo) Wo and advances both by additions when m moves on by a contraction tile -- the closed form
+    // (two divisions and two remainders by run-time values per piece and tile) cost ~100 VALU instructions a piece.
+    int pr[NINS], po[NINS];
+    const int Wo = PATCH ? p.pg.Win >> 1 : 1;
+    const int qa = TBM / Wo, qb = TBM - qa * Wo;  // uniform
 #pragma unroll
     for (int j = 0; j < NINS; ++j) {
+        pr[j] = po[j] = 0;
         const int i = wave + 8 * j;
         if (i < RINS) {
             constexpr int CPR = RW / 8, RPI = 64 / CPR;  // chunks per row, rows per wave-instruction
@@ -664,7 +672,10 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
                 // stride is not constant), column k = (kh, kw, c) -> offset inside the patch; a 16-byte chunk never
                 // straddles a (kh) segment because 2 * Cin % 8 == 0
                 src[j] = p.A + patch_col(p.pg, col) * 2;
-                step[j] = m_begin + row;  // first contraction row of this piece
+                step[j] = (int64_t)p.pg.Cin * 4;  // bytes per unit of po
+                const int m = m_begin + row, t = m / Wo;
+                pr[j] = m - t * Wo;
+                po[j] = m + t * Wo;
             } else {
                 src[j] = p.A + ((int64_t)(m_begin + row) * p.lda + col) * 2;
                 step[j] = (int64_t)TBM * p.lda * 2;
@@ -677,8 +688,11 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
             const int i = wave + 8 * j;
             const unsigned char* gp = src[j];
             if (PATCH && i >= RINS) {
-                gp += patch_base(p.pg, (int)step[j]) * 2;
-                step[j] += TBM;
+                gp += (int64_t)po[j] * step[j];
+                const int r = pr[j] + qb;
+                const bool wrap = r >= Wo;
+                pr[j] = wrap ? r - Wo : r;
+                po[j] += TBM + (qa + (wrap ? 1 : 0)) * Wo;
             } else {
                 src[j] += step[j];
             }
