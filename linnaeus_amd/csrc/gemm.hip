@@ -385,7 +385,9 @@ extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     p.tiles_m = cdiv(a->M, TILE);
     p.tiles_n = cdiv(a->N, TILE);
     hipStream_t st = (hipStream_t)stream;
-    if (nt_v2_ok(p, a->dtype) && !g_force_v1) {
+    if (nt_skinny_ok(p, a->dtype, a->out_f32 != 0) && !g_force_v1) {
+        launch_nt_skinny(p, a->out_f32 != 0, st);
+    } else if (nt_v2_ok(p, a->dtype) && !g_force_v1) {
         launch_nt_v2(p, a->out_f32 != 0, st);
     } else if (a->dtype == LNX_BF16) {
         if (a->out_f32) launch_nt<bf16_t, true>(p, st);

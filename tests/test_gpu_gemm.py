@@ -61,6 +61,24 @@ def test_nt_plain(M, N, K, dtype):
         torch.testing.assert_close(out2.float(), ref.float(), rtol=8e-3, atol=8e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 1000, 384), (256, 384, 1000), (256, 20, 384), (256, 384, 24), (200, 33, 304), (7, 5, 8), (256, 300, 40), (32, 32, 32)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_nt_skinny_batch_rows(M, N, K, with_res):
+    """M <= 256 in bf16 (the classification heads and their data gradients) takes the one-wave-per-tile kernel of
+    gemm_skinny.hip: K tails that are not a multiple of 32, N tails, bias, fp32 residual, both output types."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g).cuda().bfloat16()
+    W = (torch.randn(N, K, generator=g) / K**0.5).cuda().bfloat16()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if with_res else None
+    out, _ = run_nt(A, W, L.BF16, True, bias=b, res=res)
+    ref = A.double() @ W.double().T + b.double() + (res.double() if with_res else 0.0)
+    torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=8e-5)
+    if not with_res:
+        out2, _ = run_nt(A, W, L.BF16, False)
+        torch.testing.assert_close(out2.float(), (A.double() @ W.double().T).float(), rtol=8e-3, atol=8e-3)
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_nt_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches row/col swaps in the C write."""
