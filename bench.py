@@ -354,7 +354,7 @@ def main():
             return loss
         model.zero_grad(set_to_none=True)
         out = net(x, meta)
-        loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE, one HIP launch per task
+        loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE: one HIP launch for all tasks
         loss.backward()
         if opt is not None:
             opt.step()

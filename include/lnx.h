@@ -370,6 +370,10 @@ typedef struct lnx_softce_args {
     int64_t ldd;
 } lnx_softce_args;
 int lnx_softce(const lnx_softce_args* args, void* stream);
+/* n <= LNX_SOFTCE_MAX_TASKS independent argument sets (the tasks of the multi-task criterion: train.py's per-task loop over
+ * `criteria`, loss/hierarchical_loss.py:130-190) in ONE launch */
+#define LNX_SOFTCE_MAX_TASKS 8
+int lnx_softce_multi(const lnx_softce_args* args, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * GPU-side batch mixing of the collate step: selective Mixup / CutMix and the metadata chunk pick.

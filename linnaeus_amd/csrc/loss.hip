@@ -21,9 +21,8 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return r;
 }
 
-__global__ __launch_bounds__(256) void softce_kernel(const lnx_softce_args a) {
+__device__ __forceinline__ void softce_row(const lnx_softce_args& a, const int b) {
     __shared__ float red[4];
-    const int b = blockIdx.x;
     const float* x = a.logits + (int64_t)b * a.ld;
     const int64_t t = a.target[b];
     const bool bad = t < 0 || t >= a.C;  // out-of-range targets produce NaN loss and zero gradient (the host checks them when asked to)
@@ -64,7 +63,36 @@ __global__ __launch_bounds__(256) void softce_kernel(const lnx_softce_args a) {
     }
 }
 
+__global__ __launch_bounds__(256) void softce_kernel(const lnx_softce_args a) { softce_row(a, blockIdx.x); }
+
+// all tasks of a multi-task criterion in one launch: blockIdx.y = task (the arguments travel in the kernel-argument segment)
+struct SoftceMulti {
+    lnx_softce_args a[LNX_SOFTCE_MAX_TASKS];
+};
+__global__ __launch_bounds__(256) void softce_multi_kernel(const SoftceMulti m) {
+    const lnx_softce_args& a = m.a[blockIdx.y];
+    if ((int)blockIdx.x < a.B) softce_row(a, blockIdx.x);
+}
+
 }  // namespace
+
+extern "C" int lnx_softce_multi(const lnx_softce_args* args, int n, void* stream) {
+    LNX_CHECK(args && n > 0 && n <= LNX_SOFTCE_MAX_TASKS, "lnx_softce_multi: 1..%d argument sets, got %d", LNX_SOFTCE_MAX_TASKS, n);
+    SoftceMulti m;
+    int bmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const lnx_softce_args* a = args + i;
+        LNX_CHECK(a->logits && a->target, "lnx_softce_multi: null operand in set %d", i);
+        LNX_CHECK(a->B > 0 && a->C > 0 && a->ld >= a->C, "lnx_softce_multi: bad shape B=%d C=%d ld=%lld in set %d", a->B, a->C, (long long)a->ld, i);
+        LNX_CHECK(a->dlogits == nullptr || a->ldd >= a->C, "lnx_softce_multi: ldd < C in set %d", i);
+        LNX_CHECK(a->smoothing >= 0.f && a->smoothing < 1.f, "lnx_softce_multi: smoothing must be in [0, 1)");
+        m.a[i] = *a;
+        bmax = a->B > bmax ? a->B : bmax;
+    }
+    hipLaunchKernelGGL(softce_multi_kernel, dim3(bmax, n), dim3(256), 0, (hipStream_t)stream, m);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int lnx_softce(const lnx_softce_args* a, void* stream) {
     LNX_CHECK(a && a->logits && a->target, "lnx_softce: null operand");

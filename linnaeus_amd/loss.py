@@ -22,10 +22,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _launch(logits, target, soft, smoothing, class_weight, ignore_index, row_scale, scale, loss, loss_sum, dlogits):
+def _fill(a, logits, target, soft, smoothing, class_weight, ignore_index, row_scale, scale, loss, loss_sum, dlogits):
     if not logits.is_cuda:
         raise L.LnxError("linnaeus_amd.loss has no CPU path: logits must be on the GPU")
-    a = L.SoftCEArgs()
     a.B, a.C = logits.shape
     a.logits, a.ld = _ptr(logits), logits.stride(0)
     a.target = _ptr(target)
@@ -35,7 +34,26 @@ def _launch(logits, target, soft, smoothing, class_weight, ignore_index, row_sca
     a.row_scale, a.scale = _ptr(row_scale), float(scale)
     a.loss, a.loss_sum = _ptr(loss), _ptr(loss_sum)
     a.dlogits, a.ldd = _ptr(dlogits), (dlogits.stride(0) if dlogits is not None else 0)
+
+
+def _launch(*args):
+    a = L.SoftCEArgs()
+    _fill(a, *args)
     L.check(L.lib().lnx_softce(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lnx_softce")
+
+
+SOFTCE_MAX_TASKS = 8  # == LNX_SOFTCE_MAX_TASKS
+
+
+def _launch_multi(sets):
+    """`sets`: argument tuples of _fill, at most SOFTCE_MAX_TASKS per launch"""
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for i0 in range(0, len(sets), SOFTCE_MAX_TASKS):
+        chunk = sets[i0:i0 + SOFTCE_MAX_TASKS]
+        arr = (L.SoftCEArgs * len(chunk))()
+        for a, args in zip(arr, chunk):
+            _fill(a, *args)
+        L.check(L.lib().lnx_softce_multi(arr, len(chunk), st), "lnx_softce_multi")
 
 
 def _as_rows(logits):
@@ -128,19 +146,32 @@ class _MultiCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, targets, smoothing, *logits):
         total = torch.zeros((), device=logits[0].device, dtype=torch.float32)
-        grads = []
-        for w, t, lg in zip(weights, targets, logits):
-            x = _as_rows(lg)
-            d = torch.empty_like(x) if lg.requires_grad else None
-            _launch(x, t, None, smoothing, None, None, None, w / x.shape[0], None, total, d)
+        xs = [_as_rows(lg) for lg in logits]
+        # the gradients of all tasks live in one flat buffer: one launch fills them, one multiply scales them in backward
+        sizes = [x.numel() if lg.requires_grad else 0 for x, lg in zip(xs, logits)]
+        flat = torch.empty(sum(sizes), device=total.device, dtype=torch.float32) if any(sizes) else None
+        grads, sets, off = [], [], 0
+        for w, t, x, n in zip(weights, targets, xs, sizes):
+            d = flat[off:off + n].view_as(x) if n else None
+            off += n
+            sets.append((x, t, None, smoothing, None, None, None, w / x.shape[0], None, total, d))
             grads.append(d)
-        ctx.grads = grads
+        _launch_multi(sets)
+        ctx.flat, ctx.sizes = flat, sizes
+        ctx.shapes = [x.shape for x in xs]
         ctx.dtypes = [lg.dtype for lg in logits]
         return total
 
     @staticmethod
     def backward(ctx, go):
-        return (None, None, None) + tuple((g * go).to(dt) if g is not None else None for g, dt in zip(ctx.grads, ctx.dtypes))
+        if ctx.flat is None:
+            return (None, None, None) + (None,) * len(ctx.sizes)
+        scaled = ctx.flat * go
+        out, off = [], 0
+        for n, shp, dt in zip(ctx.sizes, ctx.shapes, ctx.dtypes):
+            out.append(scaled[off:off + n].view(shp).to(dt) if n else None)
+            off += n
+        return (None, None, None) + tuple(out)
 
 
 def multitask_cross_entropy(outputs: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor], task_weights: Optional[Dict[str, float]] = None,
