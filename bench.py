@@ -371,6 +371,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0  # the host's share: Python + launch calls, returned before the GPU has finished
     torch.cuda.synchronize()
     if dist:
         dist.barrier(device_ids=[local])
@@ -473,6 +474,7 @@ def main():
     line = {
         "metric": f"images/sec (train fwd+bwd) mFormerV1_{args.arch} 3x{args.img}x{args.img}",
         "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"mFormerV1_{args.arch} train step (forward + 4-task CE loss + backward"

@@ -1414,6 +1414,7 @@ int downsample_bwd(const Ctx& c, int i, const float* gout, int64_t ldg, lnx_rowm
     w.dtype = c.dt; w.M = Mout; w.N = Cout; w.K = 4 * Cin;
     w.dY = sC; w.lddy = Cout; w.A = c.at<void>(d.ln); w.a_mode = LNX_ADDR_PATCH2; w.Hin = Hin; w.Win = Win; w.Cin = Cin;
     w.dW = p->G[d.w.param]; w.lddw = 4 * Cin; w.k_perm_c = Cin; w.db = p->G[d.cb];
+    w.ws = c.at<float>(p->o_tnws); w.ws_floats = LNX_TN_WS_FLOATS;  // split-K partials through the workspace + reduce kernel, not by atomics (main stream only)
     {
         Timed t(c, 1, 2.0 * Mout * Cout * 4 * Cin);
         RUN(lnx_gemm_tn(&w, c.st));
