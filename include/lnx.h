@@ -292,6 +292,28 @@ int lnx_attn_bwd(const lnx_attn_bwd_args* args, void* stream);
  * k = c*16 + kh*4 + kw (torch conv weight order), zero padded to ldp (mFormerV1.py:146) */
 int lnx_im2col_stem(const float* x, int B, int Cin, int H, int W, void* patches, int dtype, int ldp, void* stream);
 
+/* The whole stem in one launch (bf16 compute type; csrc/stem.hip): nn.Conv2d(in_chans, dims[0], 4, 4) + bias, output rounded
+ * to bf16 as under autocast, then LayerNorm(dims[0], eps, "channels_first") -- mFormerV1.py:145-148.  Writes the fp32
+ * normalised rows `y` and, when asked (training plans), what the backward reads: the bf16 patch matrix [M, 64] of
+ * lnx_im2col_stem, the bf16 pre-norm tensor [M, Cout] and the row statistics.  lnx_stem_fwd_ok() tells whether the geometry is
+ * covered (Cin <= 4, H and W multiples of 4, Cout in {96, 128, 192, 256}); otherwise im2col + lnx_gemm_nt + lnx_layernorm_fwd. */
+typedef struct lnx_stem_args {
+    const float* x;      /* [B, Cin, H, W] fp32 */
+    const void* w;       /* bf16 [Cout, 64], column k = c*16 + kh*4 + kw */
+    const float* bias;   /* [Cout] */
+    const float* ln_w;   /* [Cout] */
+    const float* ln_b;   /* [Cout] */
+    void* patches;       /* bf16 [M, 64] or NULL */
+    void* pre;           /* bf16 [M, Cout] or NULL */
+    float* y;            /* fp32 [M, Cout], M = B * H/4 * W/4 */
+    float* mean;         /* [M] or NULL (with rstd) */
+    float* rstd;
+    int B, Cin, H, W, Cout;
+    float eps;
+} lnx_stem_args;
+int lnx_stem_fwd_ok(int dtype, int Cin, int H, int W, int Cout);
+int lnx_stem_fwd(const lnx_stem_args* args, void* stream);
+
 /* out[m, :] = rowscale[m / rows_per_sample] * in[map(m), :]   (fp32 in, T or fp32 out) */
 int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float* rowscale, int rows_per_sample, void* out,
                    int out_dtype, int64_t ldout, int M, int C, void* stream);

@@ -120,7 +120,7 @@ EXPORTS = [
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_fill_rows", "lnx_colsum_rows",
-    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
     "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd",
@@ -217,6 +217,12 @@ class ConvMlpBwdArgs(C.Structure):
         ("w2t", C.c_void_p), ("w1t", C.c_void_p), ("gamma", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
         ("act", C.c_void_p), ("dh", C.c_void_p), ("dz", C.c_void_p), ("dln", C.c_void_p), ("dgamma", C.c_void_p),
     ]
+
+
+class StemArgs(C.Structure):  # == lnx_stem_args
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("patches", C.c_void_p),
+                ("pre", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("B", C.c_int), ("Cin", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("Cout", C.c_int), ("eps", C.c_float)]
 
 
 class MixArgs(C.Structure):

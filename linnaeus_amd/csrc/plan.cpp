@@ -1189,15 +1189,28 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
 
     // 1. stem: 4x4/4 patchify conv as im2col + GEMM, then channels-first LN (mFormerV1.py:145-148)
     const int M0 = B * p->HW[0];
-    RUN(lnx_im2col_stem(x, B, cf.in_chans, cf.img_h, cf.img_w, c.at<void>(p->o_patches), cf.dtype, 64, stream));
-    {
-        lnx_gemm_args g = gemm_base(c, M0, D[0], 64, c.at<void>(p->o_patches), 64, c.wptr(p->stem_w), 64, c.at<void>(p->o_stem_pre), D[0], false);
-        g.bias = p->P[p->stem_b];
-        RUN(gemm_nt_t(c, &g));
-    }
     float* first = cf.conv_depths[0] > 0 ? c.at<float>(p->conv[0][0].xin) : c.at<float>(p->o_stage_out[0]);
-    RUN(ln_fwd(c, M0, D[0], 1e-6f, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, first, LNX_F32, D[0], IDM, nullptr, 0,
-               c.at<float>(p->o_stem_mean), c.at<float>(p->o_stem_rstd)));
+    if (lnx_stem_fwd_ok(cf.dtype, cf.in_chans, cf.img_h, cf.img_w, D[0])) {
+        lnx_stem_args sa;
+        memset(&sa, 0, sizeof sa);
+        sa.x = x; sa.w = c.wptr(p->stem_w); sa.bias = p->P[p->stem_b]; sa.ln_w = p->P[p->stem_lnw]; sa.ln_b = p->P[p->stem_lnb];
+        sa.y = first;
+        if (!cf.inference) {  // what the backward reads
+            sa.patches = c.at<void>(p->o_patches); sa.pre = c.at<void>(p->o_stem_pre);
+            sa.mean = c.at<float>(p->o_stem_mean); sa.rstd = c.at<float>(p->o_stem_rstd);
+        }
+        sa.B = B; sa.Cin = cf.in_chans; sa.H = cf.img_h; sa.W = cf.img_w; sa.Cout = D[0]; sa.eps = 1e-6f;
+        RUN(lnx_stem_fwd(&sa, stream));
+    } else {
+        RUN(lnx_im2col_stem(x, B, cf.in_chans, cf.img_h, cf.img_w, c.at<void>(p->o_patches), cf.dtype, 64, stream));
+        {
+            lnx_gemm_args g = gemm_base(c, M0, D[0], 64, c.at<void>(p->o_patches), 64, c.wptr(p->stem_w), 64, c.at<void>(p->o_stem_pre), D[0], false);
+            g.bias = p->P[p->stem_b];
+            RUN(gemm_nt_t(c, &g));
+        }
+        RUN(ln_fwd(c, M0, D[0], 1e-6f, c.at<void>(p->o_stem_pre), cf.dtype, D[0], IDM, p->stem_lnw, p->stem_lnb, first, LNX_F32, D[0], IDM, nullptr, 0,
+                   c.at<float>(p->o_stem_mean), c.at<float>(p->o_stem_rstd)));
+    }
 
     // 2. ConvNeXt stages + downsamplers (mFormerV1.py:427-443)
     for (int s = 0; s < 2; ++s) {

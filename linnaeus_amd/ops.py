@@ -255,6 +255,16 @@ def im2col_stem(x, patches):
     L.check(L.lib().lnx_im2col_stem(_p(x), B, Cin, H, W, _p(patches), code_of(patches), patches.stride(0), _stream()), "lnx_im2col_stem")
 
 
+def stem_fwd(x, w, bias, ln_w, ln_b, y, *, patches=None, pre=None, mean=None, rstd=None, eps=1e-6):
+    """conv 4x4/4 + bias (bf16 output) + channels-first LayerNorm in one launch: x fp32 [B, Cin, H, W], w bf16 [Cout, 64]"""
+    a = L.StemArgs()
+    a.x, a.w, a.bias, a.ln_w, a.ln_b = _p(x), _p(w), _p(bias), _p(ln_w), _p(ln_b)
+    a.patches, a.pre, a.y, a.mean, a.rstd = _p(patches), _p(pre), _p(y), _p(mean), _p(rstd)
+    a.B, a.Cin, a.H, a.W = x.shape
+    a.Cout, a.eps = w.shape[0], eps
+    L.check(L.lib().lnx_stem_fwd(C.byref(a), _stream()), "lnx_stem_fwd")
+
+
 def scale_cast(inp, out, M, Cc, *, ldin=None, in_map=None, rowscale=None, rows_per_sample=0, ldout=None):
     L.check(L.lib().lnx_scale_cast(_p(inp), C.c_int64(ldin if ldin is not None else inp.stride(-2)), _map(in_map), _p(rowscale), rows_per_sample,
                                    _p(out), code_of(out), C.c_int64(ldout if ldout is not None else out.stride(-2)), M, Cc, _stream()), "lnx_scale_cast")

@@ -538,3 +538,36 @@ def test_layernorm_fused_mxfp8_output(M, C):
     assert torch.equal(sc, rs)
     assert torch.equal(y8, r8.view(torch.uint8))
     torch.testing.assert_close(mean, x.mean(-1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(3, 3, 56, 72, 96), (2, 3, 32, 32, 192), (1, 4, 16, 20, 128), (2, 1, 64, 64, 256), (40, 3, 224, 224, 96)])
+def test_fused_stem_matches_conv_and_layernorm(B, Cin, H, W, Cout):
+    """lnx_stem_fwd (round 3) against torch: conv2d 4x4/4 on bf16-rounded operands, output rounded to bf16, channels-first
+    LayerNorm in fp32; its patch matrix against lnx_im2col_stem's bit for bit.  The last case is large enough for the
+    8-tiles-per-wave launch."""
+    g = torch.Generator().manual_seed(B + H + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).cuda()
+    w4 = (torch.randn(Cout, Cin, 4, 4, generator=g) / (Cin * 16) ** 0.5).cuda()
+    bias, lw, lb = (torch.randn(Cout, generator=g).cuda() for _ in range(3))
+    wq = torch.full((Cout, 64), float("nan"), device="cuda", dtype=torch.bfloat16)  # the padding columns must not matter
+    wq[:, :Cin * 16] = w4.reshape(Cout, -1).bfloat16()
+    M = B * (H // 4) * (W // 4)
+    y = torch.empty(M, Cout, device="cuda")
+    pre = torch.empty(M, Cout, device="cuda", dtype=torch.bfloat16)
+    patches = torch.empty(M, 64, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.stem_fwd(x, wq, bias, lw, lb, y, patches=patches, pre=pre, mean=mean, rstd=rstd)
+    ref_p = torch.zeros_like(patches)
+    ops.im2col_stem(x, ref_p)
+    assert torch.equal(patches[:, :Cin * 16], ref_p[:, :Cin * 16]) and not patches.float().abs()[:, Cin * 16:].any()
+    conv = torch.nn.functional.conv2d(x.bfloat16().double(), w4.bfloat16().double(), stride=4) + bias.double()[None, :, None, None]
+    conv = conv.permute(0, 2, 3, 1).reshape(M, Cout)
+    torch.testing.assert_close(pre.double(), conv, rtol=8e-3, atol=8e-3)
+    pf = pre.double()
+    mu, var = pf.mean(1, keepdim=True), pf.var(1, unbiased=False, keepdim=True)
+    torch.testing.assert_close(y.double(), (pf - mu) / (var + 1e-6).sqrt() * lw.double() + lb.double(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(mean.double(), mu[:, 0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd.double(), 1 / (var[:, 0] + 1e-6).sqrt(), rtol=2e-5, atol=1e-6)
+    y2 = torch.empty_like(y)
+    ops.stem_fwd(x, wq, bias, lw, lb, y2)  # inference form: nothing but y
+    assert torch.equal(y, y2)
