@@ -481,6 +481,12 @@ static bool nt_v7_preferred(const GemmP& p, int f, bool out_f32) {
     return two_per_cu;
 }
 
+// default choice (LNX_NT_V8 unset): from the measurements of tools/bench_gemm_epi.py
+static bool nt_v8_preferred(const GemmP& p, int f, bool out_f32) {
+    (void)p; (void)f; (void)out_f32;
+    return false;
+}
+
 static bool nt_v4_ok(const GemmP& p, int f) {
     static const bool off = getenv("LNX_NT_V4") && atoi(getenv("LNX_NT_V4")) == 0;  // A/B switch for benchmarking
     if (off || f == (int)F_GENERIC || p.a_mode == LNX_ADDR_PATCH2) return false;
@@ -503,6 +509,12 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     const bool patch = p.a_mode == LNX_ADDR_PATCH2;
     static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
     const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+    // LNX_NT_V8: 1 = every shape the kernel with epilogue waves can run, 0 = never, unset = the measured choice
+    {
+        const char* e8 = getenv("LNX_NT_V8");
+        const int v8 = e8 ? atoi(e8) : -1;
+        if (v8 != 0 && nt_v8_ok(p, f, out_f32) && (v8 == 1 || nt_v8_preferred(p, f, out_f32))) return launch_nt_v8(p, f, out_f32, st);
+    }
     // LNX_NT_V7: 1 = every shape the persistent deferred-store kernel can run, 0 = never, unset = the measured choice
     {
         const char* e7 = getenv("LNX_NT_V7");

@@ -455,6 +455,10 @@ struct WgradP {
 bool nt_v7_ok(const GemmP& p, int f, bool out_f32);
 int launch_nt_v7(const GemmP& p, int f, bool out_f32, hipStream_t st);
 
+// gemm4.hip: persistent 256x128 kernel with the epilogue on its own waves
+bool nt_v8_ok(const GemmP& p, int f, bool out_f32);
+int launch_nt_v8(const GemmP& p, int f, bool out_f32, hipStream_t st);
+
 // gemm_skinny.hip: M <= 256 (one wave per 32x32 output tile, operands straight from L2)
 bool nt_skinny_ok(const GemmP& p, int dtype, bool out_f32);
 int launch_nt_skinny(const GemmP& p, bool out_f32, hipStream_t st);

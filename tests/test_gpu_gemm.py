@@ -314,9 +314,21 @@ def test_nt_specialised_epilogues(kind, N):
     else:
         res = torch.randn(M, N, generator=g).cuda()
         rs = (torch.rand(523, generator=g) > 0.3).float().cuda() / 0.7
-        out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
         ref = res.double() + z * rs.double().repeat_interleave(256)[:, None]
-        torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
+        import os
+        saved = os.environ.get("LNX_NT_V8")
+        try:
+            os.environ["LNX_NT_V8"] = "0"  # the kernels that add the fp32 accumulator to the residual
+            out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
+            torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
+            os.environ["LNX_NT_V8"] = "1"  # epilogue waves: the product is rounded to bf16 first (a Linear's output under autocast)
+            out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
+            torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=8e-3 * float(z.abs().max()) / 0.7)
+        finally:
+            if saved is None:
+                os.environ.pop("LNX_NT_V8", None)
+            else:
+                os.environ["LNX_NT_V8"] = saved
 
 
 @pytest.mark.parametrize("M,N,K,kpc", [(8192, 96, 384, 0), (12800, 384, 1536, 0), (50944, 1536, 384, 0), (6400, 1000, 768, 0), (8192, 192, 384, 96)])

@@ -34,12 +34,13 @@ def time_it(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-modes = sys.argv[1:] or ["base", "v7"]  # "base" (8-wave kernels), "v7" (persistent deferred-store kernel), "v5[:stagger[:one]]"
+modes = sys.argv[1:] or ["base", "v7", "v8"]  # "base" (8-wave kernels), "v7" (persistent deferred-store kernel), "v8" (epilogue waves), "v5[:stagger[:one]]"
 
 
 def setmode(m):
     name, _, rest = m.partition(":")
     os.environ["LNX_NT_V7"] = "1" if name == "v7" else "0"
+    os.environ["LNX_NT_V8"] = "1" if name == "v8" else "0"
     os.environ["LNX_NT_V5"] = "1" if name == "v5" else "0"
     sg, _, one = rest.partition(":")
     os.environ["LNX_V5_STAGGER"] = sg or "0"
