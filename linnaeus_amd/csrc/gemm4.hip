@@ -49,6 +49,20 @@ __device__ __forceinline__ int img_key(int row) { return (row & 3) | (((row >> 4
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));  // a register vector: usable as an inline-asm "+v" operand
 __device__ __forceinline__ void v8_load16(u32x4_t& d, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr) : "memory"); }
 
+// Diagnostic build only (-DV8_STAMP, tools/build_v8_stamp.sh): per-phase s_memtime sums of wave 0 (K loop) and wave 4 (epilogue)
+// of one workgroup, written to the buffer LNX_V8_STAMPS names
+#ifdef V8_STAMP
+#define V8_T(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                     __builtin_amdgcn_sched_barrier(0); tsum[i] += t_ - tlast; tlast = t_; } while (0)
+#define V8_T0() unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory")
+#define V8_TOUT(base) do { unsigned long long* sp_ = reinterpret_cast<unsigned long long*>(p.C8s); \
+                           if (sp_ && blockIdx.x == gridDim.x / 2 && lane == 0) for (int i_ = 0; i_ < 8; ++i_) sp_[(base) + i_] = tsum[i_]; } while (0)
+#else
+#define V8_T(i) do { } while (0)
+#define V8_T0() do { } while (0)
+#define V8_TOUT(base) do { } while (0)
+#endif
+
 template <bool OUT_F32, int F>
 __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
     typedef bf16_t T;
@@ -116,12 +130,35 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
         };
 #pragma unroll
         for (int j = 0; j < PIECES8; ++j) src[j] = piece_offset(j, m0, n0);
+        auto issue_piece = [&](bool of_next, int kslice, int stage, int j) __attribute__((always_inline)) {  // j: compile-time at every call site
+            const int i = wave + 4 * j;
+            const unsigned char* base = 16 * i < BM8 ? p.A : p.W;
+            const uint32_t so = of_next ? srcn[j] : src[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (so + (uint32_t)(kslice * BK8 * 2))),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE8 + i * 1024), 16, 0, 0);
+        };
+        // The software pipeline of one K-loop wave.  At the top of iteration kt: the fragments of slice kt are in registers, slice
+        // kt + 1 is complete in LDS (stage r + 1), slice kt + 2 is on its way (stage r + 2), stage r is free.  The iteration
+        // multiplies slice kt while it reads slice kt + 1's fragments -- each A fragment into the registers of the one the last
+        // four MFMAs have just consumed, the W fragments into a second set -- and issues slice kt + 3 into stage r, one LDS-DMA
+        // piece between MFMA groups: L2 feed, LDS reads and the matrix pipe run together instead of one after the other
+        // (measured on the first version: 474 + 339 + 577 cycles per iteration in sequence).
         if (F & F_BIAS) fetch_bias(n0);
         issue(false, 0, 0);
         issue(false, 1, 1);
-        int ring = 0;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8) : "memory");  // slice 0 (and the bias) landed, slice 1 may be in flight
+        issue(false, 2, 2);
+        uint4 wfa[4], wfb[4], af[8];
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES8) : "memory");  // slice 0 (and the bias) landed
         __builtin_amdgcn_s_barrier();
+        V8_READ4(wfa, lds_base + w_off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(lds_base + a_off), "i"((i >> 2) * 64 * ROWB8 + (i & 3) * 256) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8) : "memory");  // slice 1 landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int ring = 0;  // stage of the slice whose fragments are in registers
+        V8_T0();
 
         while (true) {
             const int next = tile + gridDim.x;
@@ -149,45 +186,44 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
                     acc1[ni][mi] = b;
                 }
             }
-            for (int kt = 0; kt < nk; ++kt) {
-                const uint32_t st = lds_base + ring * STAGE8;
-                uint4 wf[4], af0[4], af1[4];
-                V8_READ4(wf, st + w_off);
-                V8_READ4(af0, st + a_off);
-                V8_READ4(af1, st + a_off + 64 * ROWB8);
-                const int stage2 = ring == 0 ? 2 : ring - 1;  // (ring + 2) % 3: read in the previous iteration, behind its barrier
-                if ((F & F_BIAS) && kt == nk - 3 && has_next) {
-                    fetch_bias(nn0);
-                    asm volatile("" ::: "memory");
-                    issue(false, kt + 2, stage2);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8 + 4) : "memory");
-                } else if (kt + 2 < nk) {
-                    issue(false, kt + 2, stage2);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8) : "memory");
-                } else if (has_next) {
-                    issue(true, kt + 2 - nk, stage2);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            auto kiter = [&](const int kt, uint4 (&wfc)[4], uint4 (&wfn)[4]) __attribute__((always_inline)) {
+                const int r1 = ring == 2 ? 0 : ring + 1;
+                const uint32_t stn = lds_base + r1 * STAGE8;
+                // what goes into the freed stage: slice kt + 3 of this tile, of the next one, or nothing (the last tile's tail)
+                const int ks = kt + 3;
+                const bool cur = ks < nk, any = cur || has_next;
+                if ((F & F_BIAS) && kt == nk - 4 && has_next) fetch_bias(nn0);  // in front of this iteration's pieces: its closing wait covers them
+                V8_READ4(wfn, stn + w_off);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        if (i < 4) Mfma<T>::run(acc0[ni][i], wfc[ni], af[i]);
+                        else Mfma<T>::run(acc1[ni][i - 4], wfc[ni], af[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[i]) : "v"(stn + a_off), "i"((i >> 2) * 64 * ROWB8 + (i & 3) * 256) : "memory");
+                    if (i < PIECES8 && any) issue_piece(!cur, cur ? ks : ks - nk, ring, i);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                V8_T(0);  // MFMAs, fragment reads and LDS-DMA pieces issued
+                if (any) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES8) : "memory");  // own pieces of slice kt + 2 landed
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                V8_T(1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();  // slice kt + 1 is in LDS for everyone; everyone is done reading slice kt
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc0[ni][mi], wf[ni], af0[mi]);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                ring = ring == 2 ? 0 : ring + 1;
+                V8_T(2);
+                __builtin_amdgcn_s_barrier();
+                V8_T(3);
+                ring = r1;
+            };
+            for (int kt = 0; kt < nk; kt += 2) {  // nk is even: the W fragment sets swap roles every iteration
+                kiter(kt, wfa, wfb);
+                kiter(kt + 1, wfb, wfa);
             }
             // ---- hand-over: lane (s, g) holds, for row slot mi, columns wn 64 + 16 g .. + 15 of row wm 128 + a 64 + frag_row + 4 mi
             __builtin_amdgcn_s_barrier();  // the epilogue waves are done with the previous image
+            V8_T(5);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -203,12 +239,14 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // the image is complete
+            V8_T(6);
             if (!has_next) break;
             tile = next;
             m0 = nm0;
             n0 = nn0;
             src = srcn;
         }
+        if (wave == 0) V8_TOUT(0);
         return;
     }
 
@@ -300,7 +338,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
 
     bool have_prev = false;
     int pm0 = 0, pn0 = 0;
-    __builtin_amdgcn_s_barrier();  // partner of the K-loop waves' prologue barrier
+    __builtin_amdgcn_s_barrier();  // partners of the K-loop waves' two prologue barriers
+    __builtin_amdgcn_s_barrier();
+    V8_T0();
     while (true) {
         const int next = tile + gridDim.x;
         const bool has_next = next < ntiles;
@@ -309,10 +349,13 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
                 const int u_lo = kt * UNITS8 / nk, u_hi = (kt + 1) * UNITS8 / nk;  // the previous tile's epilogue, spread over this K loop
                 for (int u = u_lo; u < u_hi; ++u) unit(u, pm0, pn0);
             }
+            V8_T(0);  // epilogue units
             __builtin_amdgcn_s_barrier();
+            V8_T(1);  // iteration barrier
         }
         __builtin_amdgcn_s_barrier();  // done with the previous image
         __builtin_amdgcn_s_barrier();  // the new image is complete
+        V8_T(2);
         have_prev = true;
         pm0 = m0;
         pn0 = n0;
@@ -321,11 +364,13 @@ __global__ __launch_bounds__(512) void gemm_nt_v8_kernel(const GemmP p) {
         tile_origin(tile, m0, n0);
     }
     for (int u = 0; u < UNITS8; ++u) unit(u, pm0, pn0);  // the last tile of this workgroup
+    V8_T(3);
+    if (wave == 4) V8_TOUT(8);
 }
 
 bool nt_v8_ok(const GemmP& p, int f, bool out_f32) {
     if (f == (int)F_GENERIC || p.a_mode == LNX_ADDR_PATCH2) return false;
-    if (p.K % BK8 != 0 || p.K / BK8 < 4) return false;
+    if (p.K % (2 * BK8) != 0 || p.K / BK8 < 4) return false;  // an even number of K slices (the W fragment sets alternate)
     const int64_t lim = (int64_t)1 << 31;  // 32-bit byte offsets of the LDS-DMA sources
     if ((int64_t)p.M * p.lda * 2 >= lim || (int64_t)p.N * p.ldw * 2 >= lim) return false;
     if (out_f32) return f == (F_BIAS | F_RES);
@@ -345,6 +390,10 @@ int launch_nt_v8(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
         cus = prop.multiProcessorCount;
     }
     const int grid = ntiles < cus ? ntiles : cus;  // persistent: one workgroup per CU
+#ifdef V8_STAMP
+    const char* sp = getenv("LNX_V8_STAMPS");  // device address of a 16 x uint64 buffer
+    p.C8s = sp ? reinterpret_cast<unsigned char*>(strtoull(sp, nullptr, 10)) : nullptr;
+#endif
 #define V8_LAUNCH(O, FF)                                                                                                              \
     do {                                                                                                                              \
         static bool attr = false;                                                                                                     \
