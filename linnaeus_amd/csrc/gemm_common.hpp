@@ -83,7 +83,7 @@ __device__ __forceinline__ int64_t patch_base(const PatchGeom& g, int m) {
 // offset inside a patch for patch-column k = (kh*2 + kw)*Cin + c
 __device__ __forceinline__ int64_t patch_col(const PatchGeom& g, int k) {
     const int two_c = 2 * g.Cin;
-    const int kh = k / two_c;
+    const int kh = k >= two_c ? 1 : 0;  // k < 4 Cin (checked by the host entry points): a compare, not a division by a run-time value
     return (int64_t)kh * g.Win * g.Cin + (k - kh * two_c);
 }
 
