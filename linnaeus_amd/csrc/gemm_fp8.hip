@@ -181,6 +181,294 @@ __global__ __launch_bounds__(512) void gemm_nt_fp8_kernel(const GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// MXFP8 on the 256x256 tile (round 3): the byte flow of gemm_nt_v4 (32 KiB stages of 64-BYTE rows, four of them, 8 waves with
+// 128x64 wave tiles in two ping-pong groups) with v_mfma_scale_f32_32x32x64_f8f6f4 -- a K slice is 64 e4m3 values = two MX blocks
+// per row, so a stage carries twice the work of a bf16 stage of the same size: the fill traffic per FLOP of the 256x128 fp8
+// kernel above is halved again.  Operand / scale layout of the instruction, checked with exact data
+// (tools/ubench/mfma_mx32_layout.hip): lane l = (r = l & 31, h = l >> 5) supplies row r; its dwords 0-3 belong to MX block 0 of
+// the slice, dwords 4-7 to block 1 (h picks the 16-byte half of the block: any order inside a block does, as long as A and W
+// agree); the scale of block kb of row r is byte 0 of lane (r + 32 kb)'s scale register; result register i of lane l is
+// D[8 (i / 4) + 4 h + i % 4][r].  The W rows of a 32-row block are loaded PERMUTED (MFMA row j <- block row
+// 16 ((j >> 2) & 1) + 4 (j >> 3) + (j & 3)) so that a lane's 16 results are 16 consecutive output columns.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int X8_BM = 256, X8_BN = 256, X8_BK = 64, X8_ROWB = 64;
+constexpr int X8_STAGE = (X8_BM + X8_BN) * X8_ROWB;  // 32 KiB
+constexpr int X8_SCALES = 512 * 4;                    // one dword (the four block scales of a 128-wide K span) per tile row
+constexpr int X8_NST = 4;
+constexpr int X8_PIECES = X8_STAGE / 1024 / 8;        // 4 LDS-DMA wave-instructions per wave and stage (+ 1 for the scales)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// chunk key of a 64-byte LDS row: conflict-free for 16 consecutive rows (the A fragments) and for the permuted W rows
+__device__ __forceinline__ int key_x8(int row) { return ((row >> 2) & 3) ^ (((row >> 4) & 1) << 1); }
+
+template <bool OUT_F32, int F>
+__device__ __forceinline__ void mx8_epilogue(const GemmP& p, f32x16_t (&acc)[2][4], int mrow0, int ncol0, int lane) {
+    typedef bf16_t T;
+    const int r = lane & 31, h = lane >> 5;
+    float bias[2][16];
+    if (F & F_BIAS) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(p.bias + ncol0 + 32 * nj + 16 * h + 4 * q);
+                bias[nj][4 * q] = t.x; bias[nj][4 * q + 1] = t.y; bias[nj][4 * q + 2] = t.z; bias[nj][4 * q + 3] = t.w;
+            }
+    }
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {  // two row blocks at a time: their operand fetches go out together
+        float ld[2][2][16];
+        float rs[2] = {1.f, 1.f};
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+            const int m = min(mrow0 + 32 * (2 * mp + mq) + r, p.M - 1);
+            if (F & F_RES) {
+                if (p.rowscale) rs[mq] = p.rowscale[m / p.rows_per_sample];
+            }
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int nb = ncol0 + 32 * nj + 16 * h;
+                if (F & F_GELU_BWD) {
+                    const T* ax = reinterpret_cast<const T*>(p.aux) + ((int64_t)m * p.ldaux + nb);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        Vec16<T> t;
+                        t.raw = ld16(ax + 8 * hh);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ld[mq][nj][8 * hh + j] = t.get(j);
+                    }
+                }
+                if (F & F_RES) {
+                    const float* rp = p.res + ((int64_t)m * p.ldres + nb);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+                        ld[mq][nj][4 * q] = t.x; ld[mq][nj][4 * q + 1] = t.y; ld[mq][nj][4 * q + 2] = t.z; ld[mq][nj][4 * q + 3] = t.w;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+            const int mj = 2 * mp + mq;
+            const int m = mrow0 + 32 * mj + r;
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+                const int nb = ncol0 + 32 * nj + 16 * h;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (F & F_BIAS) ? acc[nj][mj][i] + bias[nj][i] : acc[nj][mj][i];
+                const bool live = m < p.M;  // (the exchange of the MX output below needs every lane: no early exit)
+                if (F & F_C2) {
+                    if (live) {
+                        T* c2 = reinterpret_cast<T*>(p.C2) + ((int64_t)m * p.ldc2 + nb);
+                        Vec16<T> o;
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o.set(j, v[8 * hh + j]);
+                            st16(c2 + 8 * hh, o.raw);
+                        }
+                    }
+                }
+                if (F & F_GELU) Gelu<T>::fwd16(v);
+                if (F & F_GELU_BWD) Gelu<T>::mulgrad16(v, ld[mq][nj]);
+                if (F & F_RES) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = fmaf(v[j], rs[mq], ld[mq][nj][j]);
+                }
+                if (OUT_F32) {
+                    if (live) {
+                        float* cp = reinterpret_cast<float*>(p.C) + ((int64_t)m * p.ldc + nb);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(cp + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    }
+                } else {
+                    T* cp = reinterpret_cast<T*>(p.C) + ((int64_t)m * p.ldc + nb);
+                    Vec16<T> o;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o.set(j, v[8 * hh + j]);
+                        if (live) st16(cp + 8 * hh, o.raw);
+                        if (F & F_MXOUT) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[8 * hh + j] = o.get(j);  // the stored (rounded) values are what gets quantised
+                        }
+                    }
+                    if (F & F_MXOUT) {
+                        // a 32-element block = this lane's 16 columns and those of lane ^ 32 (same row, the other half)
+                        float am = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(v[j]));
+                        am = fmaxf(am, __shfl_xor(am, 32, 64));
+                        const uint32_t bits = __float_as_uint(am);
+                        int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                        e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                        const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+                        uint32_t w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * q] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * q + 1] * inv, -448.f), 448.f), 0, false);
+                            pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[4 * q + 2] * inv, -448.f), 448.f), fminf(fmaxf(v[4 * q + 3] * inv, -448.f), 448.f), pk, true);
+                            w[q] = (uint32_t)pk;
+                        }
+                        if (live) {
+                            st16(p.C8 + (int64_t)m * p.ldc8 + nb, make_uint4(w[0], w[1], w[2], w[3]));
+                            const int kb = nb >> 5;
+                            if (h == 0) p.C8s[((int64_t)(kb >> 2) * p.M + m) * 4 + (kb & 3)] = (unsigned char)e;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool OUT_F32, int F>
+__global__ __launch_bounds__(512) void gemm_nt_mx8_kernel(const GemmP p) {
+    constexpr int STAGE = X8_STAGE + X8_SCALES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [4][A 256 rows | W 256 rows][64 B] + [512] scale dwords
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;  // 128-row half, 64-column quarter; waves 0-3 / 4-7 = the ping-pong groups
+    const int r = lane & 31, h = lane >> 5;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int tn = logical % p.tiles_n;
+    const int tm = logical / p.tiles_n;
+    const int m0 = tm * X8_BM, n0 = tn * X8_BN;
+
+    // piece i (32 per stage) fills LDS rows 16 i .. 16 i + 15 (rows 0..255 = A, 256..511 = W); wave w issues i = w + 8 j
+    const unsigned char* src[X8_PIECES];
+#pragma unroll
+    for (int j = 0; j < X8_PIECES; ++j) {
+        const int i = wave + 8 * j;
+        const int row = 16 * i + (lane >> 2);
+        const int slot = lane & 3;
+        if (row < X8_BM) {
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            src[j] = p.A + (int64_t)m * p.lda + ((slot ^ key_x8(row)) << 4);
+        } else {
+            const int wr = row - X8_BM;
+            int n = n0 + wr;
+            if (n >= p.N) n = p.N - 1;
+            src[j] = p.W + (int64_t)n * p.ldw + ((slot ^ key_x8(wr)) << 4);
+        }
+    }
+    // scales: lane `lane` of wave `wave` fetches the dword of tile row 64 wave + lane (A rows 0..255, W rows 256..511): the four
+    // block scales of the 128-wide K span that holds this slice (fetched with every slice: one more VMEM instruction per stage)
+    const uint32_t* sc_src;
+    int64_t sc_step;
+    {
+        const int row = 64 * wave + lane;
+        if (row < X8_BM) {
+            int m = m0 + row;
+            if (m >= p.M) m = p.M - 1;
+            sc_src = p.mxa + m;
+            sc_step = p.M;
+        } else {
+            int n = n0 + row - X8_BM;
+            if (n >= p.N) n = p.N - 1;
+            sc_src = p.mxw + n;
+            sc_step = p.N;
+        }
+    }
+    auto issue_stage = [&](int kt, int stage) {
+#pragma unroll
+        for (int j = 0; j < X8_PIECES; ++j) {
+            const int i = wave + 8 * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (int64_t)kt * X8_BK),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + i * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sc_src + (int64_t)(kt >> 1) * sc_step),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + X8_STAGE + wave * 256), 4, 0, 0);
+    };
+
+    // fragment rows: A natural (block row r), W permuted (see above)
+    const int wperm = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t a_off[4][2], w_off[2][2], a_sc[4], w_sc[2];  // [block][MX block of the slice]
+#pragma unroll
+    for (int mj = 0; mj < 4; ++mj) {
+        const int row = wm * 128 + 32 * mj + r;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) a_off[mj][kb] = (uint32_t)(row * X8_ROWB + (((2 * kb + h) ^ key_x8(row)) << 4));
+        a_sc[mj] = (uint32_t)(X8_STAGE + row * 4 + h);
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int wr = wn * 64 + 32 * nj + wperm;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) w_off[nj][kb] = (uint32_t)((X8_BM + wr) * X8_ROWB + (((2 * kb + h) ^ key_x8(wr)) << 4));
+        w_sc[nj] = (uint32_t)(X8_STAGE + (X8_BM + wr) * 4 + h);
+    }
+
+    f32x16_t acc[2][4];  // [nj][mj]
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mj = 0; mj < 4; ++mj)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nj][mj][i] = 0.f;
+
+    const int nk = p.K / X8_BK;  // >= 4
+    issue_stage(0, 0);
+    issue_stage(1, 1);
+    issue_stage(2, 2);
+    const int grp = wave >> 2;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (X8_PIECES + 1)) : "memory");  // own pieces of slice 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t st = lds_base + (kt % X8_NST) * STAGE;
+        const uint32_t sb = (uint32_t)(2 * (kt & 1));  // which two of the dword's four block scales
+        uint4 af[4][2], wf[2][2];
+        int sca[4], scw[2];
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wf[nj][0]) : "v"(st + w_off[nj][0]) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(wf[nj][1]) : "v"(st + w_off[nj][1]) : "memory");
+            asm volatile("ds_read_u8 %0, %1" : "=v"(scw[nj]) : "v"(st + w_sc[nj] + sb) : "memory");
+        }
+#pragma unroll
+        for (int mj = 0; mj < 4; ++mj) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[mj][0]) : "v"(st + a_off[mj][0]) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[mj][1]) : "v"(st + a_off[mj][1]) : "memory");
+            asm volatile("ds_read_u8 %0, %1" : "=v"(sca[mj]) : "v"(st + a_sc[mj] + sb) : "memory");
+        }
+        if (kt + 3 < nk) {
+            issue_stage(kt + 3, (kt + 3) % X8_NST);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (X8_PIECES + 1)) : "memory");
+        } else if (kt + 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(X8_PIECES + 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int mj = 0; mj < 4; ++mj) {
+                const i32x8_t a = {(int)wf[nj][0].x, (int)wf[nj][0].y, (int)wf[nj][0].z, (int)wf[nj][0].w, (int)wf[nj][1].x, (int)wf[nj][1].y, (int)wf[nj][1].z, (int)wf[nj][1].w};
+                const i32x8_t b = {(int)af[mj][0].x, (int)af[mj][0].y, (int)af[mj][0].z, (int)af[mj][0].w, (int)af[mj][1].x, (int)af[mj][1].y, (int)af[mj][1].z, (int)af[mj][1].w};
+                acc[nj][mj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[nj][mj], 0, 0, 0, scw[nj], 0, sca[mj]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp && kt + 1 == nk)) __builtin_amdgcn_s_barrier();
+    }
+    mx8_epilogue<OUT_F32, F>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // amax / quantise: HBM-bound streaming kernels, 16-byte accesses, grid-stride over rows
 // ---------------------------------------------------------------------------------------------------------------
 template <typename TX>
@@ -361,8 +649,45 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
         f |= F_MXOUT;
     }
     LNX_CHECK(f != (int)F_GENERIC && a->gamma == nullptr, "%s: this epilogue needs the generic form, which the fp8 kernels do not carry", who);
-    const int grid = p.tiles_m * p.tiles_n;
     hipStream_t st = (hipStream_t)stream;
+    {
+        // the 256x256-tile MX kernel where it applies (LNX_FP8_X8=0: never)
+        const char* e = getenv("LNX_FP8_X8");
+        const bool x8_off = e && atoi(e) == 0;
+        if (mx && !x8_off && a->N % X8_BN == 0 && a->K % 128 == 0 && a->K / X8_BK >= 4 && (int64_t)cdiv(a->M, X8_BM) * (a->N / X8_BN) >= 128) {
+            p.tiles_m = cdiv(a->M, X8_BM);
+            p.tiles_n = a->N / X8_BN;
+            const int gridx = p.tiles_m * p.tiles_n;
+            const size_t ldsx = X8_NST * (size_t)(X8_STAGE + X8_SCALES);
+#define X8_LAUNCH(O, FF)                                                                                                              \
+    do {                                                                                                                              \
+        static bool attr = false;                                                                                                     \
+        if (!attr) {                                                                                                                  \
+            LNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_mx8_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx)); \
+            attr = true;                                                                                                              \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_mx8_kernel<O, FF>), dim3(gridx), dim3(512), ldsx, st, p);                                         \
+    } while (0)
+            bool done = true;
+            if (out_f32 && f == (F_BIAS | F_RES)) X8_LAUNCH(true, F_BIAS | F_RES);
+            else if (out_f32) done = false;
+            else if (f == 0) X8_LAUNCH(false, 0);
+            else if (f == F_BIAS) X8_LAUNCH(false, F_BIAS);
+            else if (f == (F_BIAS | F_C2 | F_GELU) && a->act == LNX_ACT_GELU) X8_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
+            else if (f == (F_BIAS | F_C2 | F_GELU | F_MXOUT) && a->act == LNX_ACT_GELU) X8_LAUNCH(false, F_BIAS | F_C2 | F_GELU | F_MXOUT);
+            else if (f == F_GELU_BWD && a->act == LNX_ACT_GELU_BWD) X8_LAUNCH(false, F_GELU_BWD);
+            else if (f == (F_GELU_BWD | F_MXOUT) && a->act == LNX_ACT_GELU_BWD) X8_LAUNCH(false, F_GELU_BWD | F_MXOUT);
+            else done = false;
+#undef X8_LAUNCH
+            if (done) {
+                LNX_LAUNCH_CHECK();
+                return 0;
+            }
+            p.tiles_m = cdiv(a->M, F8_BM);
+            p.tiles_n = cdiv(a->N, F8_BN);
+        }
+    }
+    const int grid = p.tiles_m * p.tiles_n;
 #define F8_LAUNCH_(O, FF, MXV)                                                                                                        \
     do {                                                                                                                              \
         const size_t lds = F8_NSTAGE * (size_t)(F8_STAGE + ((MXV) ? F8_SCALES : 0));                                                  \

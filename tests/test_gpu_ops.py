@@ -451,10 +451,11 @@ def _mx_reference(x):
     return q, e.to(torch.uint8)  # e: [M, K/32]
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024), (33000, 512, 512), (16500, 1024, 384)])
 @pytest.mark.parametrize("xd", [L.BF16, L.F32])
 def test_mxfp8_quantize_and_gemm(M, N, K, xd):
-    """MXFP8 path (block-scaled e4m3, scales applied inside v_mfma_scale_f32_16x16x128_f8f6f4).  Quantisation is checked
+    """MXFP8 path (block-scaled e4m3, scales applied inside v_mfma_scale_f32_16x16x128_f8f6f4; the last two shapes -- N a
+    multiple of 256, at least 128 tiles -- take the 256x256-tile kernel on v_mfma_scale_f32_32x32x64_f8f6f4, round 3).  Quantisation is checked
     byte for byte against the torch restatement above on data whose blocks span ~2^±20 (plus an all-zero block, a tiny
     block and a block at the top of the fp32/bf16 range); the GEMM against the fp64 product of the DEQUANTISED operands,
     so the only error left is fp32 accumulation order -- which also proves the scale layout and the instruction's k order."""
