@@ -63,8 +63,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None,
-                    help="per-GPU batch (weak scaling).  Default: 256 at --gpus 1 (BASELINE config 2) and 128 at --gpus > 1 "
-                         "(config 3: global batch 1024 at 8 GPUs, the point the north-star scaling target is defined at)")
+                    help="per-GPU batch.  Default: 256 at every --gpus N (BASELINE config 2's batch on every rank: weak scaling, the "
+                         "per-GPU work does not change with N).  --batch 128 at --gpus 8 is BASELINE config 3's shape (global batch 1024)")
     ap.add_argument("--arch", default="sm")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"], help="fp8: bf16 plus MXFP8 forward products in the RoPE blocks (config 5)")
@@ -229,7 +229,7 @@ def self_launch(n):
 def main():
     args = parse()
     if args.batch is None:
-        args.batch = 256 if args.gpus == 1 else 128
+        args.batch = 256  # the same per-GPU work at every N: "scaling": "weak" means what it says (rounds 1-2 ran 128 per GPU for N > 1)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
