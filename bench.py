@@ -226,10 +226,17 @@ def self_launch(n):
     sys.exit(rc if rc != 0 or line is not None else 1)
 
 
+def default_batch(n_gpus: int) -> int:
+    """Per-GPU batch when --batch is not given: BASELINE config 2's 256 at EVERY N -- "scaling": "weak" in the bench line means that
+    the per-GPU work does not change with the number of GPUs (rounds 1-2 ran 128 per GPU for N > 1, config 3's shape, which folded
+    the batch-size effect into value(N) / (N value(1)); `--batch 128` still runs that shape)."""
+    return 256
+
+
 def main():
     args = parse()
     if args.batch is None:
-        args.batch = 256  # the same per-GPU work at every N: "scaling": "weak" means what it says (rounds 1-2 ran 128 per GPU for N > 1)
+        args.batch = default_batch(args.gpus)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -249,3 +249,15 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "torch.distributed.run" in r.stderr and r.stderr.count("torch.cuda.set_device(local)") == 2, r.stderr[-3000:]
     assert "No HIP GPUs are available" in r.stderr
+
+
+def test_bench_weak_scaling_keeps_the_per_gpu_batch():
+    """bench.py labels its N > 1 lines "scaling": "weak": the per-GPU batch must then be the same at every N (the driver divides
+    value(N) by N * value(1))."""
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert {bench.default_batch(n) for n in (1, 2, 4, 8)} == {256}
