@@ -331,6 +331,42 @@ template <typename T> __device__ __forceinline__ void store4(T* p, float a, floa
     }
 }
 
+// One 64-element head row held as v[dt][0..3] = elements 16 dt + 4 g .. + 3 by the four lanes g of a row (the layout every
+// kernel here ends with).  fp32: four 16-byte stores.  bf16: lanes g and g ^ 1 swap halves first, so that the even one writes
+// elements 16 dt + 4 g .. + 7 of dt = 0, 2 and the odd one those of dt = 1, 3 -- two 16-byte stores a lane instead of four 8-byte
+// ones (whose half-filled 32-byte sectors made the key-side backward write 1.4x its output).  EVERY lane of the wave must call
+// (the exchange is a cross-lane operation); `live` gates the stores only.
+template <typename T> __device__ __forceinline__ void store_row64(T* rowp, const float (&v)[4][4], int g, bool live) {
+    if constexpr (sizeof(T) == 4) {
+        if (live) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(rowp + dt * 16 + 4 * g) = make_float4(v[dt][0], v[dt][1], v[dt][2], v[dt][3]);
+        }
+    } else {
+        uint2 pk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            T* h = reinterpret_cast<T*>(&pk[dt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = from_f<T>(v[dt][j]);
+        }
+        const bool even = (g & 1) == 0;
+        const uint2 s0 = even ? pk[1] : pk[0], s1 = even ? pk[3] : pk[2];
+        uint2 r0, r1;
+        r0.x = (uint32_t)__shfl_xor((int)s0.x, 16, 64); r0.y = (uint32_t)__shfl_xor((int)s0.y, 16, 64);
+        r1.x = (uint32_t)__shfl_xor((int)s1.x, 16, 64); r1.y = (uint32_t)__shfl_xor((int)s1.y, 16, 64);
+        if (live) {
+            if (even) {
+                st16(rowp + 4 * g, make_uint4(pk[0].x, pk[0].y, r0.x, r0.y));
+                st16(rowp + 32 + 4 * g, make_uint4(pk[2].x, pk[2].y, r1.x, r1.y));
+            } else {
+                st16(rowp + 16 + 4 * (g - 1), make_uint4(r0.x, r0.y, pk[1].x, pk[1].y));
+                st16(rowp + 48 + 4 * (g - 1), make_uint4(r1.x, r1.y, pk[3].x, pk[3].y));
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float group_max(float v) {  // over the 4 lanes s, s+16, s+32, s+48
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -455,6 +491,8 @@ __device__ __forceinline__ void dkv_epilogue(const AttnP& p, const f32x4_t (&dk)
             dy[dt][0] = b2.x; dy[dt][1] = b2.y;
         }
     }
+    // (8-byte stores here: pairing lanes for 16-byte ones, as the query side and the forward do, costs this kernel 16 more bytes
+    // of scratch per lane -- it lives at its 128-register limit -- and more written bytes than it saves)
     const bool row = key < p.N, img = row && key >= p.E;
     T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
     T* dvp = dkp + C;
@@ -507,14 +545,15 @@ __device__ __forceinline__ void dq_epilogue(const AttnP& p, const f32x4_t (&dq)[
     }
     const bool row = q < p.N, img = row && q >= p.E;
     T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
+    float oq[4][4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        const int d0 = dt * 16 + 4 * g;
         const float c0 = img ? cr[dt][0] * scale : scale, c1 = img ? cr[dt][1] * scale : scale;
-        if (row) store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
+        oq[dt][0] = dq[dt][0] * c0; oq[dt][1] = dq[dt][1] * c0; oq[dt][2] = dq[dt][2] * c1; oq[dt][3] = dq[dt][3] * c1;
         gp[dt][0] = img ? scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]) : 0.f;
         gp[dt][1] = img ? scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]) : 0.f;
     }
+    store_row64<T>(dqp, oq, g, row);
     if (rope) freq_accum(fl, gp, dx, dy, s, g);
 }
 
@@ -617,11 +656,14 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnP p) {
     }
     const float l_tot = group_sum(l_run);
     const float inv = 1.0f / l_tot;
-    if (q < p.N) {
-        T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
+    {
+        float ov[4][4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) store4<T>(op + dt * 16 + 4 * g, oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
-        if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[dt][r] = oacc[dt][r] * inv;
+        store_row64<T>(reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + min(q, p.N - 1)) * C + head * HD, ov, g, q < p.N);
+        if (q < p.N && g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
     }
 }
 
@@ -926,11 +968,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         const float l_tot = group_sum(l_run);
         const float inv = 1.0f / l_tot;
-        if (q < p.N) {
-            T* op = reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + q) * C + head * HD;
+        {
+            float ov[4][4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store4<T>(op + dt * 16 + 4 * g, oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
-            if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[dt][r] = oacc[dt][r] * inv;
+            store_row64<T>(reinterpret_cast<T*>(p.o) + ((int64_t)b * p.N + min(q, p.N - 1)) * C + head * HD, ov, g, q < p.N);
+            if (q < p.N && g == 0 && p.lse) p.lse[((int64_t)b * p.heads + head) * p.N + q] = m_run + logf(l_tot);
         }
     }
 }
@@ -1054,14 +1099,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
             }
             const bool row = q < p.N, img = row && q >= p.E;
             T* dqp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + qc) * ld + head * HD;
+            float oq[4][4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const int d0 = dt * 16 + 4 * g;
                 const float c0 = img ? cr[dt][0] * scale : scale, c1 = img ? cr[dt][1] * scale : scale;
-                if (row) store4<T>(dqp + d0, dq[dt][0] * c0, dq[dt][1] * c0, dq[dt][2] * c1, dq[dt][3] * c1);
+                oq[dt][0] = dq[dt][0] * c0; oq[dt][1] = dq[dt][1] * c0; oq[dt][2] = dq[dt][2] * c1; oq[dt][3] = dq[dt][3] * c1;
                 gp[dt][0] = img ? scale * (dq[dt][0] * qr[dt][0] + dq[dt][1] * qr[dt][1]) : 0.f;
                 gp[dt][1] = img ? scale * (dq[dt][2] * qr[dt][2] + dq[dt][3] * qr[dt][3]) : 0.f;
             }
+            store_row64<T>(dqp, oq, g, row);
             if (p.E < p.N) freq_accum(fl, gp, dx, dy, s, g);
         }
     }
