@@ -491,21 +491,26 @@ __device__ __forceinline__ void dkv_epilogue(const AttnP& p, const f32x4_t (&dk)
             dy[dt][0] = b2.x; dy[dt][1] = b2.y;
         }
     }
-    // (8-byte stores here: pairing lanes for 16-byte ones, as the query side and the forward do, costs this kernel 16 more bytes
-    // of scratch per lane -- it lives at its 128-register limit -- and more written bytes than it saves)
     const bool row = key < p.N, img = row && key >= p.E;
     T* dkp = reinterpret_cast<T*>(p.dqkv) + ((int64_t)b * p.N + kc) * ld + C + head * HD;
-    T* dvp = dkp + C;
+    {
+        float ok[4][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const int d0 = dt * 16 + 4 * g;
-        const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
-        if (row) {
-            store4<T>(dkp + d0, dk[dt][0] * c0, dk[dt][1] * c0, dk[dt][2] * c1, dk[dt][3] * c1);
-            store4<T>(dvp + d0, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+        for (int dt = 0; dt < 4; ++dt) {
+            const float c0 = img ? cr[dt][0] : 1.0f, c1 = img ? cr[dt][1] : 1.0f;
+            ok[dt][0] = dk[dt][0] * c0; ok[dt][1] = dk[dt][1] * c0; ok[dt][2] = dk[dt][2] * c1; ok[dt][3] = dk[dt][3] * c1;
+            gp[dt][0] = img ? dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1] : 0.f;
+            gp[dt][1] = img ? dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3] : 0.f;
         }
-        gp[dt][0] = img ? dk[dt][0] * kr[dt][0] + dk[dt][1] * kr[dt][1] : 0.f;
-        gp[dt][1] = img ? dk[dt][2] * kr[dt][2] + dk[dt][3] * kr[dt][3] : 0.f;
+        store_row64<T>(dkp, ok, g, row);
+    }
+    {
+        float ov[4][4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[dt][j] = dv[dt][j];
+        store_row64<T>(dkp + C, ov, g, row);
     }
     if (rope) freq_accum(fl, gp, dx, dy, s, g);
 }
@@ -741,22 +746,31 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const AttnP p) {
         __syncthreads();
         // no masks: padding keys have zero rows in all three images (their finite dS meets a zero row of K~), padding queries
         // are not stored; the clamp keeps exp finite where (query, key) is not a real pair
-        f32x4_t sacc[4], dpacc[4];
-        rows_times_frag_n<T, 4>(sacc, kimg, s, g, qf);    // S^T[key][q]
-        PHASE_FENCE();
-        rows_times_frag_n<T, 4>(dpacc, vimg, s, g, dof);  // dP^T[key][q] = V[key] . dO[q]
-        PHASE_FENCE();
-        float ds[4][4];
+        // two half steps of 32 keys: the same products with half the live registers (see the resident kernels)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int h = 0; h < 2; ++h) {
+            f32x4_t sacc[4], dpacc[4];
+            rows_times_frag_n<T, 2>(sacc, kimg + h * 32 * AT<T>::ROWB, s, g, qf);    // S^T[key][q]
+            PHASE_FENCE();
+            rows_times_frag_n<T, 2>(dpacc, vimg + h * 32 * AT<T>::ROWB, s, g, dof);  // dP^T[key][q] = V[key] . dO[q]
+            PHASE_FENCE();
+            float ds[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = RowExp<T>::clamped(sacc[t][r], lse);
-                const float dp = DROP ? (((mk[t] >> (8 * r)) & 0xffu) ? dpacc[t][r] * p.a_inv_keep : 0.f) : dpacc[t][r];
-                ds[t][r] = pr * (dp - delta);
-            }
-        PHASE_FENCE();
-        imgT_times_regs_n<T, 4>(dq, ktr, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (t < 2) {
+                        const float pr = RowExp<T>::clamped(sacc[t][r], lse);
+                        const float dp = DROP ? (((mk[2 * h + t] >> (8 * r)) & 0xffu) ? dpacc[t][r] * p.a_inv_keep : 0.f) : dpacc[t][r];
+                        ds[t][r] = pr * (dp - delta);
+                    } else {
+                        ds[t][r] = 0.f;
+                    }
+                }
+            PHASE_FENCE();
+            imgT_times_regs_n<T, 2>(dq, ktr + h * 32 * AT<T>::TRB, s, g, ds);  // dQ~^T[d][q] += K~^T . dS^T
+            PHASE_FENCE();
+        }
     }
     dq_epilogue<T>(p, dq, qb, ld, b, head, q, s, g, scale, fl);
     if (p.E < p.N) freq_flush<false>(fl, p.fpart);
@@ -829,33 +843,42 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void attn_bwd_dkv_kernel(
         d_n = p.delta[statbase + min(nxt + stl, p.N - 1)];
         __syncthreads();
         // no masks (see the dq kernel): padding queries have zero rows in the four images and finite statistics
-        f32x4_t sacc[4], dpacc[4];
-        rows_times_frag_n<T, 4>(sacc, qimg, s, g, kf);     // S[q = 16t + 4g + r][key = s]
-        PHASE_FENCE();
-        rows_times_frag_n<T, 4>(dpacc, doimg, s, g, vf);   // dP[q][key]
-        PHASE_FENCE();
-        float pr[4][4], ds[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + t * 16 + 4 * g);
-            const float4 d4 = *reinterpret_cast<const float4*>(del_s + t * 16 + 4 * g);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int h = 0; h < 2; ++h) {  // half steps of 32 queries
+            f32x4_t sacc[4], dpacc[4];
+            rows_times_frag_n<T, 2>(sacc, qimg + h * 32 * AT<T>::ROWB, s, g, kf);     // S[q = 16t + 4g + r][key = s]
+            PHASE_FENCE();
+            rows_times_frag_n<T, 2>(dpacc, doimg + h * 32 * AT<T>::ROWB, s, g, vf);   // dP[q][key]
+            PHASE_FENCE();
+            float pr[4][4], ds[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pp = RowExp<T>::clamped(sacc[t][r], lv[r]);
-                float keepf = 1.0f;
-                if constexpr (DROP) {  // this lane's key, the tile's queries: one byte per (query, key)
-                    const int qq = qt * BT + t * 16 + 4 * g + r;
-                    keepf = p.amask[(((int64_t)b * p.heads + head) * p.N + min(qq, p.N - 1)) * p.Np + min(key, p.N - 1)] ? p.a_inv_keep : 0.f;
+            for (int t = 0; t < 4; ++t) {
+                if (t < 2) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + h * 32 + t * 16 + 4 * g);
+                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + h * 32 + t * 16 + 4 * g);
+                    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pp = RowExp<T>::clamped(sacc[t][r], lv[r]);
+                        float keepf = 1.0f;
+                        if constexpr (DROP) {  // this lane's key, the tile's queries: one byte per (query, key)
+                            const int qq = qt * BT + h * 32 + t * 16 + 4 * g + r;
+                            keepf = p.amask[(((int64_t)b * p.heads + head) * p.N + min(qq, p.N - 1)) * p.Np + min(key, p.N - 1)] ? p.a_inv_keep : 0.f;
+                        }
+                        pr[t][r] = pp * keepf;
+                        ds[t][r] = pp * (dpacc[t][r] * keepf - dvv[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[t][r] = ds[t][r] = 0.f;
                 }
-                pr[t][r] = pp * keepf;
-                ds[t][r] = pp * (dpacc[t][r] * keepf - dvv[r]);
             }
+            PHASE_FENCE();
+            imgT_times_regs_n<T, 2>(dv, dotr + h * 32 * AT<T>::TRB, s, g, pr);  // dV^T[d][key] += dO^T . P
+            PHASE_FENCE();
+            imgT_times_regs_n<T, 2>(dk, qtr + h * 32 * AT<T>::TRB, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
+            PHASE_FENCE();
         }
-        PHASE_FENCE();
-        imgT_times_regs_n<T, 4>(dv, dotr, s, g, pr);  // dV^T[d][key] += dO^T . P
-        PHASE_FENCE();
-        imgT_times_regs_n<T, 4>(dk, qtr, s, g, ds);   // dK~^T[d][key] += Q~^T . dS
     }
     dkv_epilogue<T>(p, dk, dv, kb, ld, C, b, head, key, s, g, fl);
     if (p.E < p.N) freq_flush<true>(fl, p.fpart);
@@ -1004,7 +1027,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     stage_all<T, false, false, true>(nullptr, vimg, vb, ld, npad, p.N, p.E, nullptr, p.heads, head, 1.0f);
     __syncthreads();
     const int nq16 = (p.N + 15) / 16;
-    const int n4 = (p.N + 31) / BT;  // key tiles with more than 32 live rows; at most one shorter tile follows
     for (int qt = wave; qt < nq16; qt += NW) {
         const int q = qt * 16 + s;
         // every fetch of a q tile in one batch (unconditional, clamped rows): q~, dO and O fragments, the raw q values
@@ -1064,27 +1086,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         // No masks in the loop: the image rows of the padding keys (N <= key < npad) are zero, so whatever finite dS they
         // get multiplies a zero row of K~; lanes of padding queries are not stored.  exp's argument is <= 0 for every real
         // (query, key) pair, the clamp only keeps the padding ones finite.
-        auto kstep = [&](const int kt, auto ntc) __attribute__((always_inline)) {
-            constexpr int NT = decltype(ntc)::value;
+        // Steps of 32 keys (two 16-key groups, one MFMA contraction step of dS . K~): the images are staged in units of 32 rows,
+        // so every step is the same straight-line body -- and half the live registers of a 64-key step, which this kernel
+        // needs (128-register budget: two workgroups per CU).
+        for (int k0 = 0; k0 < npad; k0 += 32) {
             f32x4_t sacc[4], dpacc[4];
-            rows_times_frag_pad_n<T, NT>(sacc, kimg + kt * BT * AT<T>::TRB, s, g, qf);
+            rows_times_frag_pad_n<T, 2>(sacc, kimg + k0 * AT<T>::TRB, s, g, qf);
             PHASE_FENCE();
-            rows_times_frag_pad_n<T, NT>(dpacc, vimg + kt * BT * AT<T>::TRB, s, g, dof);
+            rows_times_frag_pad_n<T, 2>(dpacc, vimg + k0 * AT<T>::TRB, s, g, dof);
             PHASE_FENCE();
             float ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = RowExp<T>::clamped(sacc[t][r], lse);
-                    ds[t][r] = t < NT ? pr * (dpacc[t][r] - delta) : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) ds[t][r] = t < 2 ? RowExp<T>::clamped(sacc[t][r], lse) * (dpacc[t][r] - delta) : 0.f;
             PHASE_FENCE();
-            imgT_times_regs_n<T, NT>(dq, kimg + kt * BT * AT<T>::TRB, s, g, ds);
+            imgT_times_regs_n<T, 2>(dq, kimg + k0 * AT<T>::TRB, s, g, ds);
             PHASE_FENCE();
-        };
-        for (int kt = 0; kt < n4; ++kt) kstep(kt, IC<4>{});
-        if (n4 < nkt) kstep(n4, IC<2>{});
+        }
         {
             // the d cos / d freqs table entries of this row: fetched here (after the key loop: held across it they would spill)
             const float* sxp = p.dsin + ((int64_t)max(qc - p.E, 0) * p.heads + head) * 32;
@@ -1160,7 +1179,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __syncthreads();
     ATT_T(1);
     const int nk16 = (p.N + 15) / 16;
-    const int n4 = (p.N + 31) / BT;  // query tiles with more than 32 live rows; at most one shorter tile follows
     for (int ktile = wave; ktile < nk16; ktile += NW) {
         const int key = ktile * 16 + s;
         const int kc = min(key, p.N - 1);
@@ -1188,19 +1206,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
         ATT_T(2);
         // No masks in the loop (see the dq kernel): padding queries have zero rows in both images and finite statistics (0).
-        auto qstep = [&](const int qt, auto ntc) __attribute__((always_inline)) {
-            constexpr int NT = decltype(ntc)::value;
+        // steps of 32 queries (see the dq kernel)
+        for (int q0 = 0; q0 < npad; q0 += 32) {
             f32x4_t sacc[4], dpacc[4];
-            rows_times_frag_pad_n<T, NT>(sacc, qimg + qt * BT * AT<T>::TRB, s, g, kf);
+            rows_times_frag_pad_n<T, 2>(sacc, qimg + q0 * AT<T>::TRB, s, g, kf);
             PHASE_FENCE();
-            rows_times_frag_pad_n<T, NT>(dpacc, doimg + qt * BT * AT<T>::TRB, s, g, vf);
+            rows_times_frag_pad_n<T, 2>(dpacc, doimg + q0 * AT<T>::TRB, s, g, vf);
             PHASE_FENCE();
             float pr[4][4], ds[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                if (t < NT) {
-                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * BT + t * 16 + 4 * g);
-                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + qt * BT + t * 16 + 4 * g);
+                if (t < 2) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q0 + t * 16 + 4 * g);
+                    const float4 d4 = *reinterpret_cast<const float4*>(del_s + q0 + t * 16 + 4 * g);
                     const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -1214,13 +1232,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             }
             PHASE_FENCE();
-            imgT_times_regs_n<T, NT>(dv, doimg + qt * BT * AT<T>::TRB, s, g, pr);
+            imgT_times_regs_n<T, 2>(dv, doimg + q0 * AT<T>::TRB, s, g, pr);
             PHASE_FENCE();
-            imgT_times_regs_n<T, NT>(dk, qimg + qt * BT * AT<T>::TRB, s, g, ds);
+            imgT_times_regs_n<T, 2>(dk, qimg + q0 * AT<T>::TRB, s, g, ds);
             PHASE_FENCE();
-        };
-        for (int qt = 0; qt < n4; ++qt) qstep(qt, IC<4>{});
-        if (n4 < nqt) qstep(n4, IC<2>{});
+        }
         ATT_T(3);
         dkv_epilogue<T>(p, dk, dv, kb, ld, C, b, head, key, s, g, fl);
         ATT_T(4);
