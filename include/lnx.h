@@ -509,6 +509,16 @@ typedef struct lnx_convmlp_args {
     const float* x;        /* [M, C] fp32 residual input */
     float* out;            /* [M, C] fp32 */
     void* z;               /* optional [M, C] bf16: pwconv2 output before gamma (for the gamma gradient) */
+    /* Fused block LayerNorm (blocks/convnext.py:77,84 `x = self.norm(x)`, eps 1e-6; round 3): with `y` set the kernel reads the
+     * LayerNorm INPUT (the depthwise conv output) and normalises it in registers -- `ln` must then be NULL -- and writes what the
+     * backward needs: the normalised rows (operand of the pwconv1 weight gradient) and the row statistics. */
+    const void* y;         /* [M, C] bf16, or NULL: `ln` is given */
+    const float* ln_w;     /* [C] */
+    const float* ln_b;     /* [C] */
+    float ln_eps;
+    void* ln_out;          /* optional out [M, C] bf16 */
+    float* mean;           /* optional out [M] (with rstd) */
+    float* rstd;
 } lnx_convmlp_args;
 int lnx_convmlp_fwd(const lnx_convmlp_args* args, void* stream);
 
@@ -529,6 +539,16 @@ typedef struct lnx_convmlp_bwd_args {
     void* dz;              /* out [M, C]  bf16  rowscale*gamma*g */
     void* dln;             /* out [M, C]  bf16  gradient wrt the LayerNorm output */
     float* dgamma;         /* [C] += */
+    /* Fused LayerNorm backward (round 3): with `y` set, `dln` receives the gradient wrt the LayerNorm INPUT y instead (what
+     * lnx_layernorm_bwd would make of dln, y, mean, rstd), and d_ln_w / d_ln_b += the LayerNorm weight / bias gradient. */
+    const void* y;         /* [M, C] bf16, or NULL */
+    const float* ln_w;     /* [C] */
+    const float* mean;     /* [M] saved by the forward */
+    const float* rstd;
+    float* d_ln_w;         /* [C] += */
+    float* d_ln_b;         /* [C] += */
+    float* ws;             /* scratch for the per-workgroup column sums: 2 C floats per workgroup (256 workgroups at C <= 96,   */
+    int64_t ws_floats;     /* ceil(M / 128) above); too small = error                                                         */
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
 

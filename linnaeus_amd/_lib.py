@@ -207,6 +207,8 @@ class ConvMlpArgs(C.Structure):
         ("ln", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("gamma", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
         ("x", C.c_void_p), ("out", C.c_void_p), ("z", C.c_void_p),
+        ("y", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
+        ("mean", C.c_void_p), ("rstd", C.c_void_p),
     ]
 
 
@@ -216,6 +218,8 @@ class ConvMlpBwdArgs(C.Structure):
         ("g", C.c_void_p), ("ln", C.c_void_p), ("z", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
         ("w2t", C.c_void_p), ("w1t", C.c_void_p), ("gamma", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_sample", C.c_int),
         ("act", C.c_void_p), ("dh", C.c_void_p), ("dz", C.c_void_p), ("dln", C.c_void_p), ("dgamma", C.c_void_p),
+        ("y", C.c_void_p), ("ln_w", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("d_ln_w", C.c_void_p), ("d_ln_b", C.c_void_p),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
     ]
 
 

@@ -47,6 +47,18 @@ struct CmP {
     unsigned char* dln;         // bwd out [M, C]
     float* dgamma;
     int M, C, rps;
+    // fused block LayerNorm (LNF forward / LNB backward kernels)
+    const unsigned char* y;     // [M, C] bf16 LayerNorm input (the depthwise conv output)
+    const float* lnw;           // [C]
+    const float* lnb;           // [C]  (forward)
+    float eps;                  //      (forward)
+    unsigned char* ln_out;      // fwd: optional [M, C] bf16 normalised rows
+    float* mean;                // fwd out / bwd in [M]
+    float* rstd;
+    float* part;                // bwd: per-workgroup partial sums of dw | db, [gridDim.x][2C]
+    int64_t part_floats;
+    float* dlnw;                // bwd: [C] += LayerNorm weight / bias gradient (host side of the launch: the reduce kernel's targets)
+    float* dlnb;
 };
 
 __device__ __forceinline__ void mfma16(f32x4_t& acc, const uint4& a, const uint4& b) {
@@ -234,6 +246,130 @@ __device__ __forceinline__ uint4 pack8(const f32x4_t& lo, const f32x4_t& hi) {
 }
 
 // ------------------------------------------------------------------------------------
+// Block LayerNorm (blocks/convnext.py:77 `self.norm`, eps 1e-6) inside the conv-MLP kernels.  A wave owns whole rows in both
+// of its layouts -- the A-fragment layout (lane (s, g): row s, channels 32 ks + 8 g .. + 7) and the accumulator layout (row s,
+// channels 16 ct + 4 g .. + 3) -- so a row statistic is a per-lane sum plus two cross-lane steps over g, and the separate
+// LayerNorm passes (forward: read y, write ln; backward: read dln and y, write dy) disappear into kernels that are HBM-bound.
+// Same arithmetic as norm.hip: two-pass mean / centred variance, 1 / sqrtf, fma(v * rstd, w, b).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float g_sum(float v) {  // over the four lanes (g) of a row
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes s of a DPP row (every lane gets it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_get<0xB1>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0x141>(v);
+    v += dpp_get<0x140>(v);
+    return v;
+}
+// forward: the raw y fragments of one row -> its normalised (bf16) fragments; w / b: [C] (global or LDS)
+template <int NK>
+__device__ __forceinline__ void ln_row_frags(uint4 (&xf)[NK], const float* w, const float* b, int g, float eps, float& mu, float& rs) {
+    constexpr float invC = 1.0f / (float)Geo<NK>::C;
+    float v[NK][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        Vec16<bf16_t> t;
+        t.raw = xf[ks];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[ks][j] = t.get(j);
+        sum += ((v[ks][0] + v[ks][1]) + (v[ks][2] + v[ks][3])) + ((v[ks][4] + v[ks][5]) + (v[ks][6] + v[ks][7]));
+    }
+    mu = g_sum(sum) * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[ks][j] -= mu;
+            sq = fmaf(v[ks][j], v[ks][j], sq);
+        }
+    rs = 1.0f / sqrtf(fmaf(g_sum(sq), invC, eps));
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int c = ks * 32 + 8 * g;
+        const float4 w0 = *reinterpret_cast<const float4*>(w + c), w1 = *reinterpret_cast<const float4*>(w + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        Vec16<bf16_t> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.set(j, fmaf(v[ks][j] * rs, wv[j], bv[j]));
+        xf[ks] = o.raw;
+    }
+}
+// backward: dln (this wave's accumulators of m-tile MTI, rounded to bf16 as the unfused path stores them) -> dy of row m into
+// p.dln, column sums of dln * xhat and dln into the workgroup's LDS partials `dls` ([2C]).  EVERY lane must call (cross-lane sums);
+// lnws: [C] LayerNorm weight in LDS.
+// The row's y (accumulator layout) and statistics are requested by ln_bwd_fetch at the START of the tile, with the tile's other
+// operands: fetched here, at the end, every tile would pay one exposed memory round trip more (measured: +15 % kernel time).
+template <int NK>
+struct LnRow {
+    uint2 yr[Geo<NK>::CT];
+    float mu, rs;
+};
+template <int NK>
+__device__ __forceinline__ void ln_bwd_fetch(LnRow<NK>& r, const CmP& p, int m, int g) {
+    constexpr int C = Geo<NK>::C;
+    const int mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+    for (int ct = 0; ct < Geo<NK>::CT; ++ct) r.yr[ct] = *reinterpret_cast<const uint2*>(p.y + ((int64_t)mc * C + ct * 16 + 4 * g) * 2);
+    r.mu = p.mean[mc];
+    r.rs = p.rstd[mc];
+}
+template <int NK, int MT, int MTI>
+__device__ __forceinline__ void ln_bwd_rows(const CmP& p, const f32x4_t (&dl)[Geo<NK>::CT][MT], const LnRow<NK>& row, int m, int s, int g, const float* lnws,
+                                            float* dls) {
+    constexpr int C = Geo<NK>::C;
+    constexpr int CT = Geo<NK>::CT;
+    constexpr float invC = 1.0f / (float)C;
+    const bool mv = m < p.M;
+    const uint2 (&yr)[CT] = row.yr;
+    const float mu = row.mu, rs = row.rs;
+    float xh[CT][4], gv[CT][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + 4 * g;
+        const float4 w4 = *reinterpret_cast<const float4*>(lnws + c);
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+        const bf16_t* yh = reinterpret_cast<const bf16_t*>(&yr[ct]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = mv ? (float)(bf16_t)dl[ct][MTI][r] : 0.f;
+            const float x = ((float)yh[r] - mu) * rs;
+            xh[ct][r] = x;
+            gv[ct][r] = d * wv[r];
+            s1 += gv[ct][r];
+            s2 = fmaf(gv[ct][r], x, s2);
+            const float a = row16_sum(d * x), b = row16_sum(d);
+            if (s == 0) {
+                atomicAdd(&dls[c + r], a);
+                atomicAdd(&dls[C + c + r], b);
+            }
+        }
+    }
+    const float m1 = g_sum(s1) * invC, m2 = g_sum(s2) * invC;
+    if (mv) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            uint2 v;
+            bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vh[r] = (bf16_t)(rs * (gv[ct][r] - m1 - xh[ct][r] * m2));
+            *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + ct * 16 + 4 * g) * 2) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
 // Diagnostic build only (-DCM_STAMP, tools/build_stamp.sh): per-phase s_memtime sums of wave 0 of one workgroup
@@ -245,7 +381,9 @@ __device__ unsigned long long g_cm_stamp[8];
 #define CM_T(i) do { } while (0)
 #endif
 
-template <int NK, int MT, int NW>
+// LNF: the kernel reads the LayerNorm INPUT p.y and normalises it in registers (ln_row_frags); p.ln_out / p.mean / p.rstd (optional)
+// receive what the backward needs
+template <int NK, int MT, int NW, bool LNF>
 __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
 #ifdef CM_STAMP
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
@@ -275,7 +413,25 @@ __global__ __launch_bounds__(64 * NW) void convmlp_fwd_kernel(const CmP p) {
         int m = m_base + mt * 16 + s;
         if (m >= p.M) m = p.M - 1;
 #pragma unroll
-        for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+        for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = ld16((LNF ? p.y : p.ln) + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+    }
+    if constexpr (LNF) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float mu, rs;
+            ln_row_frags<NK>(xf[mt], p.lnw, p.lnb, g, p.eps, mu, rs);
+            const int m = m_base + mt * 16 + s;
+            if (m < p.M) {
+                if (p.ln_out) {
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) st16(p.ln_out + ((int64_t)m * C + ks * 32 + 8 * g) * 2, xf[mt][ks]);
+                }
+                if (p.mean && g == 0) {
+                    p.mean[m] = mu;
+                    p.rstd[m] = rs;
+                }
+            }
+        }
     }
     f32x4_t o[CT][MT];
 #pragma unroll
@@ -386,7 +542,9 @@ extern "C" int lnx_dbg_convmlp_stamps(unsigned long long* out8) { return (int)hi
 // ------------------------------------------------------------------------------------
 // ST: also store act = GELU(h) and dH ([M, 4C] each), the operands of the two weight-gradient GEMMs the plan launches after
 // this kernel (ST = false: a caller that only wants the data gradient)
-template <int NK, int MT, int NW, bool ST>
+// LNB: the LayerNorm backward runs in the epilogue (ln_bwd_rows): p.dln receives the gradient wrt the LayerNorm INPUT p.y, and
+// the workgroup's column sums for the LayerNorm weight / bias gradient go to p.part (summed by ln_partials_reduce_kernel)
+template <int NK, int MT, int NW, bool ST, bool LNB>
 __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -397,6 +555,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* b1s = reinterpret_cast<float*>(smem + 2 * STAGE);
     float* dgs = b1s + 4 * C;  // [C] per-workgroup dgamma partial
+    float* lws = dgs + C;      // LNB: [C] LayerNorm weight, [2C] column-sum partials
+    float* dls = lws + C;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -405,7 +565,13 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     for (int i = threadIdx.x; i < 4 * C; i += 64 * NW) b1s[i] = p.b1[i];
-    for (int i = threadIdx.x; i < C; i += 64 * NW) dgs[i] = 0.f;
+    for (int i = threadIdx.x; i < C; i += 64 * NW) {
+        dgs[i] = 0.f;
+        if constexpr (LNB) {
+            lws[i] = p.lnw[i];
+            dls[i] = dls[C + i] = 0.f;
+        }
+    }
     __syncthreads();
 
     uint4 xf[MT][NK], zf[MT][NK];  // ln fragments; dz = rowscale*gamma*g fragments (bf16)
@@ -460,6 +626,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    LnRow<NK> lrow;
+    if constexpr (LNB) ln_bwd_fetch<NK>(lrow, p, m_base + s, g);
 
     __syncthreads();
     dma_nmajor<NK, NW>(smem, p.w1, 0, wave, lane);
@@ -520,21 +688,28 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
         }
         prod_cmajor_pipe<NK, MT>(dl, st + 2 * PART, s, g, pd);  // dln += dH . W1
     }
+    if constexpr (LNB) {
+        static_assert(MT == 1, "ln_bwd_rows is instantiated per m-tile");
+        ln_bwd_rows<NK, MT, 0>(p, dl, lrow, m_base + s, s, g, lws, dls);
+    } else {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m_base + mt * 16 + s;
-        if (m >= p.M) continue;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + s;
+            if (m >= p.M) continue;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const int c = ct * 16 + 4 * g;
-            uint2 v;
-            bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
-            vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
-            *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + 4 * g;
+                uint2 v;
+                bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+                vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
+                *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+            }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 64 * NW) atomicAdd(p.dgamma + i, dgs[i]);
+    if constexpr (LNB)
+        for (int i = threadIdx.x; i < 2 * C; i += 64 * NW) p.part[(int64_t)blockIdx.x * (2 * C) + i] = dls[i];
 }
 
 
@@ -601,7 +776,7 @@ __device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], ui
     }
 }
 
-template <int NK>
+template <int NK, bool LNF>
 __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     constexpr int MT = 2;
     constexpr int C = Geo<NK>::C;
@@ -614,6 +789,8 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     float* b1s = reinterpret_cast<float*>(smem + 2 * NCH * PART);
     float* b2s = b1s + 4 * C;
     float* gms = b2s + C;
+    float* lws = gms + C;  // LNF: LayerNorm weight | bias
+    float* lbs = lws + C;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
@@ -623,6 +800,10 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     for (int i = threadIdx.x; i < C; i += 512) {
         b2s[i] = p.b2[i];
         gms[i] = p.gamma[i];
+        if constexpr (LNF) {
+            lws[i] = p.lnw[i];
+            lbs[i] = p.lnb[i];
+        }
     }
     dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
     dma_all_cmajor<NK>(w2img, p.w2, wave, lane);
@@ -641,7 +822,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             int m = tile * 32 + mt * 16 + s;
             if (m >= p.M) m = p.M - 1;
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) dst[mt][ks] = ld16(p.ln + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
+            for (int ks = 0; ks < NK; ++ks) dst[mt][ks] = ld16((LNF ? p.y : p.ln) + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
         }
     };
     int tile = blockIdx.x * 8 + wave;
@@ -650,6 +831,25 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
 
     for (; tile < ntile; tile += tstep) {
         const int m_base = tile * 32;
+        if constexpr (LNF) {  // xf holds raw y rows until here (requested one tile ago); first, while few other values are live
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float mu, rs;
+                ln_row_frags<NK>(xf[mt], lws, lbs, g, p.eps, mu, rs);
+                const int m = m_base + mt * 16 + s;
+                if (m < p.M) {
+                    if (p.ln_out) {
+#pragma unroll
+                        for (int ks = 0; ks < NK; ++ks) st16(p.ln_out + ((int64_t)m * C + ks * 32 + 8 * g) * 2, xf[mt][ks]);
+                    }
+                    if (p.mean && g == 0) {
+                        p.mean[m] = mu;
+                        p.rstd[m] = rs;
+                    }
+                }
+            }
+        }
+        if constexpr (LNF) __builtin_amdgcn_sched_barrier(0);  // keep the loads below out of the block above (C = 96 lives at 256 registers)
         // residual rows of this tile (consumed in the epilogue) and next tile's ln fragments
         float4 xrv[MT][CT];
 #pragma unroll
@@ -734,7 +934,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     }
 }
 
-template <int NK, int MT, bool ST>
+template <int NK, int MT, bool ST, bool LNB>
 __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -745,13 +945,21 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     unsigned char* w2timg = smem + NCH * PART;
     float* b1s = reinterpret_cast<float*>(smem + 2 * NCH * PART);
     float* dgs = b1s + 4 * C;
+    float* lws = dgs + C;  // LNB: [C] LayerNorm weight, [2C] column-sum partials
+    float* dls = lws + C;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     for (int i = threadIdx.x; i < 4 * C; i += 512) b1s[i] = p.b1[i];
-    for (int i = threadIdx.x; i < C; i += 512) dgs[i] = 0.f;
+    for (int i = threadIdx.x; i < C; i += 512) {
+        dgs[i] = 0.f;
+        if constexpr (LNB) {
+            lws[i] = p.lnw[i];
+            dls[i] = dls[C + i] = 0.f;
+        }
+    }
     dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
     dma_all_nmajor<NK>(w2timg, p.w2t, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -809,6 +1017,11 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        LnRow<NK> lrow[MT];
+        if constexpr (LNB) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ln_bwd_fetch<NK>(lrow[mt], p, m_base + mt * 16 + s, g);
+        }
 #pragma unroll 1
         for (int j = 0; j < NCH; ++j) {
             f32x4_t h[4][MT], da[4][MT];
@@ -850,17 +1063,22 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             }
             prod_tr_nmajor<NK, MT>(dl, lds0 + j * PART, s, g, pd);  // dln += dH . W1  (W1 read transposed)
         }
+        if constexpr (LNB) {
+            ln_bwd_rows<NK, MT, 0>(p, dl, lrow[0], m_base + s, s, g, lws, dls);
+            if constexpr (MT == 2) ln_bwd_rows<NK, MT, 1>(p, dl, lrow[MT - 1], m_base + 16 + s, s, g, lws, dls);
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m_base + mt * 16 + s;
-            if (m >= p.M) continue;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m_base + mt * 16 + s;
+                if (m >= p.M) continue;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int c = ct * 16 + 4 * g;
-                uint2 v;
-                bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
-                vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
-                *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int c = ct * 16 + 4 * g;
+                    uint2 v;
+                    bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+                    vh[0] = (bf16_t)dl[ct][mt][0]; vh[1] = (bf16_t)dl[ct][mt][1]; vh[2] = (bf16_t)dl[ct][mt][2]; vh[3] = (bf16_t)dl[ct][mt][3];
+                    *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + c) * 2) = v;
+                }
             }
         }
     }
@@ -878,65 +1096,105 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
         }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 512) atomicAdd(p.dgamma + i, dgs[i]);
+    if constexpr (LNB)
+        for (int i = threadIdx.x; i < 2 * C; i += 512) p.part[(int64_t)blockIdx.x * (2 * C) + i] = dls[i];
 }
 
-template <int NK>
-int launch_fwd_res(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 6 * Geo<NK>::C * sizeof(float);
+// dw[c] += sum over workgroups of part[wg][c], db[c] += ... of part[wg][C + c]: one thread per entry and slice of workgroups,
+// partial sums in a fixed order, one atomic per slice
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ part, int nwg, int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * C) return;
+    const int per = (nwg + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+        t0 += part[(int64_t)w * 2 * C + e];
+        t1 += part[(int64_t)(w + 1) * 2 * C + e];
+        t2 += part[(int64_t)(w + 2) * 2 * C + e];
+        t3 += part[(int64_t)(w + 3) * 2 * C + e];
+    }
+    for (; w < w1; ++w) t0 += part[(int64_t)w * 2 * C + e];
+    const float t = (t0 + t1) + (t2 + t3);
+    if (w0 < w1) atomicAdd((e < C ? dw : db) + (e < C ? e : e - C), t);
+}
+
+template <int NK, bool LNF>
+int launch_fwd_res_t(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int grid = cdiv(cdiv(p.M, 32), 8);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF>), dim3(grid), dim3(512), lds, st, p);
     return 0;
 }
-template <int NK, int MT, bool ST>
+template <int NK>
+int launch_fwd_res(const CmP& p, hipStream_t st) {
+    return p.y ? launch_fwd_res_t<NK, true>(p, st) : launch_fwd_res_t<NK, false>(p, st);
+}
+// LNB launches: the workgroups' column sums (p.part) are folded into the LayerNorm weight / bias gradient right behind the kernel
+inline int reduce_ln_partials(const CmP& p, int nwg, hipStream_t st) {
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * p.C, 256), nwg >= 64 ? 64 : 1), dim3(256), 0, st, p.part, nwg, p.C, p.dlnw, p.dlnb);
+    return 0;
+}
+template <int NK, int MT, bool ST, bool LNB>
 int launch_bwd_res_t(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int grid = cdiv(cdiv(p.M, 16 * MT), 8);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST>), dim3(grid), dim3(512), lds, st, p);
-    return 0;
+    if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB>), dim3(grid), dim3(512), lds, st, p);
+    return LNB ? reduce_ln_partials(p, grid, st) : 0;
 }
 template <int NK, int MT>
 int launch_bwd_res(const CmP& p, hipStream_t st) {
-    return p.act ? launch_bwd_res_t<NK, MT, true>(p, st) : launch_bwd_res_t<NK, MT, false>(p, st);
+    if (p.y) return p.act ? launch_bwd_res_t<NK, MT, true, true>(p, st) : launch_bwd_res_t<NK, MT, false, true>(p, st);
+    return p.act ? launch_bwd_res_t<NK, MT, true, false>(p, st) : launch_bwd_res_t<NK, MT, false, false>(p, st);
 }
 
-template <int NK, int MT, int NW>
-int launch_fwd(const CmP& p, hipStream_t st) {
+template <int NK, int MT, int NW, bool LNF>
+int launch_fwd_t(const CmP& p, hipStream_t st) {
     const size_t lds = 3 * 2 * Geo<NK>::PART + 4 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_kernel<NK, MT, NW, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    hipLaunchKernelGGL((convmlp_fwd_kernel<NK, MT, NW>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
-    return 0;
-}
-
-template <int NK, int MT, int NW, bool ST>
-int launch_bwd_t(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * 3 * Geo<NK>::PART + 5 * Geo<NK>::C * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((convmlp_fwd_kernel<NK, MT, NW, LNF>), dim3(cdiv(p.M, 16 * NW * MT)), dim3(64 * NW), lds, st, p);
     return 0;
 }
 template <int NK, int MT, int NW>
+int launch_fwd(const CmP& p, hipStream_t st) {
+    return p.y ? launch_fwd_t<NK, MT, NW, true>(p, st) : launch_fwd_t<NK, MT, NW, false>(p, st);
+}
+
+template <int NK, int MT, int NW, bool ST, bool LNB>
+int launch_bwd_t(const CmP& p, hipStream_t st) {
+    const size_t lds = 2 * 3 * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int grid = cdiv(p.M, 16 * NW * MT);
+    if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
+    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), dim3(grid), dim3(64 * NW), lds, st, p);
+    return LNB ? reduce_ln_partials(p, grid, st) : 0;
+}
+template <int NK, int MT, int NW>
 int launch_bwd(const CmP& p, hipStream_t st) {
-    return p.act ? launch_bwd_t<NK, MT, NW, true>(p, st) : launch_bwd_t<NK, MT, NW, false>(p, st);
+    if (p.y) return p.act ? launch_bwd_t<NK, MT, NW, true, true>(p, st) : launch_bwd_t<NK, MT, NW, false, true>(p, st);
+    return p.act ? launch_bwd_t<NK, MT, NW, true, false>(p, st) : launch_bwd_t<NK, MT, NW, false, false>(p, st);
 }
 
 // waves per workgroup of the streamed-weight kernels: 8 (two per SIMD share one weight stream) unless LNX_CM_NW=4
@@ -947,7 +1205,11 @@ static const bool nw8 = !(getenv("LNX_CM_NW") && atoi(getenv("LNX_CM_NW")) == 4)
 extern "C" int lnx_convmlp_supported(int dtype, int C) { return dtype == LNX_BF16 && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192); }
 
 extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
-    LNX_CHECK(a && a->ln && a->w1 && a->w2 && a->b1 && a->b2 && a->gamma && a->x && a->out, "lnx_convmlp_fwd: null operand");
+    LNX_CHECK(a && (a->ln || a->y) && a->w1 && a->w2 && a->b1 && a->b2 && a->gamma && a->x && a->out, "lnx_convmlp_fwd: null operand");
+    if (a->y) {
+        LNX_CHECK(a->ln_w && a->ln_b && a->ln == nullptr, "lnx_convmlp_fwd: the fused LayerNorm form takes y, ln_w, ln_b and no ln");
+        LNX_CHECK((a->mean == nullptr) == (a->rstd == nullptr), "lnx_convmlp_fwd: mean and rstd must both be given or both be NULL");
+    }
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_fwd: unsupported dtype %d / C %d (bf16, C in {32,64,96,128,192})", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_fwd: empty");
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_convmlp_fwd: rowscale needs rows_per_sample");
@@ -955,6 +1217,7 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
     p.ln = (const unsigned char*)a->ln; p.w1 = (const unsigned char*)a->w1; p.w2 = (const unsigned char*)a->w2;
     p.b1 = a->b1; p.b2 = a->b2; p.gamma = a->gamma; p.rowscale = a->rowscale; p.x = a->x; p.out = a->out; p.z = (unsigned char*)a->z;
     p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.y = (const unsigned char*)a->y; p.lnw = a->ln_w; p.lnb = a->ln_b; p.eps = a->ln_eps; p.ln_out = (unsigned char*)a->ln_out; p.mean = a->mean; p.rstd = a->rstd;
     hipStream_t st = (hipStream_t)stream;
     switch (a->C) {
         case 32: launch_fwd_res<1>(p, st); break;
@@ -974,21 +1237,26 @@ extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_bwd: unsupported dtype %d / C %d", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_bwd: empty");
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_convmlp_bwd: rowscale needs rows_per_sample");
+    if (a->y) LNX_CHECK(a->ln_w && a->mean && a->rstd && a->d_ln_w && a->d_ln_b && a->ws, "lnx_convmlp_bwd: the fused LayerNorm form needs ln_w, mean, rstd, d_ln_w, d_ln_b and ws");
     CmP p{};
+    p.y = (const unsigned char*)a->y; p.lnw = a->ln_w; p.mean = const_cast<float*>(a->mean); p.rstd = const_cast<float*>(a->rstd);
+    p.part = a->ws; p.part_floats = a->ws_floats; p.dlnw = a->d_ln_w; p.dlnb = a->d_ln_b;
     p.g = a->g; p.ln = (const unsigned char*)a->ln; p.zin = (const unsigned char*)a->z; p.w1 = (const unsigned char*)a->w1;
     p.w2t = (const unsigned char*)a->w2t; p.w1t = (const unsigned char*)a->w1t; p.b1 = a->b1; p.gamma = a->gamma; p.rowscale = a->rowscale;
     p.act = (unsigned char*)a->act; p.dh = (unsigned char*)a->dh; p.dz = (unsigned char*)a->dz; p.dln = (unsigned char*)a->dln; p.dgamma = a->dgamma;
     p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
     hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
     switch (a->C) {
         // rows per wave tile (16 MT): MT = 2 halves the LDS weight reads per MFMA but needs 256+ registers at C >= 64
         // (it spilled 26 / 103 of them to scratch)
-        case 32: launch_bwd_res<1, 2>(p, st); break;
-        case 64: launch_bwd_res<2, 1>(p, st); break;
-        case 96: launch_bwd_res<3, 1>(p, st); break;
-        case 128: if (nw8) launch_bwd<4, 1, 8>(p, st); else launch_bwd<4, 1, 4>(p, st); break;
-        case 192: if (nw8) launch_bwd<6, 1, 8>(p, st); else launch_bwd<6, 1, 4>(p, st); break;
+        case 32: rc = launch_bwd_res<1, 2>(p, st); break;
+        case 64: rc = launch_bwd_res<2, 1>(p, st); break;
+        case 96: rc = launch_bwd_res<3, 1>(p, st); break;
+        case 128: rc = nw8 ? launch_bwd<4, 1, 8>(p, st) : launch_bwd<4, 1, 4>(p, st); break;
+        case 192: rc = nw8 ? launch_bwd<6, 1, 8>(p, st) : launch_bwd<6, 1, 4>(p, st); break;
     }
+    LNX_CHECK(rc == 0, "lnx_convmlp_bwd: ws too small for the LayerNorm partial sums (M=%d C=%d ws_floats=%lld)", a->M, a->C, (long long)a->ws_floats);
     LNX_LAUNCH_CHECK();
     return 0;
 }

@@ -54,6 +54,7 @@ struct OpW {          // a GEMM weight in the T-typed operand arena
 
 struct ConvBlk {
     bool fused = false;  // pwconv1 -> GELU -> pwconv2 -> LayerScale -> residual in one kernel (hidden tensor stays on chip)
+    bool fused_ln = false;  // ... and the block LayerNorm (forward and backward) inside those kernels: no separate LayerNorm pass
     int gamma, dww, dwb, lnw, lnb, b1, b2;
     OpW w1, w2;
     int64_t w49;  // fp32 [49][C] in the arena
@@ -546,6 +547,13 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.fused = lnx_convmlp_supported(c.dtype, (int)C) != 0 && getenv("LNX_NO_FUSED_MLP") == nullptr &&
                       (getenv("LNX_FUSED_MLP_MAXC") == nullptr || C <= atoi(getenv("LNX_FUSED_MLP_MAXC")));
             any_fused = any_fused || k.fused;
+            // LNX_NO_FUSED_LN: the block LayerNorm as its own passes again (A/B switch).  The backward kernel leaves 2C floats of
+            // column sums per workgroup in the LayerNorm scratch: 256 workgroups at C <= 96, one per 128 rows above.
+            {
+                const int64_t nwg = C <= 96 ? 256 : (M + 127) / 128;
+                const int64_t lnws = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);  // = lnws_floats below
+                k.fused_ln = k.fused && getenv("LNX_NO_FUSED_LN") == nullptr && nwg * 2 * C <= lnws;
+            }
             if (!k.fused) {
                 k.hpre = share ? f.hpre : cv.take(M * 4 * C * esz);
                 k.act = share ? f.act : cv.take(M * 4 * C * esz);
@@ -1026,12 +1034,21 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
         Timed t(c, 4, (double)M * C * (4 + p->esz));  // bytes: read fp32 x, write T y
         RUN(lnx_dwconv7_fwd(&d, c.st));
     }
-    RUN(ln_fwd(c, M, C, 1e-6f, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<void>(k.ln), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean), c.at<float>(k.rstd)));
+    if (!k.fused_ln)
+        RUN(ln_fwd(c, M, C, 1e-6f, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<void>(k.ln), c.dt, C, IDM, nullptr, 0, c.at<float>(k.mean), c.at<float>(k.rstd)));
     if (k.fused) {
         lnx_convmlp_args f;
         memset(&f, 0, sizeof f);
         f.dtype = c.dt; f.M = M; f.C = C;
-        f.ln = c.at<void>(k.ln); f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1]; f.w2 = c.wptr(k.w2); f.b2 = p->P[k.b2];
+        if (k.fused_ln) {  // the kernel normalises y itself; a training plan keeps the normalised rows and the statistics for the backward
+            f.y = c.at<void>(k.y); f.ln_w = p->P[k.lnw]; f.ln_b = p->P[k.lnb]; f.ln_eps = 1e-6f;
+            if (!p->c.inference) {
+                f.ln_out = c.at<void>(k.ln); f.mean = c.at<float>(k.mean); f.rstd = c.at<float>(k.rstd);
+            }
+        } else {
+            f.ln = c.at<void>(k.ln);
+        }
+        f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1]; f.w2 = c.wptr(k.w2); f.b2 = p->P[k.b2];
         f.gamma = p->P[k.gamma]; f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
         f.x = c.at<float>(k.xin); f.out = xout; f.z = c.at<void>(k.z);
         Timed t(c, 6, 2.0 * M * C * 4 * C * 2);
@@ -1375,6 +1392,11 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         f.w2t = c.wtptr(k.w2); f.w1t = c.wtptr(k.w1); f.gamma = p->P[k.gamma];
         f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
         f.act = sB; f.dh = sA; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
+        if (k.fused_ln) {  // sD then holds the gradient wrt the depthwise conv output
+            f.y = c.at<void>(k.y); f.ln_w = p->P[k.lnw]; f.mean = c.at<float>(k.mean); f.rstd = c.at<float>(k.rstd);
+            f.d_ln_w = p->G[k.lnw]; f.d_ln_b = p->G[k.lnb];
+            f.ws = c.at<float>(p->o_lnws); f.ws_floats = p->lnws_floats;
+        }
         {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
@@ -1391,11 +1413,15 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
         RUN(gemm_nt_t(c, &a));
     }
-    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<float>(k.mean), c.at<float>(k.rstd), nullptr, sC, c.dt, C, false));
+    void* dy = sD;  // gradient wrt the depthwise conv output
+    if (!k.fused_ln) {
+        RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<void>(k.y), c.dt, C, IDM, k.lnw, k.lnb, c.at<float>(k.mean), c.at<float>(k.rstd), nullptr, sC, c.dt, C, false));
+        dy = sC;
+    }
     lnx_dwconv_wgrad_args w;
     memset(&w, 0, sizeof w);
     w.B = B; w.H = H; w.W = W; w.C = C;
-    w.x = c.at<float>(k.xin); w.x_dtype = LNX_F32; w.dy = sC; w.dy_dtype = c.dt;
+    w.x = c.at<float>(k.xin); w.x_dtype = LNX_F32; w.dy = dy; w.dy_dtype = c.dt;
     w.dw = p->G[k.dww]; w.db = p->G[k.dwb];
     {
         Timed t(c, 5, (double)M * C * (4 + p->esz));
@@ -1404,7 +1430,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
     lnx_dwconv_args d;
     memset(&d, 0, sizeof d);
     d.B = B; d.H = H; d.W = W; d.C = C;
-    d.x = sC; d.x_dtype = c.dt; d.w49 = c.at<float>(k.w49); d.bias = nullptr; d.flip = 1; d.res = g; d.y = g; d.y_dtype = LNX_F32;
+    d.x = dy; d.x_dtype = c.dt; d.w49 = c.at<float>(k.w49); d.bias = nullptr; d.flip = 1; d.res = g; d.y = g; d.y_dtype = LNX_F32;
     {
         Timed t(c, 4, (double)M * C * (8 + p->esz));  // bytes: read T dy + fp32 g, write fp32 g
         RUN(lnx_dwconv7_fwd(&d, c.st));

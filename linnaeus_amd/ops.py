@@ -295,19 +295,27 @@ def pack_meta(meta, off, dim, out):
     L.check(L.lib().lnx_pack_meta(_p(meta), meta.shape[1], off, dim, _p(out), code_of(out), meta.shape[0], _stream()), "lnx_pack_meta")
 
 
-def convmlp_fwd(ln, w1, b1, w2, b2, gamma, x, out, *, rowscale=None, rows_per_sample=0, z=None):
+def convmlp_fwd(ln, w1, b1, w2, b2, gamma, x, out, *, rowscale=None, rows_per_sample=0, z=None, y=None, ln_w=None, ln_b=None, ln_eps=1e-6,
+                ln_out=None, mean=None, rstd=None):
+    """`y` given (and `ln` None): the kernel applies the block LayerNorm (ln_w, ln_b, ln_eps) to y itself and writes ln_out / mean / rstd."""
     a = L.ConvMlpArgs()
-    a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
+    src = ln if y is None else y
+    a.dtype, a.M, a.C = code_of(src), src.shape[0], src.shape[1]
     a.ln, a.w1, a.b1, a.w2, a.b2, a.gamma = _p(ln), _p(w1), _p(b1), _p(w2), _p(b2), _p(gamma)
     a.rowscale, a.rows_per_sample, a.x, a.out, a.z = _p(rowscale), rows_per_sample, _p(x), _p(out), _p(z)
+    a.y, a.ln_w, a.ln_b, a.ln_eps, a.ln_out, a.mean, a.rstd = _p(y), _p(ln_w), _p(ln_b), ln_eps, _p(ln_out), _p(mean), _p(rstd)
     L.check(L.lib().lnx_convmlp_fwd(C.byref(a), _stream()), "lnx_convmlp_fwd")
     return out
 
 
-def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, rowscale=None, rows_per_sample=0):
+def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, rowscale=None, rows_per_sample=0, y=None, ln_w=None, mean=None,
+                rstd=None, d_ln_w=None, d_ln_b=None, ws=None):
+    """`y` given: the LayerNorm backward runs in the kernel too -- `dln` receives the gradient wrt y, d_ln_w / d_ln_b are accumulated."""
     a = L.ConvMlpBwdArgs()
     a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
     a.g, a.ln, a.z, a.w1, a.b1, a.w2t, a.w1t, a.gamma = _p(g), _p(ln), _p(z), _p(w1), _p(b1), _p(w2t), _p(w1t), _p(gamma)
     a.rowscale, a.rows_per_sample = _p(rowscale), rows_per_sample
     a.act, a.dh, a.dz, a.dln, a.dgamma = _p(act), _p(dh), _p(dz), _p(dln), _p(dgamma)
+    a.y, a.ln_w, a.mean, a.rstd, a.d_ln_w, a.d_ln_b = _p(y), _p(ln_w), _p(mean), _p(rstd), _p(d_ln_w), _p(d_ln_b)
+    a.ws, a.ws_floats = _p(ws), (ws.numel() if ws is not None else 0)
     L.check(L.lib().lnx_convmlp_bwd(C.byref(a), _stream()), "lnx_convmlp_bwd")

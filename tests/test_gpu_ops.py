@@ -393,6 +393,84 @@ def test_convmlp_fused_fwd_bwd(C_, M):
     torch.testing.assert_close(dgam2, dgam, rtol=2e-3, atol=2e-3)  # float atomics: summation order differs between launches
 
 
+@pytest.mark.parametrize("C_,M", [(32, 200), (64, 130), (96, 777), (128, 100), (192, 333), (96, 50001), (192, 40000)])
+def test_convmlp_fused_layernorm(C_, M):
+    """The conv-MLP kernels with the block LayerNorm inside (blocks/convnext.py:77,84: `x = self.norm(x)` in front of pwconv1):
+    forward = lnx_layernorm_fwd followed by the plain kernel; backward = the plain kernel followed by lnx_layernorm_bwd.  The two
+    forms differ only in the summation order of the row statistics, i.e. by single bf16 ulps of the normalised rows."""
+    gen = g(C_ * 7 + M)
+    bf = torch.bfloat16
+    rps = 50
+    nb = (M + rps - 1) // rps
+    y = (1.5 * torch.randn(M, C_, generator=gen) + 0.3).cuda().to(bf)
+    lw = (1.0 + 0.2 * torch.randn(C_, generator=gen)).cuda()
+    lb = (0.1 * torch.randn(C_, generator=gen)).cuda()
+    w1 = (torch.randn(4 * C_, C_, generator=gen) / C_**0.5).cuda().to(bf)
+    b1 = (0.2 * torch.randn(4 * C_, generator=gen)).cuda()
+    w2 = (torch.randn(C_, 4 * C_, generator=gen) / (4 * C_) ** 0.5).cuda().to(bf)
+    b2 = (0.2 * torch.randn(C_, generator=gen)).cuda()
+    gam = (0.5 + 0.3 * torch.randn(C_, generator=gen)).cuda()
+    rs = (torch.rand(nb, generator=gen) > 0.3).float().cuda() * 1.25
+    x = torch.randn(M, C_, generator=gen).cuda()
+    # two-pass form
+    ln0 = torch.empty(M, C_, device="cuda", dtype=bf)
+    mean0, rstd0 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(y, lw, lb, ln0, eps=1e-6, mean=mean0, rstd=rstd0)
+    out0, z0 = torch.empty(M, C_, device="cuda"), torch.empty(M, C_, device="cuda", dtype=bf)
+    ops.convmlp_fwd(ln0, w1, b1, w2, b2, gam, x, out0, rowscale=rs, rows_per_sample=rps, z=z0)
+    # fused form
+    ln1 = torch.full((M, C_), float("nan"), device="cuda", dtype=bf)
+    mean1, rstd1 = torch.full((M,), float("nan"), device="cuda"), torch.full((M,), float("nan"), device="cuda")
+    out1, z1 = torch.empty(M, C_, device="cuda"), torch.empty(M, C_, device="cuda", dtype=bf)
+    ops.convmlp_fwd(None, w1, b1, w2, b2, gam, x, out1, rowscale=rs, rows_per_sample=rps, z=z1, y=y, ln_w=lw, ln_b=lb, ln_eps=1e-6, ln_out=ln1,
+                    mean=mean1, rstd=rstd1)
+    torch.testing.assert_close(mean1, mean0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd1, rstd0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ln1.float(), ln0.float(), rtol=8e-3, atol=1e-6)  # one bf16 ulp
+    assert (ln1 != ln0).float().mean().item() < 1e-3
+    yd = y.double()
+    mu = yd.mean(1, keepdim=True)
+    xh = (yd - mu) / torch.sqrt(yd.var(1, unbiased=False, keepdim=True) + 1e-6)
+    torch.testing.assert_close(ln1.double(), xh * lw.double() + lb.double(), rtol=8e-3, atol=8e-3)
+    torch.testing.assert_close(out1, out0, rtol=2e-3, atol=6e-3)
+    # the same without the optional outputs (an inference plan's call)
+    out2 = torch.empty_like(out1)
+    ops.convmlp_fwd(None, w1, b1, w2, b2, gam, x, out2, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, ln_b=lb, ln_eps=1e-6)
+    assert torch.equal(out2, out1)
+
+    # backward, both forms from the SAME saved tensors (ln1, z1, mean1, rstd1)
+    gout = torch.randn(M, C_, generator=gen).cuda()
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    def bufs():
+        return (torch.empty(M, 4 * C_, device="cuda", dtype=bf), torch.empty(M, 4 * C_, device="cuda", dtype=bf), torch.empty(M, C_, device="cuda", dtype=bf),
+                torch.full((M, C_), float("nan"), device="cuda", dtype=bf), torch.zeros(C_, device="cuda"))
+    act0, dh0, dz0, dln0, dg0 = bufs()
+    ops.convmlp_bwd(gout, ln1, z1, w1, b1, w2t, w1t, gam, act0, dh0, dz0, dln0, dg0, rowscale=rs, rows_per_sample=rps)
+    dy0 = torch.empty(M, C_, device="cuda", dtype=bf)
+    dw0, db0 = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    ops.layernorm_bwd(dln0, y, lw, mean1, rstd1, dy0, dw=dw0, db=db0)
+    act1, dh1, dz1, dy1, dg1 = bufs()
+    dw1, db1 = torch.full((C_,), 3.0, device="cuda"), torch.full((C_,), -2.0, device="cuda")  # accumulated into
+    ws = torch.empty(max(256, (M + 127) // 128) * 2 * C_, device="cuda")
+    ops.convmlp_bwd(gout, ln1, z1, w1, b1, w2t, w1t, gam, act1, dh1, dz1, dy1, dg1, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, mean=mean1,
+                    rstd=rstd1, d_ln_w=dw1, d_ln_b=db1, ws=ws)
+    assert torch.equal(act1, act0) and torch.equal(dh1, dh0) and torch.equal(dz1, dz0)
+    torch.testing.assert_close(dy1.float(), dy0.float(), rtol=1.6e-2, atol=2e-3 * dy0.float().abs().max().item())
+    scale = max(1.0, dw0.abs().max().item())
+    torch.testing.assert_close(dw1 - 3.0, dw0, rtol=2e-3, atol=2e-3 * scale)
+    torch.testing.assert_close(db1 + 2.0, db0, rtol=2e-3, atol=2e-3 * max(1.0, db0.abs().max().item()))
+    # against fp64 math on the stored dln
+    dl = dln0.double()
+    gvv = dl * lw.double()
+    dy_ref = (gvv - gvv.mean(1, keepdim=True) - xh * (gvv * xh).mean(1, keepdim=True)) * rstd1.double()[:, None]
+    torch.testing.assert_close(dy1.double(), dy_ref, rtol=1.6e-2, atol=2e-3 * dy_ref.abs().max().item())
+    torch.testing.assert_close((dw1 - 3.0).double(), (dl * xh).sum(0), rtol=3e-3, atol=3e-3 * scale)
+    # too little scratch for the column sums is an error, not a silent overrun
+    with pytest.raises(L.LnxError):
+        ops.convmlp_bwd(gout, ln1, z1, w1, b1, w2t, w1t, gam, act1, dh1, dz1, dy1, dg1, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, mean=mean1,
+                        rstd=rstd1, d_ln_w=dw1, d_ln_b=db1, ws=ws[:C_])
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
 @pytest.mark.parametrize("xd", [L.BF16, L.F32])
 def test_fp8_quantize_and_gemm(M, N, K, xd):
