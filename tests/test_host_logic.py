@@ -238,7 +238,8 @@ def test_plan_footprint_counts_dropout_masks_and_logits():
 def test_bench_gpus_n_launches_its_own_ranks():
     """`python bench.py --gpus 2` with WORLD_SIZE unset starts the ranks itself (torch.distributed.run as a
     child process, never exec) before any GPU call in the parent; in a GPU-less container the only failure is
-    torch.cuda.set_device inside the two children, and the parent propagates the launcher's return code."""
+    torch.cuda.set_device inside the children (the launcher stops the second rank as soon as the first has failed, so one or two
+    tracebacks reach stderr), and the parent propagates the launcher's return code."""
     import subprocess
     import sys
 
@@ -247,7 +248,7 @@ def test_bench_gpus_n_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and r.stdout.strip() == ""
-    assert "torch.distributed.run" in r.stderr and r.stderr.count("torch.cuda.set_device(local)") == 2, r.stderr[-3000:]
+    assert "torch.distributed.run" in r.stderr and r.stderr.count("torch.cuda.set_device(local)") in (1, 2), r.stderr[-3000:]
     assert "No HIP GPUs are available" in r.stderr
 
 
