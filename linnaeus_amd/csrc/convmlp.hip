@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             dma_nmajor<NK, NW>(nx, p.w1, 64 * (j + 1), wave, lane);
             dma_nmajor<NK, NW>(nx + PART, p.w2t, 64 * (j + 1), wave, lane);
             dma_cmajor<NK, NW>(nx + 2 * PART, p.w1t, 64 * (j + 1), wave, lane);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");  // (allowing the previous chunk's act / dH stores to stay in flight here, vmcnt(NLD + 4 MT), changes nothing: measured)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

@@ -69,3 +69,12 @@ if which in ("all", "cm"):
         t2 = time_it(lambda: ops.convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gam, act, dh, dz, dln, dg, rowscale=rs, rows_per_sample=M // 256))
         by2 = M * C * (4 + 2 + 2 + 2 + 2) + 2 * M * 4 * C * 2
         print(f"convmlp {name} fwd {t*1e6:7.1f}us {fl/t/1e12:6.0f} TF/s {by/t/1e9:6.0f} GB/s | bwd {t2*1e6:7.1f}us {1.5*fl/t2/1e12:6.0f} TF/s {by2/t2/1e9:6.0f} GB/s", flush=True)
+        # the same with the block LayerNorm inside the kernels (what the plan launches)
+        y = torch.randn(M, C, device="cuda").to(bf); lw = torch.ones(C, device="cuda"); lb = torch.zeros(C, device="cuda")
+        mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda"); dlw = torch.zeros(C, device="cuda"); dlb = torch.zeros(C, device="cuda")
+        ws = torch.empty(max(256, (M + 127) // 128) * 2 * C, device="cuda")
+        t3 = time_it(lambda: ops.convmlp_fwd(None, w1, b1, w2, b2, gam, x, out, rowscale=rs, rows_per_sample=M // 256, z=z, y=y, ln_w=lw, ln_b=lb, ln_out=ln,
+                                             mean=mean, rstd=rstd))
+        t4 = time_it(lambda: ops.convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gam, act, dh, dz, dln, dg, rowscale=rs, rows_per_sample=M // 256, y=y, ln_w=lw,
+                                             mean=mean, rstd=rstd, d_ln_w=dlw, d_ln_b=dlb, ws=ws))
+        print(f"convmlp {name} +LN  fwd {t3*1e6:7.1f}us | bwd {t4*1e6:7.1f}us", flush=True)
