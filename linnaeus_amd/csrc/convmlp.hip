@@ -330,7 +330,8 @@ __device__ __forceinline__ void ln_bwd_rows(const CmP& p, const f32x4_t (&dl)[Ge
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
     constexpr float invC = 1.0f / (float)C;
-    const bool mv = m < p.M;
+    const bool mv = m < p.M;        // a lane beyond M holds row M - 1 again (clamped loads): it stores the same dy as its live twin
+    const int mc = mv ? m : p.M - 1;  // and contributes nothing to the column sums
     const uint2 (&yr)[CT] = row.yr;
     const float mu = row.mu, rs = row.rs;
     float xh[CT][4], gv[CT][4];
@@ -343,13 +344,14 @@ __device__ __forceinline__ void ln_bwd_rows(const CmP& p, const f32x4_t (&dl)[Ge
         const bf16_t* yh = reinterpret_cast<const bf16_t*>(&yr[ct]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float d = mv ? (float)(bf16_t)dl[ct][MTI][r] : 0.f;
+            const float d = (float)(bf16_t)dl[ct][MTI][r];
             const float x = ((float)yh[r] - mu) * rs;
             xh[ct][r] = x;
             gv[ct][r] = d * wv[r];
             s1 += gv[ct][r];
             s2 = fmaf(gv[ct][r], x, s2);
-            const float a = row16_sum(d * x), b = row16_sum(d);
+            const float dm = mv ? d : 0.f;
+            const float a = row16_sum(dm * x), b = row16_sum(dm);
             if (s == 0) {
                 atomicAdd(&dls[c + r], a);
                 atomicAdd(&dls[C + c + r], b);
@@ -357,15 +359,13 @@ __device__ __forceinline__ void ln_bwd_rows(const CmP& p, const f32x4_t (&dl)[Ge
         }
     }
     const float m1 = g_sum(s1) * invC, m2 = g_sum(s2) * invC;
-    if (mv) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            uint2 v;
-            bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
+    for (int ct = 0; ct < CT; ++ct) {
+        uint2 v;
+        bf16_t* vh = reinterpret_cast<bf16_t*>(&v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vh[r] = (bf16_t)(rs * (gv[ct][r] - m1 - xh[ct][r] * m2));
-            *reinterpret_cast<uint2*>(p.dln + ((int64_t)m * C + ct * 16 + 4 * g) * 2) = v;
-        }
+        for (int r = 0; r < 4; ++r) vh[r] = (bf16_t)(rs * (gv[ct][r] - m1 - xh[ct][r] * m2));
+        *reinterpret_cast<uint2*>(p.dln + ((int64_t)mc * C + ct * 16 + 4 * g) * 2) = v;
     }
 }
 
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     for (int mt = 0; mt < MT; ++mt) {
         int m = m_base + mt * 16 + s;
         mvalid[mt] = m < p.M;
-        if (!mvalid[mt]) m = p.M - 1;
+        if (!mvalid[mt]) m = p.M - 1;  // such a lane redoes row M - 1 and stores the same bytes as its live twin; only the column sums mask it
         const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
         // loads of every k-step first, then compute + dz stores (see the forward epilogue note)
         float4 g0v[NK], g1v[NK], a0v[NK], a1v[NK];
@@ -605,10 +605,10 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float sg = mvalid[mt] ? rs * gv[j] : 0.f;
+                const float sg = rs * gv[j];
                 dzv.set(j, sg * av[j]);
                 // dgamma partial: this lane's 8 channels of its row; reduced over rows below
-                const float dgp = sg * zin.get(j);
+                const float dgp = mvalid[mt] ? sg * zin.get(j) : 0.f;
                 // sum over the 16 rows (lanes s) of this m-tile that share g: xor-shuffle over the low 4 lane bits
                 float t = dgp;
                 t += __shfl_xor(t, 1, 64);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
                 if (s == 0) atomicAdd(&dgs[c + j], t);  // LDS atomic, 4 lanes per wave
             }
             zf[mt][ks] = dzv.raw;
-            if (mvalid[mt]) st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+            st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
         }
     }
     f32x4_t dl[CT][MT];
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             pd[mt][0] = pack8(da[0][mt], da[1][mt]);
             pd[mt][1] = pack8(da[2][mt], da[3][mt]);
             // packed element j of k-step ks2 <-> hidden n = 64 j_chunk + 32 ks2 + 8 g + j : 16 contiguous bytes per row
-            const int m = m_base + mt * 16 + s;
-            if (ST && m < p.M) {
+            const int m = min(m_base + mt * 16 + s, p.M - 1);
+            if constexpr (ST) {
                 const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
                 st16(p.act + off, pa[mt][0]);
                 st16(p.act + off + 64, pa[mt][1]);
@@ -694,8 +694,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m_base + mt * 16 + s;
-            if (m >= p.M) continue;
+            const int m = min(m_base + mt * 16 + s, p.M - 1);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int c = ct * 16 + 4 * g;
@@ -776,7 +775,9 @@ __device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], ui
     }
 }
 
-template <int NK, bool LNF>
+template <bool V> struct BoolC { static constexpr bool value = V; };
+// SAVE: the outputs the backward needs are written -- z, and with LNF the normalised rows and the row statistics (all or none)
+template <int NK, bool LNF, bool SAVE>
 __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     constexpr int MT = 2;
     constexpr int C = Geo<NK>::C;
@@ -814,13 +815,17 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     // tile t are requested BEFORE tile t's MFMA/GELU work, so every HBM round trip runs under
     // arithmetic (all waves of the chip would otherwise alternate in lockstep between a compute
     // phase and a memory phase, which is what the ablation showed: the phase times simply added up).
+    // No memory operation of the tile loop sits under a branch: with one in-order counter for loads and stores the compiler can only
+    // count ("wait until the loads issued before these N stores have landed") when every path issues the same operations -- under a
+    // branch it drains the counter instead, which made every tile wait for the previous tile's store acknowledgements AND the next
+    // tile's prefetch (round 3).  So: rows beyond M are clamped to M - 1 (such a lane recomputes row M - 1 and stores the same bytes
+    // as its live twin), the optional outputs are a template parameter (SAVE), the DropPath scale is loaded unconditionally.
     const int ntile = (p.M + 31) / 32;
     const int tstep = gridDim.x * 8;
-    auto load_x = [&](uint4 (&dst)[MT][NK], int tile) {
+    auto load_x = [&](uint4 (&dst)[MT][NK], int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            int m = tile * 32 + mt * 16 + s;
-            if (m >= p.M) m = p.M - 1;
+            const int m = min(tile * 32 + mt * 16 + s, p.M - 1);
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) dst[mt][ks] = ld16((LNF ? p.y : p.ln) + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
         }
@@ -828,6 +833,8 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     int tile = blockIdx.x * 8 + wave;
     uint4 xf[MT][NK];
     if (tile < ntile) load_x(xf, tile);
+    const float* rsp = p.rowscale ? p.rowscale : p.gamma;  // always a valid address; rsf folds the loaded value away when there is no scale
+    const float rsf = p.rowscale ? 1.0f : 0.0f;
 
     for (; tile < ntile; tile += tstep) {
         const int m_base = tile * 32;
@@ -836,13 +843,11 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             for (int mt = 0; mt < MT; ++mt) {
                 float mu, rs;
                 ln_row_frags<NK>(xf[mt], lws, lbs, g, p.eps, mu, rs);
-                const int m = m_base + mt * 16 + s;
-                if (m < p.M) {
-                    if (p.ln_out) {
+                const int m = min(m_base + mt * 16 + s, p.M - 1);
+                if constexpr (SAVE) {
 #pragma unroll
-                        for (int ks = 0; ks < NK; ++ks) st16(p.ln_out + ((int64_t)m * C + ks * 32 + 8 * g) * 2, xf[mt][ks]);
-                    }
-                    if (p.mean && g == 0) {
+                    for (int ks = 0; ks < NK; ++ks) st16(p.ln_out + ((int64_t)m * C + ks * 32 + 8 * g) * 2, xf[mt][ks]);
+                    if (g == 0) {
                         p.mean[m] = mu;
                         p.rstd[m] = rs;
                     }
@@ -850,27 +855,35 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             }
         }
         if constexpr (LNF) __builtin_amdgcn_sched_barrier(0);  // keep the loads below out of the block above (C = 96 lives at 256 registers)
-        // residual rows of this tile (consumed in the epilogue) and next tile's ln fragments
+        // The tile's residual rows / DropPath scale (consumed in the epilogue) and the next tile's ln fragments are requested in the LAST
+        // hidden-chunk iteration: one chunk of MFMA + GELU work and the epilogue cover the round trip, and the 48 + 24 registers
+        // they occupy are not live through the whole chunk loop (at C = 96 that spilled, and a scratch reload waits for every
+        // outstanding load).  The next fragments go straight into xf, which is dead once the chunk's first product is issued; the
+        // last tile fetches itself again (unconditional).
         float4 xrv[MT][CT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int m = m_base + mt * 16 + s;
-            if (m >= p.M) m = p.M - 1;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) xrv[mt][ct] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + ct * 16 + 4 * g);
-        }
-        uint4 xn[MT][NK];
-        const bool more = tile + tstep < ntile;
-        if (more) load_x(xn, tile + tstep);
+        float rsv[MT];
         f32x4_t o[CT][MT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) o[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int j = 0; j < NCH; ++j) {
+        auto chunk = [&](const int j, auto lastc) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(lastc)::value;
+            if constexpr (LAST) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = min(m_base + mt * 16 + s, p.M - 1);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) xrv[mt][ct] = *reinterpret_cast<const float4*>(p.x + (int64_t)m * C + ct * 16 + 4 * g);
+                    rsv[mt] = rsp[p.rowscale ? m / p.rps : 0];
+                }
+            }
             f32x4_t h[4][MT];
             prod_nmajor<NK, MT>(h, lds0 + j * PART, s, g, xf);
+            if constexpr (LAST) {
+                __builtin_amdgcn_sched_barrier(0);  // not above the product that still reads xf
+                load_x(xf, tile + tstep < ntile ? tile + tstep : tile);
+            }
             f32x4_t bv[4];
             const uint32_t ba = lds0 + 2 * NCH * PART + (uint32_t)((64 * j + 8 * g) * 4);
             CM_DS_READ128(bv[0], ba, 0);
@@ -900,36 +913,31 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
                 pf[mt][1] = pack8(h[2][mt], h[3][mt]);
             }
             prod_cmajor<NK, MT>(o, lds0 + NCH * PART + j * PART, s, g, pf);
-        }
-        // epilogue: b2 / gamma come from LDS, the residual from the registers requested above
+        };
+#pragma unroll 1
+        for (int j = 0; j < NCH - 1; ++j) chunk(j, BoolC<false>{});
+        chunk(NCH - 1, BoolC<true>{});
+        // epilogue: b2 / gamma come from LDS, the residual and the scale from the registers requested above
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m_base + mt * 16 + s;
-            if (m < p.M) {
-                const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
+            const int m = min(m_base + mt * 16 + s, p.M - 1);
+            const float rs = fmaf(rsv[mt] - 1.0f, rsf, 1.0f);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int c = ct * 16 + 4 * g;
-                    const float4 b2 = *reinterpret_cast<const float4*>(b2s + c);
-                    const float4 gm = *reinterpret_cast<const float4*>(gms + c);
-                    const float4 xr = xrv[mt][ct];
-                    const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
-                    if (p.z) {
-                        uint2 zz;
-                        bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
-                        zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
-                        *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
-                    }
-                    *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
-                        make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = ct * 16 + 4 * g;
+                const float4 b2 = *reinterpret_cast<const float4*>(b2s + c);
+                const float4 gm = *reinterpret_cast<const float4*>(gms + c);
+                const float4 xr = xrv[mt][ct];
+                const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
+                if constexpr (SAVE) {
+                    uint2 zz;
+                    bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
+                    zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
+                    *reinterpret_cast<uint2*>(p.z + ((int64_t)m * C + c) * 2) = zz;
                 }
+                *reinterpret_cast<float4*>(p.out + (int64_t)m * C + c) =
+                    make_float4(xr.x + rs * gm.x * z0, xr.y + rs * gm.y * z1, xr.z + rs * gm.z * z2, xr.w + rs * gm.w * z3);
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) xf[mt][ks] = xn[mt][ks];
         }
     }
 }
@@ -947,6 +955,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     float* dgs = b1s + 4 * C;
     float* lws = dgs + C;  // LNB: [C] LayerNorm weight, [2C] column-sum partials
     float* dls = lws + C;
+    float* gms = dls + 2 * C;  // [C] LayerScale gamma
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s = lane & 15, g = lane >> 4;
@@ -955,6 +964,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     for (int i = threadIdx.x; i < 4 * C; i += 512) b1s[i] = p.b1[i];
     for (int i = threadIdx.x; i < C; i += 512) {
         dgs[i] = 0.f;
+        gms[i] = p.gamma[i];
         if constexpr (LNB) {
             lws[i] = p.lnw[i];
             dls[i] = dls[C + i] = 0.f;
@@ -971,45 +981,67 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dgp[ks][j] = 0.f;
 
+    // Software pipeline over this wave's tiles, no memory operation under a branch (see convmlp_fwd_res_kernel): the operands of tile
+    // t + 1 are requested after tile t's hidden-chunk loop, BEFORE its epilogue stores, so their round trip runs under the epilogue's
+    // arithmetic and the wait for them does not include those stores' acknowledgements.
     const int ntile = (p.M + 16 * MT - 1) / (16 * MT);
-    for (int tile = blockIdx.x * 8 + wave; tile < ntile; tile += gridDim.x * 8) {
+    const int tstep = gridDim.x * 8;
+    const float* rsp = p.rowscale ? p.rowscale : p.gamma;
+    const float rsf = p.rowscale ? 1.0f : 0.0f;
+    struct TileIn {
+        uint4 x[MT][NK], z[MT][NK];
+        float4 g0[MT][NK], g1[MT][NK];
+        float rs[MT];
+        LnRow<NK> lr[MT];
+    };
+    auto fetch_tile = [&](TileIn& t, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = min(tile * (16 * MT) + mt * 16 + s, p.M - 1);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const int c = ks * 32 + 8 * g;
+                t.x[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
+                t.g0[mt][ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
+                t.g1[mt][ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
+                t.z[mt][ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
+            }
+            t.rs[mt] = rsp[p.rowscale ? m / p.rps : 0];
+            if constexpr (LNB) ln_bwd_fetch<NK>(t.lr[mt], p, m, g);
+        }
+    };
+    int tile = blockIdx.x * 8 + wave;
+    TileIn cur;
+    if (tile < ntile) fetch_tile(cur, tile);
+    for (; tile < ntile; tile += tstep) {
         const int m_base = tile * (16 * MT);
         uint4 xf[MT][NK], zf[MT][NK];
+        LnRow<NK> lrow[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int m = m_base + mt * 16 + s;
             const bool mv = m < p.M;
-            if (!mv) m = p.M - 1;
-            const float rs = p.rowscale ? p.rowscale[m / p.rps] : 1.0f;
-            // loads of every k-step first, then compute + dz stores (see the forward epilogue note)
-            float4 g0v[NK], g1v[NK], a0v[NK], a1v[NK];
-            uint4 zraw[NK];
+            if (!mv) m = p.M - 1;  // redoes row M - 1, stores the same bytes as its live twin; masked out of the column sums only
+            const float rs = fmaf(cur.rs[mt] - 1.0f, rsf, 1.0f);
+            lrow[mt] = cur.lr[mt];
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 const int c = ks * 32 + 8 * g;
-                xf[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
-                g0v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
-                g1v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
-                a0v[ks] = *reinterpret_cast<const float4*>(p.gamma + c);
-                a1v[ks] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
-                zraw[ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
-            }
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const int c = ks * 32 + 8 * g;
-                const float4 g0 = g0v[ks], g1 = g1v[ks], a0 = a0v[ks], a1 = a1v[ks];
+                xf[mt][ks] = cur.x[mt][ks];
+                const float4 g0 = cur.g0[mt][ks], g1 = cur.g1[mt][ks];
+                const float4 a0 = *reinterpret_cast<const float4*>(gms + c), a1 = *reinterpret_cast<const float4*>(gms + c + 4);
                 Vec16<bf16_t> zin, dzv;
-                zin.raw = zraw[ks];
+                zin.raw = cur.z[mt][ks];
                 const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float sg = mv ? rs * gv[j] : 0.f;
+                    const float sg = rs * gv[j];
                     dzv.set(j, sg * av[j]);
-                    dgp[ks][j] = fmaf(sg, zin.get(j), dgp[ks][j]);
+                    dgp[ks][j] = fmaf(mv ? sg : 0.f, zin.get(j), dgp[ks][j]);
                 }
                 zf[mt][ks] = dzv.raw;
-                if (mv) st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+                st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
             }
         }
         f32x4_t dl[CT][MT];
@@ -1017,11 +1049,6 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) dl[ct][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        LnRow<NK> lrow[MT];
-        if constexpr (LNB) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ln_bwd_fetch<NK>(lrow[mt], p, m_base + mt * 16 + s, g);
-        }
 #pragma unroll 1
         for (int j = 0; j < NCH; ++j) {
             f32x4_t h[4][MT], da[4][MT];
@@ -1052,8 +1079,8 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 const uint4 pa0 = pack8(h[0][mt], h[1][mt]), pa1 = pack8(h[2][mt], h[3][mt]);
                 pd[mt][0] = pack8(da[0][mt], da[1][mt]);
                 pd[mt][1] = pack8(da[2][mt], da[3][mt]);
-                const int m = m_base + mt * 16 + s;
-                if (ST && m < p.M) {
+                const int m = min(m_base + mt * 16 + s, p.M - 1);
+                if constexpr (ST) {
                     const int64_t off = ((int64_t)m * (4 * C) + 64 * j + 8 * g) * 2;
                     st16(p.act + off, pa0);
                     st16(p.act + off + 64, pa1);
@@ -1063,14 +1090,14 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             }
             prod_tr_nmajor<NK, MT>(dl, lds0 + j * PART, s, g, pd);  // dln += dH . W1  (W1 read transposed)
         }
+        fetch_tile(cur, tile + tstep < ntile ? tile + tstep : tile);  // (the last tile fetches itself again: unconditional)
         if constexpr (LNB) {
             ln_bwd_rows<NK, MT, 0>(p, dl, lrow[0], m_base + s, s, g, lws, dls);
             if constexpr (MT == 2) ln_bwd_rows<NK, MT, 1>(p, dl, lrow[MT - 1], m_base + 16 + s, s, g, lws, dls);
         } else {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = m_base + mt * 16 + s;
-                if (m >= p.M) continue;
+                const int m = min(m_base + mt * 16 + s, p.M - 1);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     const int c = ct * 16 + 4 * g;
@@ -1120,22 +1147,23 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
     if (w0 < w1) atomicAdd((e < C ? dw : db) + (e < C ? e : e - C), t);
 }
 
-template <int NK, bool LNF>
+template <int NK, bool LNF, bool SAVE>
 int launch_fwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK, LNF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_fwd_res_kernel<NK, LNF, SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int grid = cdiv(cdiv(p.M, 32), 8);
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF>), dim3(grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF, SAVE>), dim3(grid), dim3(512), lds, st, p);
     return 0;
 }
 template <int NK>
 int launch_fwd_res(const CmP& p, hipStream_t st) {
-    return p.y ? launch_fwd_res_t<NK, true>(p, st) : launch_fwd_res_t<NK, false>(p, st);
+    if (p.y) return p.z ? launch_fwd_res_t<NK, true, true>(p, st) : launch_fwd_res_t<NK, true, false>(p, st);
+    return p.z ? launch_fwd_res_t<NK, false, true>(p, st) : launch_fwd_res_t<NK, false, false>(p, st);
 }
 // LNB launches: the workgroups' column sums (p.part) are folded into the LayerNorm weight / bias gradient right behind the kernel
 inline int reduce_ln_partials(const CmP& p, int nwg, hipStream_t st) {
@@ -1144,7 +1172,7 @@ inline int reduce_ln_partials(const CmP& p, int nwg, hipStream_t st) {
 }
 template <int NK, int MT, bool ST, bool LNB>
 int launch_bwd_res_t(const CmP& p, hipStream_t st) {
-    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
+    const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 9 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1208,7 +1236,8 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
     LNX_CHECK(a && (a->ln || a->y) && a->w1 && a->w2 && a->b1 && a->b2 && a->gamma && a->x && a->out, "lnx_convmlp_fwd: null operand");
     if (a->y) {
         LNX_CHECK(a->ln_w && a->ln_b && a->ln == nullptr, "lnx_convmlp_fwd: the fused LayerNorm form takes y, ln_w, ln_b and no ln");
-        LNX_CHECK((a->mean == nullptr) == (a->rstd == nullptr), "lnx_convmlp_fwd: mean and rstd must both be given or both be NULL");
+        LNX_CHECK((a->mean == nullptr) == (a->z == nullptr) && (a->rstd == nullptr) == (a->z == nullptr) && (a->ln_out == nullptr) == (a->z == nullptr),
+                  "lnx_convmlp_fwd: with y, the outputs z, ln_out, mean and rstd are written together (what a backward needs) or not at all");
     }
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_fwd: unsupported dtype %d / C %d (bf16, C in {32,64,96,128,192})", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_fwd: empty");

@@ -1050,7 +1050,8 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
         }
         f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1]; f.w2 = c.wptr(k.w2); f.b2 = p->P[k.b2];
         f.gamma = p->P[k.gamma]; f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
-        f.x = c.at<float>(k.xin); f.out = xout; f.z = c.at<void>(k.z);
+        f.x = c.at<float>(k.xin); f.out = xout;
+        if (!p->c.inference) f.z = c.at<void>(k.z);  // (only the backward reads it)
         Timed t(c, 6, 2.0 * M * C * 4 * C * 2);
         RUN(lnx_convmlp_fwd(&f, c.st));
         return 0;
