@@ -141,6 +141,43 @@ __device__ __forceinline__ void prod_nmajor(f32x4_t (&h)[4][MT], uint32_t part_a
     }
 }
 
+// the same with KB k-steps of fragment reads per wait (4 KB registers): the resident kernels, whose waves run without barriers and
+// in pairs of the same shape per SIMD, expose every LDS round trip they wait for
+template <int NK, int MT, int KB>
+__device__ __forceinline__ void prod_nmajor_b(f32x4_t (&h)[4][MT], uint32_t part_addr, int s, int g, const uint4 (&xf)[MT][NK]) {
+    const uint32_t unit = (uint32_t)((g ^ key4(s >> 2)) << 4);
+    const uint32_t base = part_addr + (uint32_t)((8 * (s >> 2) + (s & 3)) * 64) + unit;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) h[nt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k0 = 0; k0 < NK; k0 += KB) {
+        uint4 wf[KB][4];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (k0 + kb < NK) {
+                const uint32_t a = base + (k0 + kb) * 4096;
+                CM_DS_READ128(wf[kb][0], a, 0);
+                CM_DS_READ128(wf[kb][1], a, 256);
+                CM_DS_READ128(wf[kb][2], a, 2048);
+                CM_DS_READ128(wf[kb][3], a, 2304);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (k0 + kb < NK) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mfma16(h[nt][mt], wf[kb][nt], xf[mt][k0 + kb]);
+            }
+        }
+    }
+}
+
 // second-kind product:  O^T[c][m] += sum_n Wc[c][n] * P[n][m]   (n over the chunk's 64 hidden units)
 template <int NK, int MT>
 __device__ __forceinline__ void prod_cmajor(f32x4_t (&o)[Geo<NK>::CT][MT], uint32_t part_addr, int s, int g, const uint4 (&pf)[MT][2]) {
@@ -755,20 +792,26 @@ template <int NK, int MT>
 __device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], uint32_t part_addr, int s, int g, const uint4 (&pf)[MT][2]) {
     constexpr int CT = Geo<NK>::CT;
     const int q = s >> 2, pp = s & 3;
+    // One batch of transposed reads per k-step (all CT channel tiles: 4 CT registers, free at this point of the chunk -- the hidden
+    // accumulators are packed), ONE wait, then the MFMAs.  Per channel tile (read, wait, MFMA) exposed 12 LDS round trips per hidden
+    // chunk of the backward: with two waves per SIMD of the same shape that is idle time, not overlap.
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {
         const int n = 32 * ks2 + 8 * g + q;  // (n >> 3) & 3 == g for this row and the one 4 below
+        uint2 lo[CT], hi[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int ks = ct >> 1;
             const int unit = 2 * (ct & 1) + (pp >> 1);
             const uint32_t a = part_addr + (uint32_t)(ks * 4096 + n * 64 + ((unit ^ key4(g)) << 4) + (pp & 1) * 8);
-            uint2 lo, hi;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi) : "v"(a) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const uint4 wf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[ct]) : "v"(a) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi[ct]) : "v"(a) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const uint4 wf = make_uint4(lo[ct].x, lo[ct].y, hi[ct].x, hi[ct].y);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) mfma16(o[ct][mt], wf, pf[mt][ks2]);
         }
@@ -879,7 +922,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
                 }
             }
             f32x4_t h[4][MT];
-            prod_nmajor<NK, MT>(h, lds0 + j * PART, s, g, xf);
+            prod_nmajor_b<NK, MT, NK>(h, lds0 + j * PART, s, g, xf);
             if constexpr (LAST) {
                 __builtin_amdgcn_sched_barrier(0);  // not above the product that still reads xf
                 load_x(xf, tile + tstep < ntile ? tile + tstep : tile);
@@ -1052,8 +1095,8 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
 #pragma unroll 1
         for (int j = 0; j < NCH; ++j) {
             f32x4_t h[4][MT], da[4][MT];
-            prod_nmajor<NK, MT>(h, lds0 + j * PART, s, g, xf);
-            prod_nmajor<NK, MT>(da, lds0 + NCH * PART + j * PART, s, g, zf);
+            prod_nmajor_b<NK, MT, NK>(h, lds0 + j * PART, s, g, xf);
+            prod_nmajor_b<NK, MT, NK>(da, lds0 + NCH * PART + j * PART, s, g, zf);
             f32x4_t bv[4];
             const uint32_t ba = lds0 + 2 * NCH * PART + (uint32_t)((64 * j + 8 * g) * 4);
             CM_DS_READ128(bv[0], ba, 0);
