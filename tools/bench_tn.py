@@ -15,7 +15,7 @@ for name, M, N, K in [("r0.qkv", 50944, 1152, 384), ("r0.fc1", 50944, 1536, 384)
     A = torch.randn(M, K, device="cuda").bfloat16(); dY = torch.randn(M, N, device="cuda").bfloat16()
     dW = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda"); wsb = torch.empty(L.TN_WS_FLOATS, device="cuda")
     res = []
-    for splits in (0,):
+    for splits in [int(v) for v in os.environ.get("TN_SPLITS", "0").split(",")]:
         w = L.WgradArgs(); w.dtype, w.M, w.N, w.K = L.BF16, M, N, K
         w.dY, w.lddy, w.A, w.lda, w.dW, w.lddw, w.db, w.splits = ptr(dY), N, ptr(A), K, ptr(dW), K, ptr(db), splits
         if os.environ.get("TN_WS", "1") == "1": w.ws, w.ws_floats = ptr(wsb), wsb.numel()
