@@ -239,8 +239,9 @@ __device__ __forceinline__ void imgT_times_regs(f32x4_t (&out)[4], const unsigne
 // ---- the same two products with the number of live 16-row groups as a compile-time constant -------------------------------
 // With a run-time `nt` every group sits under its own branch: hipcc then emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per
 // group -- one exposed LDS round trip per pair of MFMAs (round 3: the resident backward kernels spent most of their key /
-// query loop that way).  The images are staged in units of 32 rows, so two bodies cover every sequence length: NT = 4 for a
-// tile with more than 32 live rows (a fourth group of pure padding costs two MFMAs), NT = 2 for the last tile otherwise.
+// query loop that way).  The images are staged in units of 32 rows.  The forward uses NT = 4 for a tile with more than 32 live rows
+// (a fourth group of pure padding costs two MFMAs) and NT = 2 for the last tile otherwise; the backward kernels walk in steps of
+// NT = 2 throughout (half the live accumulators per step: no scratch).
 // PHASE_FENCE keeps the products of one tile step apart: left free, the scheduler hoists the fragment loads of all of them to
 // the top and the 128-register budget (two workgroups per CU) spills.
 #define PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
