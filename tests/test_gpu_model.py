@@ -758,6 +758,44 @@ def test_recompute_sm_b24_production_dispatch_and_config_flag():
         assert err <= 2e-5 * ga[k].norm().item() + 2e-7, (k, err)
 
 
+def test_fused_block_layernorm_matches_separate_passes(monkeypatch):
+    """sm@224, B = 8, bf16, DropPath on: the plan with the conv-block LayerNorm inside the fused conv-MLP kernels (default) against the
+    plan that runs it as its own forward / backward passes (LNX_NO_FUSED_LN, read when a plan is created).  Same arithmetic up to the
+    summation order of the row statistics: logits agree to bf16 rounding noise, gradients to 1 % globally -- and both paths really are
+    different plans (the LayerNorm gradients are not bit-equal)."""
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300)), drop_path_rate=0.2)
+    B = 8
+    sd = O.seeded_state_dict(O.param_shapes(spec), 41)
+    x, meta = O.seeded_inputs(spec, B, 224, 42)
+    drops = _drop_scales(spec, B, 43)
+
+    def run():
+        model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+        model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+        model = model.cuda()
+        model.set_compute_dtype("bf16")
+        model.train(True)
+        model._inject_drop = drops
+        out = model(x.cuda(), meta.cuda())
+        O.probe_loss(out).backward()
+        return {t: v.detach().float() for t, v in out.items()}, _grads(model)
+
+    out_f, g_f = run()
+    monkeypatch.setenv("LNX_NO_FUSED_LN", "1")
+    out_s, g_s = run()
+    for t in out_f:
+        scale = out_s[t].abs().max().item()
+        assert (out_f[t] - out_s[t]).abs().max().item() <= 0.02 * scale, t
+    num = sum((g_f[k].double() - g_s[k].double()).pow(2).sum().item() for k in g_f) ** 0.5
+    den = sum(g_s[k].double().pow(2).sum().item() for k in g_s) ** 0.5
+    assert num <= 0.01 * den, (num, den)
+    ln_keys = [k for k in g_f if k.startswith("stages.0.") and ".norm." in k]
+    assert ln_keys and any(not torch.equal(g_f[k], g_s[k]) for k in ln_keys), "both runs took the same path"
+    for k in ln_keys:  # the gradients the fused backward produces itself
+        err = (g_f[k] - g_s[k]).norm().item()
+        assert err <= 0.02 * g_s[k].norm().item() + 1e-6, (k, err, g_s[k].norm().item())
+
+
 # ----------------------------------------------------------------------------------------------------
 # (f-4) / config 5: the fp8 MFMA path at the model level (MXFP8 forward products in the RoPE blocks)
 # ----------------------------------------------------------------------------------------------------
