@@ -549,6 +549,7 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
         else if (f == 0) V5_LAUNCH(false, 0);
         else if (f == F_BIAS) V5_LAUNCH(false, F_BIAS);
         else if (f == (F_BIAS | F_C2 | F_GELU)) V5_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
+        else if (f == (F_BIAS | F_GELU)) V5_LAUNCH(false, F_BIAS | F_GELU);
         else V5_LAUNCH(false, F_GELU_BWD);
 #undef V5_LAUNCH
         return 0;
@@ -571,6 +572,7 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
         else if (f == 0) V4_LAUNCH(false, 0);
         else if (f == F_BIAS) V4_LAUNCH(false, F_BIAS);
         else if (f == (F_BIAS | F_C2 | F_GELU)) V4_LAUNCH(false, F_BIAS | F_C2 | F_GELU);
+        else if (f == (F_BIAS | F_GELU)) V4_LAUNCH(false, F_BIAS | F_GELU);
         else V4_LAUNCH(false, F_GELU_BWD);
 #undef V4_LAUNCH
         return 0;
@@ -597,6 +599,8 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
         V2_LAUNCH(false, false, F_BIAS);
     } else if (f == (F_BIAS | F_C2 | F_GELU)) {
         V2_LAUNCH(false, false, F_BIAS | F_C2 | F_GELU);
+    } else if (f == (F_BIAS | F_GELU)) {
+        V2_LAUNCH(false, false, F_BIAS | F_GELU);
     } else {
         V2_LAUNCH(false, false, F_GELU_BWD);
     }

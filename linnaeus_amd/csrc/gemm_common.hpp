@@ -431,7 +431,7 @@ static inline int fast_epilogue_mask(const GemmP& p, bool out_f32) {
     }
     if (p.rowscale && !p.res) return F_GENERIC;
     // the compiled forms
-    if (!out_f32 && (f == 0 || f == F_BIAS || f == (F_BIAS | F_C2 | F_GELU) || f == F_GELU_BWD)) return f;
+    if (!out_f32 && (f == 0 || f == F_BIAS || f == (F_BIAS | F_C2 | F_GELU) || f == (F_BIAS | F_GELU) || f == F_GELU_BWD)) return f;  // (bias + GELU alone: an inference plan's fc1)
     if (out_f32 && f == (F_BIAS | F_RES)) return f;
     return F_GENERIC;
 }

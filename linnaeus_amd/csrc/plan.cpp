@@ -1057,7 +1057,10 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
         return 0;
     }
     lnx_gemm_args g = gemm_base(c, M, 4 * C, C, c.at<void>(k.ln), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.act), 4 * C, false);
-    g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU; g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
+    g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU;
+    if (!p->c.inference) {  // the pre-activation is the backward's
+        g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
+    }
     RUN(gemm_nt_t(c, &g));
     g = gemm_base(c, M, C, 4 * C, c.at<void>(k.act), 4 * C, c.wptr(k.w2), k.w2.ld, xout, C, true);
     g.bias = p->P[k.b2]; g.c2 = c.at<void>(k.z); g.ldc2 = C;
@@ -1144,6 +1147,9 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     // k.hpre holds GELU'(fc1 output) on bf16 / fp32 plans (evaluated here, once, from the fp32 pre-activation: the data-gradient
     // product's epilogue is then one multiply), the pre-activation itself in blocks that run their products in fp8 (those epilogue forms predate this)
     g.bias = p->P[k.fc1b]; g.act = f8 ? LNX_ACT_GELU : LNX_ACT_GELU_D; g.c2 = c.at<void>(k.hpre); g.ldc2 = hid;
+    if (p->c.inference && !f8) {  // nobody differentiates an inference plan: one output, no GELU' tensor
+        g.act = LNX_ACT_GELU; g.c2 = nullptr; g.ldc2 = 0;
+    }
     RUN(linear_fwd(c, g, k.fc1, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     if (p->dmask) {
         // Mlp.drop after the activation and after fc2 (blocks/mlp.py:63,65); the saved `act` is the dropped one, which is
