@@ -89,6 +89,17 @@ typedef struct lnx_gemm_args {
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 
+/* Which kernel family lnx_gemm_nt's dispatcher chose (host-side bookkeeping, no device work): the parity tests use it to prove
+ * that a shape really ran on the kernel it is meant to cover (e.g. the persistent gemm_nt_v7 at the benchmark's M = 50 944).
+ * lnx_last_nt_kernel(): family of the most recent NT launch of this process (any stream), 0 before the first.
+ * lnx_nt_kernel_launches(kind): launches of that family since the library was loaded. */
+enum { LNX_NT_KERNEL_NONE = 0, LNX_NT_KERNEL_V1 = 1 /* 128x128 register-staged, both storage types */, LNX_NT_KERNEL_V2 = 2 /* 256x128 LDS-DMA ring */,
+       LNX_NT_KERNEL_SKINNY = 3 /* M <= 256, one wave per tile */, LNX_NT_KERNEL_V4 = 4 /* 256x256 tile */,
+       LNX_NT_KERNEL_V7 = 7 /* persistent 256x128, deferred stores */, LNX_NT_KERNEL_V9 = 9 /* persistent 256x256 (round 4) */,
+       LNX_NT_KERNEL_EXPERIMENT = 15 /* a kernel of tools/experiments/ (never in the shipped library) */, LNX_NT_KERNEL_KINDS = 16 };
+int lnx_last_nt_kernel(void);
+int64_t lnx_nt_kernel_launches(int kind);
+
 /* fp8 operands (BASELINE config 5's "fp8 MFMA path"; the reference has no fp8 code: this is the MI355X form of its
  * bf16 Linear, mlp.py:46-66 / rope_2d_mhsa.py:432,500).  OCP e4m3fn storage, one dequantisation scale per tensor:
  *   lnx_amax          amax[0] = max(amax[0], max |x|)            (device scalar, caller zeroes it)
@@ -547,10 +558,12 @@ typedef struct lnx_convmlp_bwd_args {
     const float* rstd;
     float* d_ln_w;         /* [C] += */
     float* d_ln_b;         /* [C] += */
-    float* ws;             /* scratch for the per-workgroup column sums: 2 C floats per workgroup (256 workgroups at C <= 96,   */
-    int64_t ws_floats;     /* ceil(M / 128) above); too small = error                                                         */
+    float* ws;             /* scratch for the per-workgroup column sums: lnx_convmlp_bwd_ws_floats(C, M) floats (2 C per workgroup */
+    int64_t ws_floats;     /* of the launch this library would make for (C, M)); too small = error                              */
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
+/* floats of `ws` the fused-LayerNorm backward needs for (C, M), from the same grid choice the launcher makes (0: unsupported C) */
+int64_t lnx_convmlp_bwd_ws_floats(int C, int M);
 
 /* (round 2 had lnx_convmlp_wgrad here: both weight gradients from ln / dz with the hidden recomputed on chip, so that act / dH
  * never reached HBM.  Correct, but slower end to end on MI355X -- 302 + 207 us per block at C = 96 against 317 us for the two

@@ -98,6 +98,8 @@ def lib() -> C.CDLL:
             )
         _lib = C.CDLL(LIB_PATH)
         _lib.lnx_last_error.restype = C.c_char_p
+        _lib.lnx_nt_kernel_launches.restype = C.c_int64
+        _lib.lnx_convmlp_bwd_ws_floats.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(_lib, name):
                 raise LnxError(f"{LIB_PATH} does not export {name}; rebuild it")
@@ -112,10 +114,13 @@ def check(rc: int, what: str) -> None:
 # lnx_aug_pointwise operations (include/lnx.h)
 AUG_CLAMP, AUG_POSTERIZE, AUG_SOLARIZE, AUG_SOLARIZE_ADD, AUG_INVERT, AUG_BRIGHTNESS, AUG_CONTRAST = range(7)
 
+# lnx_last_nt_kernel / lnx_nt_kernel_launches kinds (include/lnx.h)
+NT_KERNEL_NONE, NT_KERNEL_V1, NT_KERNEL_V2, NT_KERNEL_SKINNY, NT_KERNEL_V4, NT_KERNEL_V7, NT_KERNEL_V9, NT_KERNEL_EXPERIMENT = 0, 1, 2, 3, 4, 7, 9, 15
+
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus",
-    "lnx_gemm_nt", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
+    "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_gemm_tn", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
@@ -123,7 +128,7 @@ EXPORTS = [
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
     "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
-    "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd",
+    "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_bwd_ws_floats",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",
     "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end",

@@ -154,14 +154,17 @@ __global__ __launch_bounds__(256) void stencil_kernel(const float* __restrict__ 
 }
 
 // rects[j] = (image, y0, x0, h, w); vals[j, c]: one workgroup column per rectangle
-__global__ __launch_bounds__(256) void erase_kernel(float* __restrict__ x, int C, int H, int W, const int* __restrict__ rects, const float* __restrict__ vals) {
+// (the list lives on the device, the host entry cannot check it: a rectangle of another image, or an empty one, is skipped and
+// every pixel is clipped to the image)
+__global__ __launch_bounds__(256) void erase_kernel(float* __restrict__ x, int B, int C, int H, int W, const int* __restrict__ rects, const float* __restrict__ vals) {
     const int j = blockIdx.y;
     const int b = rects[5 * j], y0 = rects[5 * j + 1], x0 = rects[5 * j + 2], h = rects[5 * j + 3], w = rects[5 * j + 4];
+    if (b < 0 || b >= B || h <= 0 || w <= 0) return;
     const int64_t n = (int64_t)C * h * w;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int ww = (int)(i % w), hh = (int)((i / w) % h), c = (int)(i / ((int64_t)w * h));
         const int yy = y0 + hh, xx = x0 + ww;
-        if (yy < H && xx < W) x[(((int64_t)b * C + c) * H + yy) * W + xx] = vals[(int64_t)j * C + c];
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) x[(((int64_t)b * C + c) * H + yy) * W + xx] = vals[(int64_t)j * C + c];
     }
 }
 
@@ -236,7 +239,7 @@ extern "C" int lnx_erase_rects(float* x, int B, int C, int H, int W, const int* 
     LNX_CHECK(x && B > 0 && C > 0 && H > 0 && W > 0, "lnx_erase_rects: empty tensor");
     if (n_rects == 0) return 0;
     LNX_CHECK(n_rects > 0 && n_rects <= 65535 && rects_dev && values_dev, "lnx_erase_rects: bad rectangle list (%d)", n_rects);
-    hipLaunchKernelGGL(erase_kernel, dim3(16, n_rects), dim3(256), 0, (hipStream_t)stream, x, C, H, W, rects_dev, values_dev);
+    hipLaunchKernelGGL(erase_kernel, dim3(16, n_rects), dim3(256), 0, (hipStream_t)stream, x, B, C, H, W, rects_dev, values_dev);
     LNX_LAUNCH_CHECK();
     return 0;
 }

@@ -1190,6 +1190,20 @@ __global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __
     if (w0 < w1) atomicAdd((e < C ? dw : db) + (e < C ? e : e - C), t);
 }
 
+// waves per workgroup of the streamed-weight kernels: 8 (two per SIMD share one weight stream) unless LNX_CM_NW=4
+static const bool nw8 = !(getenv("LNX_CM_NW") && atoi(getenv("LNX_CM_NW")) == 4);
+
+// workgroups of the backward launch for (C, M) -- ONE place: the launchers below, the LayerNorm partial-sum scratch they check
+// (2 C floats per workgroup) and lnx_convmlp_bwd_ws_floats(), which the plan sizes that scratch from
+static int bwd_grid(int C, int M) {
+    if (C <= 96) {  // resident-weight kernels: 8 waves per workgroup, 16 MT rows per wave tile (MT = 2 at C = 32)
+        const int rows = C == 32 ? 32 : 16;
+        const int grid = cdiv(cdiv(M, rows), 8);
+        return grid > 256 ? 256 : grid;
+    }
+    return cdiv(M, 16 * (nw8 ? 8 : 4));  // streamed-weight kernels: NW waves x 16 rows per workgroup
+}
+
 template <int NK, bool LNF, bool SAVE>
 int launch_fwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
@@ -1221,8 +1235,7 @@ int launch_bwd_res_t(const CmP& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    int grid = cdiv(cdiv(p.M, 16 * MT), 8);
-    if (grid > 256) grid = 256;
+    const int grid = bwd_grid(p.C, p.M);
     if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
     hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB>), dim3(grid), dim3(512), lds, st, p);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
@@ -1257,7 +1270,8 @@ int launch_bwd_t(const CmP& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int grid = cdiv(p.M, 16 * NW * MT);
+    static_assert(MT == 1, "bwd_grid() assumes 16-row wave tiles in the streamed-weight backward");
+    const int grid = bwd_grid(p.C, p.M);
     if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
     hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), dim3(grid), dim3(64 * NW), lds, st, p);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
@@ -1268,10 +1282,12 @@ int launch_bwd(const CmP& p, hipStream_t st) {
     return p.act ? launch_bwd_t<NK, MT, NW, true, false>(p, st) : launch_bwd_t<NK, MT, NW, false, false>(p, st);
 }
 
-// waves per workgroup of the streamed-weight kernels: 8 (two per SIMD share one weight stream) unless LNX_CM_NW=4
-static const bool nw8 = !(getenv("LNX_CM_NW") && atoi(getenv("LNX_CM_NW")) == 4);
-
 }  // namespace
+
+extern "C" int64_t lnx_convmlp_bwd_ws_floats(int C, int M) {
+    if (!lnx_convmlp_supported(LNX_BF16, C) || M <= 0) return 0;
+    return (int64_t)bwd_grid(C, M) * 2 * C;
+}
 
 extern "C" int lnx_convmlp_supported(int dtype, int C) { return dtype == LNX_BF16 && (C == 32 || C == 64 || C == 96 || C == 128 || C == 192); }
 

@@ -15,6 +15,8 @@
 // a vectorised epilogue (bias/gamma as float4).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm_common.hpp"
 
 namespace {
@@ -331,6 +333,21 @@ int launch_tn(const WgradP& p, hipStream_t st) {
 
 static bool g_force_v1 = getenv("LNX_GEMM_V1") != nullptr;  // A/B switch for benchmarking
 
+// dispatch bookkeeping (include/lnx.h: lnx_last_nt_kernel / lnx_nt_kernel_launches)
+static std::atomic<int> g_last_nt{0};
+static std::atomic<long long> g_nt_launches[LNX_NT_KERNEL_KINDS];
+namespace lnxg {
+void note_nt_kernel(int kind) {
+    if (kind < 0 || kind >= LNX_NT_KERNEL_KINDS) return;
+    g_last_nt.store(kind, std::memory_order_relaxed);
+    g_nt_launches[kind].fetch_add(1, std::memory_order_relaxed);
+}
+}  // namespace lnxg
+extern "C" int lnx_last_nt_kernel(void) { return g_last_nt.load(std::memory_order_relaxed); }
+extern "C" int64_t lnx_nt_kernel_launches(int kind) {
+    return (kind < 0 || kind >= LNX_NT_KERNEL_KINDS) ? -1 : (int64_t)g_nt_launches[kind].load(std::memory_order_relaxed);
+}
+
 extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     LNX_CHECK(a != nullptr, "lnx_gemm_nt: null args");
     LNX_CHECK(a->dtype == LNX_F32 || a->dtype == LNX_BF16, "lnx_gemm_nt: bad dtype %d", a->dtype);
@@ -386,13 +403,16 @@ extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     p.tiles_n = cdiv(a->N, TILE);
     hipStream_t st = (hipStream_t)stream;
     if (nt_skinny_ok(p, a->dtype, a->out_f32 != 0) && !g_force_v1) {
+        note_nt_kernel(LNX_NT_KERNEL_SKINNY);
         launch_nt_skinny(p, a->out_f32 != 0, st);
     } else if (nt_v2_ok(p, a->dtype) && !g_force_v1) {
-        launch_nt_v2(p, a->out_f32 != 0, st);
+        launch_nt_v2(p, a->out_f32 != 0, st);  // (notes its own choice: v2 / v4 / v7 / v9)
     } else if (a->dtype == LNX_BF16) {
+        note_nt_kernel(LNX_NT_KERNEL_V1);
         if (a->out_f32) launch_nt<bf16_t, true>(p, st);
         else launch_nt<bf16_t, false>(p, st);
     } else {
+        note_nt_kernel(LNX_NT_KERNEL_V1);
         launch_nt<float, true>(p, st);  // T == float: both output kinds are fp32
     }
     LNX_LAUNCH_CHECK();

@@ -455,9 +455,13 @@ struct WgradP {
 bool nt_v7_ok(const GemmP& p, int f, bool out_f32);
 int launch_nt_v7(const GemmP& p, int f, bool out_f32, hipStream_t st);
 
-// gemm4.hip: persistent 256x128 kernel with the epilogue on its own waves
-bool nt_v8_ok(const GemmP& p, int f, bool out_f32);
-int launch_nt_v8(const GemmP& p, int f, bool out_f32, hipStream_t st);
+// measurement kernels live outside the product (tools/experiments/); their library registers a dispatcher here.  It returns 0
+// when it has launched the product, anything else to decline.  nullptr in the shipped library.
+typedef int (*nt_experiment_fn)(const GemmP& p, int f, bool out_f32, hipStream_t st);
+extern nt_experiment_fn g_nt_experiment;
+
+// which NT kernel family a launch took (lnx_last_nt_kernel / lnx_nt_kernel_launches: the tests' proof of dispatch)
+void note_nt_kernel(int kind);
 
 // gemm_skinny.hip: M <= 256 (one wave per 32x32 output tile, operands straight from L2)
 bool nt_skinny_ok(const GemmP& p, int dtype, bool out_f32);

@@ -623,6 +623,9 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
     LNX_CHECK(a->lda % 16 == 0 && a->ldw % 16 == 0 && ((((uintptr_t)a->A) | ((uintptr_t)a->W)) & 15) == 0, "%s: A/W rows must be 16-byte aligned", who);
     LNX_CHECK(a->a_mode == LNX_ADDR_PLAIN && a->c_mode == LNX_ADDR_PLAIN && a->c_map.group == 0 && a->c_map.pad == 0 && a->c_map.off == 0,
               "%s: plain addressing only", who);
+    // the fp8 epilogues carry GELU (+ pre-activation copy) and GELU' only: GELU_D / MUL_AUX / ReLU would be dispatched on the
+    // feature mask of their bf16 twins and silently compute something else
+    LNX_CHECK(a->act == LNX_ACT_NONE || a->act == LNX_ACT_GELU || a->act == LNX_ACT_GELU_BWD, "%s: act %d is not carried by the fp8 kernels (NONE, GELU, GELU_BWD)", who, a->act);
     if (a->act == LNX_ACT_GELU_BWD) LNX_CHECK(a->aux != nullptr, "%s: GELU_BWD needs aux", who);
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "%s: rowscale needs rows_per_sample", who);
     const bool mx = mxa != nullptr;

@@ -548,11 +548,11 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
                       (getenv("LNX_FUSED_MLP_MAXC") == nullptr || C <= atoi(getenv("LNX_FUSED_MLP_MAXC")));
             any_fused = any_fused || k.fused;
             // LNX_NO_FUSED_LN: the block LayerNorm as its own passes again (A/B switch).  The backward kernel leaves 2C floats of
-            // column sums per workgroup in the LayerNorm scratch: 256 workgroups at C <= 96, one per 128 rows above.
+            // column sums per workgroup in the LayerNorm scratch; how many workgroups is the launcher's business
+            // (lnx_convmlp_bwd_ws_floats), a batch whose sums do not fit keeps the separate LayerNorm passes.
             {
-                const int64_t nwg = C <= 96 ? 256 : (M + 127) / 128;
                 const int64_t lnws = (int64_t)2048 * 2 * (D[3] > D[0] ? D[3] : D[0]);  // = lnws_floats below
-                k.fused_ln = k.fused && getenv("LNX_NO_FUSED_LN") == nullptr && nwg * 2 * C <= lnws;
+                k.fused_ln = k.fused && getenv("LNX_NO_FUSED_LN") == nullptr && lnx_convmlp_bwd_ws_floats((int)C, (int)M) <= lnws;
             }
             if (!k.fused) {
                 k.hpre = share ? f.hpre : cv.take(M * 4 * C * esz);

@@ -277,10 +277,11 @@ def test_tn_padded_logits_rows(M, dtype):
 @pytest.mark.parametrize("N", [128, 256])
 @pytest.mark.parametrize("kind", ["plain", "gelu_c2", "gelu_bwd", "res_f32", "bias_bf16"])
 def test_nt_specialised_epilogues(kind, N):
-    """Large aligned problems take the pipelined kernel with an epilogue compiled for its feature set (gemm2.hip,
-    gemm_epilogue_fast): check every form the plan launches, on a grid of 523 tiles (more than two per CU); N = 256
-    takes the 256x256-tile kernel, N = 128 the 256x128 one."""
-    M, K = 256 * 523, 192
+    """Large aligned problems take the pipelined kernels with an epilogue compiled for its feature set (gemm2.hip,
+    gemm_epilogue_fast; gemm3.hip): every form the plan launches, on a grid of 523 tiles (more than two per CU) and with K = 384
+    (six K slices: the shortest loop the persistent kernel accepts).  N = 256 takes the 256x256-tile kernel; N = 128 the
+    persistent 256x128 kernel (gemm_nt_v7) for the forms it is preferred for and the one-shot 256x128 kernel for the others."""
+    M, K = 256 * 523, 384
     g = torch.Generator().manual_seed(11)
     A = (torch.randn(M, K, generator=g)).cuda().bfloat16()
     W = (torch.randn(N, K, generator=g) / K**0.5).cuda().bfloat16()
@@ -315,20 +316,94 @@ def test_nt_specialised_epilogues(kind, N):
         res = torch.randn(M, N, generator=g).cuda()
         rs = (torch.rand(523, generator=g) > 0.3).float().cuda() / 0.7
         ref = res.double() + z * rs.double().repeat_interleave(256)[:, None]
-        import os
-        saved = os.environ.get("LNX_NT_V8")
-        try:
-            os.environ["LNX_NT_V8"] = "0"  # the kernels that add the fp32 accumulator to the residual
-            out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
-            torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
-            os.environ["LNX_NT_V8"] = "1"  # epilogue waves: the product is rounded to bf16 first (a Linear's output under autocast)
-            out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
-            torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=8e-3 * float(z.abs().max()) / 0.7)
-        finally:
-            if saved is None:
-                os.environ.pop("LNX_NT_V8", None)
-            else:
-                os.environ["LNX_NT_V8"] = saved
+        out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=256, res=res)
+        torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=2e-4)
+    # the dispatcher's own record; which of the pipelined families a form takes is pinned at the benchmark's shapes below
+    assert L.lib().lnx_last_nt_kernel() in (L.NT_KERNEL_V2, L.NT_KERNEL_V4, L.NT_KERNEL_V7, L.NT_KERNEL_V9)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Round 4: the persistent kernel the benchmark's RoPE-block products run on (gemm3.hip: gemm_nt_v7 / gemm_nt_v9), at the
+# benchmark's own M = 256 x 199 = 50 944 rows, every epilogue form x every (N, K) of mFormerV1_sm's stage 3, against fp64.
+# Reference math: rope_2d_mhsa.py:432 (qkv), :500 (proj), blocks/mlp.py:46-66 (fc1 / fc2) and their autograd data gradients.
+# ----------------------------------------------------------------------------------------------------
+M_SM = 256 * 199
+# (form, N, K) the B = 256 plan launches and the default dispatch is expected to give to the persistent kernels
+PLAN_PERSISTENT = {("plain", 384, 384), ("plain", 384, 1152), ("plain", 384, 1536), ("bias", 1152, 384), ("res_f32", 384, 384),
+                   ("res_f32", 384, 1536), ("mul_aux", 1536, 384)}
+
+
+def _gpu_randn(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(*shape, generator=g, device="cuda") * scale
+
+
+def _check_form(form, M, N, K, rows_per_sample=199):
+    """One NT product of the given epilogue form against the fp64 product of the same (bf16-rounded) operands."""
+    A = _gpu_randn((M, K), 1 + M + N + K).bfloat16()
+    W = _gpu_randn((N, K), 2 + N * 3 + K, K**-0.5).bfloat16()
+    b = _gpu_randn((N,), 3)
+    z0 = A.double() @ W.double().T
+    z = z0 + b.double()
+    bt = dict(rtol=8e-3, atol=8e-3)  # bf16 output: one rounding of an O(1) value
+    if form == "plain":
+        out, _ = run_nt(A, W, L.BF16, False)
+        torch.testing.assert_close(out.double(), z0, **bt)
+    elif form == "bias":
+        out, _ = run_nt(A, W, L.BF16, False, bias=b)
+        torch.testing.assert_close(out.double(), z, **bt)
+    elif form == "res_f32":  # proj / fc2: x + DropPath_scale[sample] * (A W^T + b), fp32 residual stream
+        res = _gpu_randn((M, N), 4)
+        nb = -(-M // rows_per_sample)
+        rs = (torch.rand(nb, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) > 0.2).float() / 0.8
+        out, _ = run_nt(A, W, L.BF16, True, bias=b, rowscale=rs, rps=rows_per_sample, res=res)
+        ref = res.double() + z * rs.double().repeat_interleave(rows_per_sample)[:M, None]
+        torch.testing.assert_close(out.double(), ref, rtol=2e-5, atol=3e-4)
+    elif form == "mul_aux":  # fc2 data gradient: dH = (dY W2) * GELU'(h), the factor saved by the forward
+        aux = _gpu_randn((M, N), 6).bfloat16()
+        out, _ = run_nt(A, W, L.BF16, False, act=L.ACT_MUL_AUX, aux=aux)
+        torch.testing.assert_close(out.double(), z0 * aux.double(), rtol=1e-2, atol=1e-2)
+    elif form == "gelu_bwd":  # the same with the derivative evaluated in the epilogue (fp8 blocks, inference-free plans)
+        aux = _gpu_randn((M, N), 6).bfloat16()
+        out, _ = run_nt(A, W, L.BF16, False, act=L.ACT_GELU_BWD, aux=aux)
+        x = aux.double().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        torch.testing.assert_close(out.double(), z0 * x.grad, rtol=1e-2, atol=1e-2)
+    elif form == "fc1":  # GELU(h) and the pre-activation h
+        out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU, want_c2=True)
+        torch.testing.assert_close(c2.double(), z, **bt)
+        torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), rtol=1.2e-2, atol=1.2e-2)
+    else:
+        raise AssertionError(form)
+    return L.lib().lnx_last_nt_kernel()
+
+
+PERSISTENT = (L.NT_KERNEL_V7, L.NT_KERNEL_V9)
+
+
+@pytest.mark.parametrize("K", [384, 1152, 1536])
+@pytest.mark.parametrize("N", [384, 1152, 1536])
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1"])
+def test_nt_persistent_kernel_at_benchmark_rows(form, N, K, monkeypatch):
+    """Default dispatch at M = 50 944: the products of PLAN_PERSISTENT must really run on a persistent kernel (the dispatcher's
+    own record, lnx_last_nt_kernel), every other (form, N, K) on whatever the dispatcher prefers -- all against fp64."""
+    monkeypatch.delenv("LNX_NT_V7", raising=False)
+    kind = _check_form(form, M_SM, N, K)
+    if (form, N, K) in PLAN_PERSISTENT:
+        assert kind in PERSISTENT, (form, N, K, kind)
+    else:
+        assert kind in (L.NT_KERNEL_V2, L.NT_KERNEL_V4) + PERSISTENT, kind
+
+
+@pytest.mark.parametrize("M,N,K", [(M_SM, 384, 384), (M_SM, 1152, 384), (M_SM, 1536, 384), (M_SM, 384, 1536), (M_SM, 1536, 1536), (M_SM, 1152, 1152),
+                                   (M_SM - 37, 448, 384), (M_SM - 37, 448, 1152), (128 * 199, 384, 384), (13312, 768, 768), (13312, 2304, 768), (13312, 768, 3072)])
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1"])
+def test_nt_v7_forced_every_form(form, M, N, K, monkeypatch):
+    """LNX_NT_V7=1: gemm_nt_v7 wherever it can run -- both peelings (K / 64 < 17 and >= 17), a ragged last row tile with a column
+    count that is not a multiple of 128 (M = 50 907, N = 448), the 128-image batch of BASELINE config 3 and the stage-4 shapes."""
+    monkeypatch.setenv("LNX_NT_V7", "1")
+    kind = _check_form(form, M, N, K, rows_per_sample=199 if M != 13312 else 52)
+    assert kind == L.NT_KERNEL_V7, kind
 
 
 @pytest.mark.parametrize("M,N,K,kpc", [(8192, 96, 384, 0), (12800, 384, 1536, 0), (50944, 1536, 384, 0), (6400, 1000, 768, 0), (8192, 192, 384, 96)])
