@@ -30,6 +30,7 @@ TASKS = (("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 2
 FLOP_PER_IMG = 25.79e9          # fwd+bwd FLOPs per image, mFormerV1_sm @224
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+MEASURED_HBM_COPY_GBS = 5000.0   # what a plain streaming copy gets from this HBM (read + written bytes; tools/ubench/hbm_rw.hip: 4.8-5.3 TB/s)
 
 
 def log(msg):
@@ -209,6 +210,86 @@ def cpu_baseline(args, cfg):
             "reference_in_build_container": ref}
 
 
+def live_profile(args, model, state, loss_fn, ips_per_gpu):
+    """Untimed extra steps on rank 0 with HIP events on the launch stream.  Pass 1: an event pair around every launch of the timed
+    kernel classes (time, FLOPs, algorithmic HBM bytes per class).  Pass 2: an event pair around every whole RoPE block and
+    nothing inside it (what the attention + MLP blocks cost in the step -> north-star's own fraction)."""
+    from linnaeus_amd import _lib as L
+
+    lib = L.lib()
+    st = model._active
+    NC = 10
+    x, meta, tg = state["x"], state["meta"], state["tg"]
+    hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
+
+    def run_steps(begin):
+        L.check(begin(st["handle"]), "profile_begin")
+        for _ in range(args.profile_steps):
+            model.zero_grad(set_to_none=True)
+            loss_fn(model(x, meta), tg).backward()
+        ms, work, byts, cnt = (C.c_double * NC)(), (C.c_double * NC)(), (C.c_double * NC)(), (C.c_int * NC)()
+        L.check(lib.lnx_plan_profile_end_ex(st["handle"], ms, work, byts, cnt), "profile_end_ex")
+        return ms, work, byts, cnt
+
+    ms, work, byts, cnt = run_steps(lib.lnx_plan_profile_begin)
+    sms, swork, _, scnt = run_steps(lib.lnx_plan_profile_begin_spans)
+    model._segment_hook = hook
+    n = args.profile_steps
+    kernels = {}
+    names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
+    for i, nm in enumerate(names):
+        if cnt[i] == 0:
+            continue
+        per = {"ms_per_step": round(ms[i] / n, 4), "launches_per_step": cnt[i] // n, "avg_launch_us": round(ms[i] * 1e3 / cnt[i], 2)}
+        if i < 4 or i >= 6:
+            per["tflops"] = round(work[i] / (ms[i] * 1e-3) / 1e12, 2)
+        else:
+            per["gbs"] = round(work[i] / (ms[i] * 1e-3) / 1e9, 1)
+        if byts[i] > 0:
+            per["algorithmic_gb_per_step"] = round(byts[i] / n / 1e9, 3)
+            per["algorithmic_gbs"] = round(byts[i] / (ms[i] * 1e-3) / 1e9, 1)
+        kernels[nm] = per
+    for i, nm in ((8, "rope_block_spans"), (9, "conv_block_spans")):
+        if scnt[i]:
+            kernels[nm] = {"ms_per_step": round(sms[i] / n, 4), "spans_per_step": scnt[i] // n, "tflops": round(swork[i] / (sms[i] * 1e-3) / 1e12, 2)}
+    # ---- the dominant class: forward + data-gradient GEMMs.  Two roofs, both stated; `bound` is the one its own FLOP/byte puts it under.
+    a_tf = work[0] / (ms[0] * 1e-3) / 1e12
+    alg_b = byts[0] / cnt[0]                      # algorithmic bytes per launch
+    intensity = work[0] / byts[0]                 # FLOP per algorithmic byte
+    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the figure comes from the
+    # committed rocprofv3 --pmc passes of this same command (profiles/*_gemm_nt_traffic.json); null for other workloads
+    traffic = traffic_src = None
+    if args.arch == "sm" and state["x"].shape[0] == 256 and args.dtype == "bf16" and args.img == 224:
+        traffic, traffic_src = committed_traffic()
+    launch_s = ms[0] * 1e-3 / cnt[0]
+    hbm = {"algorithmic_bytes_per_launch": round(alg_b), "counter_bytes_per_launch": traffic, "flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+           "achieved_tbs_algorithmic": round(alg_b / launch_s / 1e12, 3),
+           "achieved_tbs_counter": round(traffic / launch_s / 1e12, 3) if traffic else None,
+           "frac_of_spec": round((traffic or alg_b) / launch_s / (PEAK_HBM_GBS * 1e9), 4),
+           "frac_of_measured": round((traffic or alg_b) / launch_s / (MEASURED_HBM_COPY_GBS * 1e9), 4),
+           "spec_gbs": PEAK_HBM_GBS, "measured_copy_gbs": MEASURED_HBM_COPY_GBS, "measured_copy_source": "tools/ubench/hbm_rw.hip, profiles/r03_hbm_rw.log",
+           "mfma_frac_ceiling_at_spec_hbm": round(min(1.0, intensity / ridge), 3),
+           "mfma_frac_ceiling_at_measured_hbm": round(min(1.0, intensity * MEASURED_HBM_COPY_GBS * 1e9 / (PEAK_BF16_TFLOPS * 1e12)), 3)}
+    roofline = {"bound": "hbm" if intensity < ridge else "mfma",
+                "kernel": f"gemm_nt class <{args.dtype}>: forward + data-gradient GEMMs with M >= 1024 (gemm_nt_v2 / v4 one-shot and gemm_nt_v7 / v9 persistent LDS-DMA kernels, fused epilogues)",
+                "achieved": round(a_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a_tf / PEAK_BF16_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
+                "launches_per_step": kernels["gemm_nt"]["launches_per_step"], "flops_per_step": work[0] / n, "hbm": hbm,
+                "note": "frac = achieved / dense bf16 MFMA peak.  The class's FLOP per algorithmic byte is below the ridge, so by its own bytes it is HBM-bound: "
+                        "its MFMA fraction cannot exceed hbm.mfma_frac_ceiling_* at the stated bandwidths"}
+    rope = None
+    if scnt[8]:
+        # north-star: ">= 60 % of MFMA peak on the attention + MLP blocks".  FLOPs = the plan's own count for the RoPE blocks
+        # (forward + 2x backward; BASELINE.md section 2: 15.94 GFLOP/img for sm @224), time = the block spans of pass 2
+        tf = swork[8] / (sms[8] * 1e-3) / 1e12
+        rope = {"frac": round(tf / PEAK_BF16_TFLOPS, 4), "achieved_tflops": round(tf, 2), "ms_per_step": round(sms[8] / n, 3),
+                "gflop_per_image": round(swork[8] / n / state["x"].shape[0] / 1e9, 3), "blocks_timed_per_step": scnt[8] // n,
+                "what": "HIP-event spans around every whole RoPE2DMHSABlock forward and backward on the launch stream (LayerNorms, qkv, attention, proj, Mlp, "
+                        "weight gradients, reduces; no events between the kernels), untimed extra steps"}
+    return roofline, kernels, rope
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, one process per GPU, as
     the driver's own command line does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
@@ -239,17 +320,18 @@ def self_launch(n):
     sys.exit(rc if rc != 0 or line is not None else 1)
 
 
-def default_batch(n_gpus: int) -> int:
-    """Per-GPU batch when --batch is not given: BASELINE config 2's 256 at EVERY N -- "scaling": "weak" in the bench line means that
-    the per-GPU work does not change with the number of GPUs (rounds 1-2 ran 128 per GPU for N > 1, config 3's shape, which folded
-    the batch-size effect into value(N) / (N value(1)); `--batch 128` still runs that shape)."""
-    return 256
+def legs_for(n_gpus, batch):
+    """What `bench.py --gpus N` times.  [(name, per-GPU batch)], the first leg is the line's `value`.
+    N = 1: BASELINE config 2 (256 images).  N > 1: BASELINE config 3 / BASELINE.md section 3's shape -- 128 images per GPU, global
+    batch 128 N (1024 at 8 GPUs) -- is `value`; the 256-per-GPU weak leg is timed in the same run and reported beside it
+    (`weak256`).  --batch B: that one batch at any N."""
+    if batch is not None:
+        return [("batch", batch)]
+    return [("config2", 256)] if n_gpus == 1 else [("config3", 128), ("weak256", 256)]
 
 
 def main():
     args = parse()
-    if args.batch is None:
-        args.batch = default_batch(args.gpus)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,6 +341,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (python bench.py --gpus N starts them itself)")
     if args.eval:
         return eval_throughput(args)
+    legs = legs_for(2 if (args.force_dp and world == 1) else world, args.batch)  # --force-dp: the N > 1 legs rehearsed on one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # stdout carries the one JSON line and nothing else: anything a library prints on the way (RCCL's version banner goes to
@@ -293,7 +376,10 @@ def main():
         from linnaeus_amd.ddp import DataParallel
 
         net = DataParallel(model, single_rank_collectives=args.force_dp)
-    else:
+    elif not (args.drop_in or args.torch_optim):
+        # gradients written straight into the flat arena the fused optimizer reads.  The reference's own glue (--drop-in) and a
+        # torch optimizer get the model's default grad_mode ("autograd": one arena copy per backward + AccumulateGrad), which
+        # is what a drop-in user pays
         model.grad_mode = "direct"
     if args.no_optim:
         opt = None
@@ -308,180 +394,180 @@ def main():
 
     from linnaeus_amd.loss import multitask_cross_entropy
 
-    B = args.batch
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
-    x = torch.rand(B, 3, args.img, args.img, device=dev, generator=g)
-    meta = torch.rand(B, 5, device=dev, generator=g)
-    tg = {t: torch.randint(1, c, (B,), device=dev, generator=g) for t, c in TASKS}
-
     params = [p_ for p_ in model.parameters() if p_.requires_grad]
+    cleanup = []
 
-    feed = None
-    if args.flat_file:
-        import queue
-        import tempfile
-        import threading
+    def make_step(B):
+        """Inputs of one leg (resident in HBM unless --host-input / --flat-file) and the step function over them."""
+        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        state = {"x": torch.rand(B, 3, args.img, args.img, device=dev, generator=g), "meta": torch.rand(B, 5, device=dev, generator=g),
+                 "tg": {t: torch.randint(1, c, (B,), device=dev, generator=g) for t, c in TASKS}}
+        feed = None
+        if args.flat_file:
+            import queue
+            import tempfile
+            import threading
 
-        from linnaeus_amd.aug import u8hwc_to_f32chw
-        from linnaeus_amd.flatdata import FlatBatchLoader, FlatSyntheticDataset, write_synthetic_flat
-        from linnaeus_amd.prefetch import DevicePrefetcher
+            from linnaeus_amd.aug import u8hwc_to_f32chw
+            from linnaeus_amd.flatdata import FlatBatchLoader, FlatSyntheticDataset, write_synthetic_flat
+            from linnaeus_amd.prefetch import DevicePrefetcher
 
-        path = os.path.join(tempfile.gettempdir(), f"lnx_bench_{os.getpid()}_{rank}.flat")
-        write_synthetic_flat(path, 4 * B, args.img, dict(TASKS), meta=(("TEMPORAL", 2), ("SPATIAL", 3)), seed=42 + rank, null_fraction=0.0)
-        ds = FlatSyntheticDataset(path)
-        q = queue.Queue(maxsize=4)
+            fd, path = tempfile.mkstemp(prefix=f"lnx_bench_{rank}_", suffix=".flat")
+            os.close(fd)
+            write_synthetic_flat(path, 4 * B, args.img, dict(TASKS), meta=(("TEMPORAL", 2), ("SPATIAL", 3)), seed=42 + rank, null_fraction=0.0)
+            ds = FlatSyntheticDataset(path)
+            os.unlink(path)  # the memory map keeps the pages; nothing is left in the temp dir whatever happens next
+            q = queue.Queue(maxsize=4)
+            stop = threading.Event()
 
-        def produce():  # the reference's loader workers: read + collate off the training thread, straight into pinned memory
-            for b in FlatBatchLoader(ds, B, shuffle=True, seed=rank, raw_uint8=True, epochs=None, workers=4, pin=True):
-                q.put(b)
+            def produce():  # the reference's loader workers: read + collate off the training thread, straight into pinned memory
+                for b in FlatBatchLoader(ds, B, shuffle=True, seed=rank, raw_uint8=True, epochs=None, workers=4, pin=True):
+                    while not stop.is_set():
+                        try:
+                            q.put(b, timeout=0.2)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
 
-        threading.Thread(target=produce, daemon=True).start()
+            th = threading.Thread(target=produce, daemon=True)
+            th.start()
 
-        def drain():
-            while True:
-                yield q.get()
+            def stop_producer():  # joined before the interpreter (and the HIP runtime its pinned allocations use) shuts down
+                stop.set()
+                while th.is_alive():
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass
+                    th.join(timeout=0.2)
 
-        def to_step(it):
-            for raw, onehot, aux, _masks, _gids in it:
-                yield u8hwc_to_f32chw(raw), aux, {t: onehot[t].argmax(-1) for t, _ in TASKS}
+            cleanup.append(stop_producer)
 
-        feed = to_step(iter(DevicePrefetcher(drain(), dev)))
-    elif args.host_input:
-        from linnaeus_amd.prefetch import DevicePrefetcher
+            def drain():
+                while True:
+                    yield q.get()
 
-        host = [(torch.rand(B, 3, args.img, args.img).pin_memory(), torch.rand(B, 5).pin_memory(),
-                 {t: torch.randint(1, c, (B,)).pin_memory() for t, c in TASKS}) for _ in range(3)]
+            def to_step(it):
+                for raw, onehot, aux, _masks, _gids in it:
+                    yield u8hwc_to_f32chw(raw), aux, {t: onehot[t].argmax(-1) for t, _ in TASKS}
 
-        def cycle():
-            while True:
-                yield from host
+            feed = to_step(iter(DevicePrefetcher(drain(), dev)))
+        elif args.host_input:
+            from linnaeus_amd.prefetch import DevicePrefetcher
 
-        feed = iter(DevicePrefetcher(cycle(), dev))
+            host = [(torch.rand(B, 3, args.img, args.img).pin_memory(), torch.rand(B, 5).pin_memory(),
+                     {t: torch.randint(1, c, (B,)).pin_memory() for t, c in TASKS}) for _ in range(3)]
 
-    def step():
-        nonlocal x, meta, tg
-        if feed is not None:
-            x, meta, tg = next(feed)
-        if args.drop_in:
-            # the reference's step glue (train.py:147-176,279-316) around the drop-in model, torch ops only
+            def cycle():
+                while True:
+                    yield from host
+
+            feed = iter(DevicePrefetcher(cycle(), dev))
+
+        def step():
+            if feed is not None:
+                state["x"], state["meta"], state["tg"] = next(feed)
+            x, meta, tg = state["x"], state["meta"], state["tg"]
+            if args.drop_in:
+                # the reference's step glue (train.py:147-176,279-316) around the drop-in model, torch ops only
+                out = net(x, meta)
+                loss = sum(F.cross_entropy(out[t].float(), tg[t]) for t, _ in TASKS)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, 1.0)
+                if opt is not None:
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                return loss
+            model.zero_grad(set_to_none=True)
             out = net(x, meta)
-            loss = sum(F.cross_entropy(out[t].float(), tg[t]) for t, _ in TASKS)
+            loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE: one HIP launch for all tasks
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
             if opt is not None:
                 opt.step()
-                opt.zero_grad(set_to_none=True)
             return loss
-        model.zero_grad(set_to_none=True)
-        out = net(x, meta)
-        loss = multitask_cross_entropy(out, tg)  # sum over the 4 tasks of the batch-mean CE: one HIP launch for all tasks
-        loss.backward()
-        if opt is not None:
-            opt.step()
-        return loss
 
-    log(f"model on {dev}, batch {B}/GPU; warm-up {args.warmup} steps")
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    log("warm-up done; timing")
-    if dist:
-        dist.barrier(device_ids=[local])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    host_dt = time.perf_counter() - t0  # the host's share: Python + launch calls, returned before the GPU has finished
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier(device_ids=[local])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
-    last_loss = float(loss.item())
-    log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step")
-    ips = world * B * args.steps / dt
+        return step, state
 
-    # ---- data parallel only: the same steps WITHOUT the gradient collectives (no_sync), outside the timed region.
-    # exposed_allreduce_ms = step time with collectives - without; n1_equiv = what one GPU does alone at this per-GPU
-    # batch, so the scaling efficiency value / (n_gpus * n1_equiv) is computable from this one line.
-    dp_extra = None
-    rccl_ranks = None
+    def run_leg(name, B):
+        """W untimed + EXACTLY K timed steps between barrier + device synchronisation on both sides, MAX over ranks; then (data
+        parallel only) the same steps without the gradient collectives, outside the timed region."""
+        step, state = make_step(B)
+        log(f"leg {name}: batch {B}/GPU on {dev}; warm-up {args.warmup} steps")
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        host_dt = time.perf_counter() - t0  # the host's share: Python + launch calls, returned before the GPU has finished
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        res = {"name": name, "per_gpu_batch": B, "global_batch": B * world, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "images_per_sec": round(world * B * args.steps / dt, 2), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
+               "loss": round(float(loss.item()), 4), "step": step, "state": state}
+        log(f"leg {name}: timed {args.steps} steps: {res['ms_per_step']:.2f} ms/step, {res['images_per_sec']:.0f} img/s")
+        # ---- data parallel only: n1_equiv = what ONE GPU does alone at this per-GPU batch (the same steps under no_sync: no
+        # gradient collective is issued), exposed_allreduce_ms = step time with collectives - without, and
+        # scaling_efficiency = images/sec / (n_gpus * n1_equiv): all three from this one run, at this leg's batch
+        if dist and hasattr(net, "no_sync"):
+            k = max(3, min(args.steps, 10))
+            with net.no_sync():
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                dist.barrier(device_ids=[local])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    step()
+                torch.cuda.synchronize()
+                dt_ns = time.perf_counter() - t1
+            tt = torch.tensor([dt_ns], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms_ns = tt.item() / k * 1e3
+            n1 = B / (ms_ns * 1e-3)
+            res.update({"ms_per_step_no_sync": round(ms_ns, 3), "exposed_allreduce_ms": round(res["ms_per_step"] - ms_ns, 3),
+                        "n1_equiv_images_per_sec": round(n1, 2), "scaling_efficiency": round(res["images_per_sec"] / (world * n1), 4)})
+        return res
+
+    results = [run_leg(name, B) for name, B in legs]
+    head = results[0]
+    B = head["per_gpu_batch"]
+    step, state = head["step"], head["state"]
+    ips = head["images_per_sec"]
+
+    rccl = None
     if dist:
         # the world size the communicator itself reports, and proof that a collective saw that many contributions
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
-        rccl_ranks = {"world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()), "backend": dist.get_backend()}
-    if dist and hasattr(net, "no_sync"):
-        k = max(3, min(args.steps, 10))
-        with net.no_sync():
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            dist.barrier(device_ids=[local])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(k):
-                step()
-            torch.cuda.synchronize()
-            dt_ns = time.perf_counter() - t1
-        tt = torch.tensor([dt_ns], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ms_ns = tt.item() / k * 1e3
-        dp_extra = {"ms_per_step_no_sync": round(ms_ns, 3), "exposed_allreduce_ms": round(dt / args.steps * 1e3 - ms_ns, 3),
-                    "n1_equiv_images_per_sec": round(B / (ms_ns * 1e-3), 2),
-                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
-                    "nccl_env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith(("NCCL_", "RCCL_"))}}
+        rccl = {"world_size": dist.get_world_size(), "allreduce_of_ones": int(one.item()), "backend": dist.get_backend(),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                "nccl_env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith(("NCCL_", "RCCL_"))}}
 
     # ---- live per-kernel-class timing (untimed extra steps, rank 0 only) ----
-    roofline, kernels = None, {}
+    roofline, kernels, rope = None, {}, None
     if rank == 0 and args.profile_steps > 0:
-        from linnaeus_amd import _lib as L
-
-        lib = L.lib()
-        st = model._active
-        NC = 8
-        L.check(lib.lnx_plan_profile_begin(st["handle"]), "profile_begin")
-        hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
-        for _ in range(args.profile_steps):
-            model.zero_grad(set_to_none=True)
-            out = model(x, meta)
-            multitask_cross_entropy(out, tg).backward()
-        model._segment_hook = hook
-        ms = (C.c_double * NC)()
-        work = (C.c_double * NC)()
-        cnt = (C.c_int * NC)()
-        L.check(lib.lnx_plan_profile_end(st["handle"], ms, work, cnt), "profile_end")
-        names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
-        for i, nm in enumerate(names):
-            if cnt[i] == 0:
-                continue
-            per = {"ms_per_step": round(ms[i] / args.profile_steps, 4), "launches_per_step": cnt[i] // args.profile_steps,
-                   "avg_launch_us": round(ms[i] * 1e3 / cnt[i], 2)}
-            if i < 4 or i >= 6:
-                per["tflops"] = round(work[i] / (ms[i] * 1e-3) / 1e12, 2)
-            else:
-                per["gbs"] = round(work[i] / (ms[i] * 1e-3) / 1e9, 1)
-            kernels[nm] = per
-        a = work[0] / (ms[0] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure comes
-        # from the committed rocprofv3 --pmc passes of this same command (profiles/*_gemm_nt_traffic.json); null otherwise
-        traffic = traffic_src = None
-        if args.arch == "sm" and args.batch == 256 and args.dtype == "bf16" and args.img == 224:
-            traffic, traffic_src = committed_traffic()
-        roofline = {"bound": "mfma", "kernel": f"gemm_nt_v2 / v4 / v7 kernels <{args.dtype}> (LDS-DMA pipelined forward + data-gradient GEMMs with M >= 1024, fused epilogues)",
-                    "achieved": round(a, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
-                    "launches_per_step": kernels["gemm_nt"]["launches_per_step"],
-                    "flops_per_step": work[0] / args.profile_steps}
+        roofline, kernels, rope = live_profile(args, model, state, multitask_cross_entropy, ips / world)
 
     if dist:
         # every rank gets here before any communicator is torn down (rank 0 has just run its profiled steps alone)
         torch.cuda.synchronize()
         dist.barrier(device_ids=[local])
+    for fn in cleanup:
+        fn()
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -493,25 +579,35 @@ def main():
         log("cpu baseline done")
     line = {
         "metric": f"images/sec (train fwd+bwd) mFormerV1_{args.arch} 3x{args.img}x{args.img}",
-        "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": ips, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "host_enqueue_ms_per_step": head["host_enqueue_ms_per_step"],
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"mFormerV1_{args.arch} train step (forward + 4-task CE loss + backward"
                                f"{' + RCCL gradient all-reduce' if world > 1 else ''}{'' if args.no_optim else ' + AdamW (' + ('torch fused' if args.torch_optim else 'one HIP launch') + ')'}), "
                                f"{'bf16 operands with MXFP8 forward products in the RoPE blocks' if args.dtype == 'fp8' else args.dtype + ' operands'} / fp32 accumulate+residual, batch {B}/GPU, 3x{args.img}x{args.img} synthetic, "
                                "DropPath 0.2, gradient checkpointing off",
-                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "tasks": dict(TASKS)},
+                   "baseline_config": {"config2": "BASELINE.json configs[1]: train fwd+bwd bf16, batch 256, 1 GPU",
+                                       "config3": "BASELINE.json configs[2] / BASELINE.md section 3: 128 images per GPU, global batch 128 N (1024 at 8 GPUs)",
+                                       "weak256": "256 images per GPU", "batch": "--batch given on the command line"}[head["name"]],
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "tasks": dict(TASKS), "grad_mode": model.grad_mode},
         # FLOP_PER_IMG is the sm @224 figure: other architectures / sizes report no whole-step fraction
         "step_mfma_roofline_frac": round(ips / world * FLOP_PER_IMG / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.arch == "sm" and args.img == 224) else None,
-        "loss": round(last_loss, 4),
+        "rope_blocks_mfma_frac": rope["frac"] if rope else None, "rope_blocks": rope,
+        "loss": head["loss"],
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }
-    if rccl_ranks:
-        line["rccl_ranks"] = rccl_ranks["world_size"]
-        line["rccl"] = rccl_ranks
-    if dp_extra:
-        line["data_parallel"] = dp_extra
+    dp_keys = ("ms_per_step_no_sync", "exposed_allreduce_ms", "n1_equiv_images_per_sec", "scaling_efficiency")
+    if rccl:
+        line["rccl_ranks"] = rccl["world_size"]
+        line["rccl"] = rccl
+    if "scaling_efficiency" in head:
+        # value / (n_gpus * n1_equiv), both measured in THIS run at THIS leg's per-GPU batch: not value / (N * the N = 1 line's
+        # value), which at N = 1 is quoted on 256 images
+        line["scaling_efficiency"] = head["scaling_efficiency"]
+        line["data_parallel"] = {k_: head[k_] for k_ in dp_keys}
+    for extra in results[1:]:
+        line[extra["name"]] = {k_: v_ for k_, v_ in extra.items() if k_ not in ("step", "state", "name")}
     if args.recompute:
         line["config"]["workload"] = line["config"]["workload"].replace("gradient checkpointing off", "gradient checkpointing ON (recompute plan)")
         line["workspace_gb"] = round(model._active["ws"].numel() / 1e9, 2)

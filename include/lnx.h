@@ -656,6 +656,17 @@ int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float* dfeats, in
 #define LNX_PROFILE_CLASSES 8
 int lnx_plan_profile_begin(lnx_plan* p);
 int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
+/* Round 4.  lnx_plan_profile_end_ex: as lnx_plan_profile_end with LNX_PROFILE_CLASSES_EX entries per array and, per class, the
+ * ALGORITHMIC HBM bytes of its launches (every operand read once, every output written once; GEMM classes 0 / 1 only) -- what
+ * bench.py's roofline object prices the achieved TB/s and the FLOP/byte of the dominant class with.
+ * lnx_plan_profile_begin_spans: block-level timing instead of per-launch timing -- ONE event pair around each whole block on
+ * the main stream, forward and backward (incl. a recompute plan's re-forward): class 8 = RoPE2DMHSABlock (rope_2d_mhsa.py:584-645:
+ * both LayerNorms, qkv, attention, proj, Mlp, their weight gradients and reduces), work = the block's FLOPs (forward 1x +
+ * backward 2x of its GEMM and attention products: BASELINE.md's 15.94 GFLOP/img for mFormerV1_sm); class 9 = ConvNeXtBlock
+ * (convnext.py:73-87).  No events sit between the kernels of a block, so the span is what the block costs in the timed step. */
+#define LNX_PROFILE_CLASSES_EX 10
+int lnx_plan_profile_begin_spans(lnx_plan* p);
+int lnx_plan_profile_end_ex(lnx_plan* p, double* ms, double* work, double* bytes, int* launches);
 /* indices of the parameters whose gradient is final after `segment`; returns their count.  The metadata heads' backward
  * runs on the plan's side stream and is joined one segment after the one that forks it, so the stage-4 heads report
  * segment 1 and the stage-3 heads segment 2 (a caller that stops early must run the following segment, or -1, to join). */

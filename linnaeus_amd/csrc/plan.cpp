@@ -149,7 +149,8 @@ struct lnx_plan {
     hipEvent_t ev_fork = nullptr, ev_meta = nullptr, ev_bfork[2] = {nullptr, nullptr}, ev_bjoin[2] = {nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
     bool profile = false;
-    struct Span { hipEvent_t e0, e1; int cls; double work; };
+    bool profile_spans = false;  // block-level spans only (classes 8 / 9: whole RoPE / ConvNeXt blocks), no per-launch events
+    struct Span { hipEvent_t e0, e1; int cls; double work, bytes; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -877,10 +878,13 @@ struct Timed {
     hipStream_t st;
     bool on;
     lnx_plan::Span sp;
-    Timed(const Ctx& c, int cls, double work) : p(c.p), st((hipStream_t)c.st), on(c.p->profile && cls >= 0) {
+    // classes 0-7: one launch (lnx_plan_profile_begin); classes 8 / 9: a whole block (lnx_plan_profile_begin_spans)
+    Timed(const Ctx& c, int cls, double work, double bytes = 0.0)
+        : p(c.p), st((hipStream_t)c.st), on(cls >= 0 && (cls >= 8 ? c.p->profile_spans : (c.p->profile && !c.p->profile_spans))) {
         if (on) {
             sp.cls = cls;
             sp.work = work;
+            sp.bytes = bytes;
             sp.e0 = take_event(p);
             sp.e1 = take_event(p);
             (void)hipEventRecord(sp.e0, st);
@@ -893,10 +897,16 @@ struct Timed {
         }
     }
 };
+// algorithmic HBM bytes of one NT product: each operand read once, each output written once, the fp32 residual read once
+double nt_bytes(const Ctx& c, const lnx_gemm_args* a, int a_elem = 0) {
+    const double e = c.p->esz, ea = a_elem ? a_elem : e, mn = (double)a->M * a->N;
+    return ea * ((double)a->M * a->K + (double)a->N * a->K) + (a->out_f32 ? 4.0 : e) * mn + (a->c2 ? e * mn : 0.0) + (a->aux ? e * mn : 0.0) +
+           (a->res ? 4.0 * mn : 0.0) + (a->c8 ? mn * (1.0 + 1.0 / 32) : 0.0);
+}
 int gemm_nt_t(const Ctx& c, const lnx_gemm_args* a) {
     // profile classes 0/1 are the bulk GEMMs; the M = batch problems of the metadata heads and the tail (another
     // kernel, partly on the side stream) are not counted
-    Timed t(c, a->M >= 1024 ? 0 : -1, 2.0 * a->M * a->N * a->K);
+    Timed t(c, a->M >= 1024 ? 0 : -1, 2.0 * a->M * a->N * a->K, nt_bytes(c, a));
     return lnx_gemm_nt(a, c.st);
 }
 
@@ -970,7 +980,7 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
         a.ws = c.at<float>(c.p->o_tnws);
         a.ws_floats = LNX_TN_WS_FLOATS;
     }
-    Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K);
+    Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K, (double)c.p->esz * ((double)M * N + (double)M * K) + 8.0 * N * K);
     return lnx_gemm_tn(&a, c.st);
 }
 
@@ -995,7 +1005,7 @@ int linear_fwd(const Ctx& c, lnx_gemm_args g, const OpW& w, int64_t a8, int64_t 
     if (out8s) {
         g.c8 = c.at<void>(out8); g.ldc8 = g.N; g.c8_scales = c.at<void>(out8s);
     }
-    Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K);
+    Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K, nt_bytes(c, &g, 1));
     return lnx_gemm_nt_mxfp8(&g, c.at<void>(a8s), c.at<void>(w.off8s), c.st);
 }
 
@@ -1012,7 +1022,7 @@ int linear_dgrad(const Ctx& c, lnx_gemm_args g, const OpW& w, bool quantise, int
     if (out8s) {
         g.c8 = c.at<void>(out8); g.ldc8 = g.N; g.c8_scales = c.at<void>(out8s);
     }
-    Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K);
+    Timed t(c, g.M >= 1024 ? 0 : -1, 2.0 * g.M * g.N * g.K, nt_bytes(c, &g, 1));
     return lnx_gemm_nt_mxfp8(&g, c.at<void>(a8s), c.at<void>(w.off8ts), c.st);
 }
 
@@ -1024,6 +1034,7 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
     const int M = B * H * W;
     (void)xin;
     p->resident[s] = i;
+    Timed span(c, 9, 2.0 * M * C * (8.0 * C + 49.0));
     lnx_dwconv_args d;
     memset(&d, 0, sizeof d);
     d.B = B; d.H = H; d.W = W; d.C = C;
@@ -1105,6 +1116,12 @@ int meta_head_fwd(const Ctx& cc, int s, int m, const float* meta, int meta_width
     return 0;
 }
 
+// forward FLOPs of one RoPE2DMHSABlock: qkv + proj + fc1 + fc2 products and the two attention products (SURVEY 8d's count)
+double rope_block_flops(int B, int N, int C, int hid, int heads) {
+    const double M = (double)B * N;
+    return 2.0 * M * C * (3.0 * C + C + 2.0 * hid) + 4.0 * B * heads * (double)N * N * 64.0;
+}
+
 int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     lnx_plan* p = c.p;
     RopeBlk& k = p->rope[s][i];
@@ -1112,6 +1129,7 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     const int N = s == 0 ? p->N2 : p->N3, M = B * N, E = p->E;
     const float* xin = c.at<float>(k.xin);
     p->resident[2 + s] = i;
+    Timed span(c, 8, rope_block_flops(B, N, C, hid, heads));
     const bool f8 = fp8_rows(p, M, C);
     void* a8 = f8 ? c.at<void>(p->o_a8) : nullptr;
     void* a8s = f8 ? c.at<void>(p->o_a8s) : nullptr;
@@ -1335,6 +1353,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     void* sA = c.at<void>(p->o_sA);
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
+    Timed span(c, 8, 2.0 * rope_block_flops(B, N, C, hid, heads));
     // ---- MLP branch ----
     if (!have_dy) RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_fc2, p->inv_keep, M, C, c.st));  // through the dropout after fc2
@@ -1390,6 +1409,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
     void* sA = c.at<void>(p->o_sA);
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
+    Timed span(c, 9, 4.0 * M * C * (8.0 * C + 49.0));
     if (k.fused) {
         void* sB = c.at<void>(p->o_sB);
         lnx_convmlp_bwd_args f;
@@ -1694,6 +1714,16 @@ extern "C" int lnx_plan_segment_params(const lnx_plan* p, int segment, int* idx_
 extern "C" int lnx_plan_profile_begin(lnx_plan* p) {
     if (!p) FAIL("lnx_plan_profile_begin: null plan");
     p->profile = true;
+    p->profile_spans = false;
+    p->spans.clear();
+    p->ev_used = 0;
+    return 0;
+}
+
+extern "C" int lnx_plan_profile_begin_spans(lnx_plan* p) {
+    if (!p) FAIL("lnx_plan_profile_begin_spans: null plan");
+    p->profile = true;
+    p->profile_spans = true;
     p->spans.clear();
     p->ev_used = 0;
     return 0;
@@ -1702,23 +1732,36 @@ extern "C" int lnx_plan_profile_begin(lnx_plan* p) {
 // Ends profiling; synchronises the device and returns, per kernel class, the summed launch
 // time (ms), the summed algorithmic work (FLOPs, or bytes for the HBM-bound classes) and the
 // number of launches.  Arrays must hold LNX_PROFILE_CLASSES entries.
-extern "C" int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches) {
-    if (!p || !ms || !work || !launches) FAIL("lnx_plan_profile_end: null argument");
+static int profile_collect(lnx_plan* p, int ncls, double* ms, double* work, double* bytes, int* launches) {
     p->profile = false;
+    p->profile_spans = false;
     HIPRUN(hipDeviceSynchronize());
-    for (int i = 0; i < LNX_PROFILE_CLASSES; ++i) {
+    for (int i = 0; i < ncls; ++i) {
         ms[i] = 0;
         work[i] = 0;
+        if (bytes) bytes[i] = 0;
         launches[i] = 0;
     }
     for (const auto& sp : p->spans) {
+        if (sp.cls >= ncls) continue;
         float t = 0.f;
         HIPRUN(hipEventElapsedTime(&t, sp.e0, sp.e1));
         ms[sp.cls] += t;
         work[sp.cls] += sp.work;
+        if (bytes) bytes[sp.cls] += sp.bytes;
         launches[sp.cls] += 1;
     }
     p->spans.clear();
     p->ev_used = 0;
     return 0;
+}
+
+extern "C" int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches) {
+    if (!p || !ms || !work || !launches) FAIL("lnx_plan_profile_end: null argument");
+    return profile_collect(p, LNX_PROFILE_CLASSES, ms, work, nullptr, launches);
+}
+
+extern "C" int lnx_plan_profile_end_ex(lnx_plan* p, double* ms, double* work, double* bytes, int* launches) {
+    if (!p || !ms || !work || !bytes || !launches) FAIL("lnx_plan_profile_end_ex: null argument");
+    return profile_collect(p, LNX_PROFILE_CLASSES_EX, ms, work, bytes, launches);
 }

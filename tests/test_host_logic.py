@@ -252,13 +252,17 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert "No HIP GPUs are available" in r.stderr
 
 
-def test_bench_weak_scaling_keeps_the_per_gpu_batch():
-    """bench.py labels its N > 1 lines "scaling": "weak": the per-GPU batch must then be the same at every N (the driver divides
-    value(N) by N * value(1))."""
+def test_bench_legs():
+    """What `bench.py --gpus N` times: N = 1 is BASELINE config 2 (256 images); N > 1 times config 3's 128 images per GPU (global
+    1024 at 8: the line's `value`) AND the 256-per-GPU weak leg in the same run; --batch overrides both."""
     import importlib.util
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert {bench.default_batch(n) for n in (1, 2, 4, 8)} == {256}
+    assert bench.legs_for(1, None) == [("config2", 256)]
+    for n in (2, 4, 8):
+        legs = bench.legs_for(n, None)
+        assert legs[0] == ("config3", 128) and legs[0][1] * 8 == 1024 and ("weak256", 256) in legs
+    assert bench.legs_for(8, 64) == [("batch", 64)]
