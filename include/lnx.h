@@ -29,6 +29,12 @@ const char* lnx_last_error(void);
 int lnx_version(void);
 /* number of compute units of the current device (used to size grids) */
 int lnx_device_cus(void);
+/* Persistent kernels (gemm_nt_v7 / v9, the resident-weight conv-MLP kernels, the depthwise kernels: one workgroup per CU that
+ * draws tiles from atomic counters) launch on (compute units - margin) CUs.  Default 0, or LNX_CU_MARGIN from the environment at
+ * first use.  With the counters a workgroup that cannot be placed beside a resident collective kernel costs nothing (the others
+ * take its tiles); a margin only spares the hardware the queue of unplaceable workgroups.  Replaces nothing in the reference:
+ * torch DDP's NCCL kernels and cuBLAS share the SMs the same way (linnaeus/main.py:936-983). */
+int lnx_set_cu_margin(int cus);
 
 /* Row map for token buffers that carry E extra rows per sample:
  * phys_row = m + (m / group) * pad + off   (group == 0: identity). */

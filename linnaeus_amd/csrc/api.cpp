@@ -2,6 +2,10 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
 
 #include "../../include/lnx.h"
 
@@ -22,4 +26,44 @@ extern "C" int lnx_device_cus(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     return prop.multiProcessorCount;
+}
+
+// ---- tile scheduling of the persistent kernels (common.hpp) ----
+static std::atomic<int> g_cu_margin{-1};
+int persistent_cus(int cus) {
+    int m = g_cu_margin.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("LNX_CU_MARGIN");
+        m = e ? atoi(e) : 0;
+        if (m < 0) m = 0;
+        g_cu_margin.store(m, std::memory_order_relaxed);
+    }
+    const int room = cus - m;
+    return room < 8 ? 8 : room;
+}
+void set_cu_margin(int m) { g_cu_margin.store(m < 0 ? 0 : m, std::memory_order_relaxed); }
+bool tile_sched_static() {
+    const char* e = getenv("LNX_TILE_SCHED");
+    return e && strcmp(e, "static") == 0;
+}
+int next_tile_slot() {
+    static std::atomic<unsigned> seq{0};
+    return (int)(seq.fetch_add(1, std::memory_order_relaxed) % 64u);  // TILE_SLOTS of common.hpp
+}
+int device_cus() {
+    static std::atomic<int> cached{0};  // (one device per process: one process per GPU)
+    int c = cached.load(std::memory_order_relaxed);
+    if (c == 0) {
+        c = lnx_device_cus();
+        if (c > 0) cached.store(c, std::memory_order_relaxed);
+    }
+    return c > 0 ? c : 0;
+}
+extern "C" int lnx_set_cu_margin(int cus) {
+    if (cus < 0 || cus > 128) {
+        lnx_set_error("lnx_set_cu_margin: %d (0..128 compute units)", cus);
+        return 1;
+    }
+    set_cu_margin(cus);
+    return 0;
 }

@@ -38,6 +38,69 @@ void lnx_set_error(const char* fmt, ...);
 #define LNX_LAUNCH_CHECK() LNX_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------------------------
+// Tile scheduling of the persistent kernels (round 4).  One workgroup per CU that owns the CU's LDS / registers cannot be placed
+// beside a resident collective kernel (data-parallel training: the previous backward segment's gradient all-reduce sits on
+// 32-64 CUs for hundreds of microseconds); with `tile += gridDim.x` such a workgroup still owes its whole share when it finally
+// starts and the launch takes two rounds.  Here every tile -- the first one too -- is DRAWN from an atomic counter: the
+// workgroups that run eat the tiles, a latecomer draws a position beyond the end and leaves.
+//   g_tile_ctr[slot][x]   counters of one launch (`slot` handed out round-robin by the host: TILE_SLOTS launches may be in flight), one
+//                         per XCD: workgroup b runs on XCD b & 7 (round-robin dispatch), XCD x owns a contiguous eighth of the
+//                         tiles and a counter that only its own CUs touch -- the line stays in that XCD's L2 (one counter for the
+//                         whole chip bounced between the eight L2s: +10 % on the conv-MLP kernels, 25 000 draws per launch).
+//                         Nothing is stolen across XCDs: a collective's workgroups are dealt round-robin too.  Zero at module
+//                         load.  A counter sees exactly (tiles + drawers) draws per launch -- every drawer's last draw fails --
+//                         so the draw that returns tiles + drawers - 1 is the last, and its owner stores 0 for the next launch.
+// LNX_TILE_SCHED=static restores the stride (A/B); LNX_CU_MARGIN / lnx_set_cu_margin() launch on fewer CUs.
+// ---------------------------------------------------------------------------------
+constexpr int TILE_SLOTS = 64;
+static __device__ unsigned g_tile_ctr[TILE_SLOTS][8][32];  // [slot][XCD][0]: one 128-byte line per XCD counter, so that each stays in
+                                                           // its own XCD's L2 (one instance per translation unit)
+
+// Draw for kernels whose memory waits are the compiler's (conv-MLP, depthwise): a raw-buffer atomic over a 4-byte buffer -- lane 0 is
+// in range, the other lanes fall outside and are dropped by the bounds check: one atomic per wave, no branch, and the compiler counts it
+// like any load (its own s_waitcnt vmcnt(N) in front of the first use).  Lane 0 of the result is the counter's previous value; keep
+// the first use behind a sched_barrier, or the scheduler hoists it (and its wait) up to the draw.
+__device__ __forceinline__ int sched_draw_counted(unsigned* ctr) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(ctr, 0, 4, 0x00020000);
+    return __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, r, (int)(threadIdx.x & 63) * 4, 0, 0);
+}
+// Draw for kernels that count the in-order memory counter themselves (gemm_nt_v7): inline asm with EXEC narrowed to one lane inside
+// the statement, invisible to the compiler's wait insertion; the caller waits before its (inline-asm) consumer reads `result`.
+__device__ __forceinline__ void sched_draw(uint32_t& result, unsigned* ctr) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc parses device functions too and knows no "v" registers)
+    const uint32_t one = 1u;
+    uint64_t save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                 : "=&v"(result), "=&s"(save) : "v"(ctr), "v"(one) : "memory");
+#endif
+}
+__device__ __forceinline__ void sched_reset(unsigned* ctr) { __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A launch of `grid` workgroups splits its n tiles into nx = min(8, grid) contiguous parts, one per XCD (part = blockIdx.x % nx:
+// round-robin dispatch; fewer than 8 workgroups = fewer parts, so that no part is left without a worker).  TileShare: this
+// workgroup's part [base, base + cnt), its index among the part's `workers` workgroups, and the counter line the part draws from.
+struct TileShare {
+    int part, base, cnt, index, workers;
+};
+__device__ __forceinline__ TileShare tile_share(int n) {
+    const int grid = (int)gridDim.x, nx = grid < 8 ? grid : 8;
+    TileShare t;
+    t.part = (int)blockIdx.x % nx;
+    t.index = (int)blockIdx.x / nx;
+    t.workers = grid / nx + (t.part < grid % nx ? 1 : 0);
+    const int q = n / nx, r = n % nx;
+    t.cnt = q + (t.part < r ? 1 : 0);
+    t.base = t.part < r ? t.part * (q + 1) : r * (q + 1) + (t.part - r) * q;
+    return t;
+}
+
+// host side (api.cpp)
+int persistent_cus(int cus);   // CUs a persistent launch may occupy: cus - margin
+void set_cu_margin(int m);
+bool tile_sched_static();      // LNX_TILE_SCHED=static, read per launch
+int next_tile_slot();
+int device_cus();              // cached multiProcessorCount of the current device (0 on failure)
+
+// ---------------------------------------------------------------------------------
 // scalar type traits.  T is the storage type of activations / GEMM operands:
 // bf16 (production) or float (strict-parity mode).  Accumulation is always fp32.
 // ---------------------------------------------------------------------------------

@@ -57,6 +57,7 @@ struct CmP {
     float* rstd;
     float* part;                // bwd: per-workgroup partial sums of dw | db, [gridDim.x][2C]
     int64_t part_floats;
+    int tile_slot;              // resident-weight kernels: tile counter set of this launch (common.hpp), -1 = static stride
     float* dlnw;                // bwd: [C] += LayerNorm weight / bias gradient (host side of the launch: the reduce kernel's targets)
     float* dlnb;
 };
@@ -849,6 +850,12 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             lbs[i] = p.lnb[i];
         }
     }
+    // tile scheduling (common.hpp): each WAVE draws its 32-row tiles from the launch's counter, the first one here, under the
+    // weight DMA (its round trip is covered by the wait below); static stride when tile_slot < 0
+    const bool dyn = p.tile_slot >= 0;
+    const TileShare sh = tile_share((p.M + 31) / 32);
+    unsigned* const ctr = &g_tile_ctr[dyn ? p.tile_slot : 0][sh.part][0];
+    int drawn = dyn ? sched_draw_counted(ctr) : 0;
     dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
     dma_all_cmajor<NK>(w2img, p.w2, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -864,7 +871,6 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     // tile's prefetch (round 3).  So: rows beyond M are clamped to M - 1 (such a lane recomputes row M - 1 and stores the same bytes
     // as its live twin), the optional outputs are a template parameter (SAVE), the DropPath scale is loaded unconditionally.
     const int ntile = (p.M + 31) / 32;
-    const int tstep = gridDim.x * 8;
     auto load_x = [&](uint4 (&dst)[MT][NK], int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -873,13 +879,19 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             for (int ks = 0; ks < NK; ++ks) dst[mt][ks] = ld16((LNF ? p.y : p.ln) + ((int64_t)m * C + ks * 32 + 8 * g) * 2);
         }
     };
-    int tile = blockIdx.x * 8 + wave;
+    // this XCD's tiles [xbase, xbase + xcnt) and its waves; positions are drawn (or strided over, LNX_TILE_SCHED=static) within them
+    const int xbase = sh.base, xcnt = sh.cnt, xwaves = 8 * sh.workers;
+    const int last_draw = xcnt + xwaves - 1;  // one draw per tile + one failed draw per wave: the counter's last answer
+    int pos = dyn ? __builtin_amdgcn_readfirstlane(drawn) : sh.index * 8 + wave;
+    bool reset_ctr = dyn && pos == last_draw;
     uint4 xf[MT][NK];
-    if (tile < ntile) load_x(xf, tile);
+    if (pos < xcnt) load_x(xf, xbase + pos);
     const float* rsp = p.rowscale ? p.rowscale : p.gamma;  // always a valid address; rsf folds the loaded value away when there is no scale
     const float rsf = p.rowscale ? 1.0f : 0.0f;
 
-    for (; tile < ntile; tile += tstep) {
+    int next = 0;
+    for (; pos < xcnt; pos = next) {
+        const int tile = xbase + pos;
         const int m_base = tile * 32;
         if constexpr (LNF) {  // xf holds raw y rows until here (requested one tile ago); first, while few other values are live
 #pragma unroll
@@ -898,6 +910,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             }
         }
         if constexpr (LNF) __builtin_amdgcn_sched_barrier(0);  // keep the loads below out of the block above (C = 96 lives at 256 registers)
+        if (dyn) drawn = sched_draw_counted(ctr);  // the tile after this one; read in the last hidden chunk, NCH - 1 chunks of arithmetic from here
         // The tile's residual rows / DropPath scale (consumed in the epilogue) and the next tile's ln fragments are requested in the LAST
         // hidden-chunk iteration: one chunk of MFMA + GELU work and the epilogue cover the round trip, and the 48 + 24 registers
         // they occupy are not live through the whole chunk loop (at C = 96 that spilled, and a scratch reload waits for every
@@ -913,6 +926,13 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
         auto chunk = [&](const int j, auto lastc) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(lastc)::value;
             if constexpr (LAST) {
+                __builtin_amdgcn_sched_barrier(0);  // the draw's first use (and the wait the compiler puts in front of it) stays down here
+                if (dyn) {  // nothing else of this wave is in flight here: the tile's first stores and the draw are NCH - 1 chunks old
+                    next = __builtin_amdgcn_readfirstlane(drawn);
+                    reset_ctr = reset_ctr || next == last_draw;
+                } else {
+                    next = pos + xwaves;
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = min(m_base + mt * 16 + s, p.M - 1);
@@ -925,7 +945,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             prod_nmajor_b<NK, MT, NK>(h, lds0 + j * PART, s, g, xf);
             if constexpr (LAST) {
                 __builtin_amdgcn_sched_barrier(0);  // not above the product that still reads xf
-                load_x(xf, tile + tstep < ntile ? tile + tstep : tile);
+                load_x(xf, next < xcnt ? xbase + next : tile);
             }
             f32x4_t bv[4];
             const uint32_t ba = lds0 + 2 * NCH * PART + (uint32_t)((64 * j + 8 * g) * 4);
@@ -983,6 +1003,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
             }
         }
     }
+    if (reset_ctr && lane == 0) sched_reset(ctr);
 }
 
 template <int NK, int MT, bool ST, bool LNB>
@@ -1013,6 +1034,10 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             dls[i] = dls[C + i] = 0.f;
         }
     }
+    const bool dyn = p.tile_slot >= 0;  // tile scheduling as in convmlp_fwd_res_kernel
+    const TileShare sh = tile_share((p.M + 16 * MT - 1) / (16 * MT));
+    unsigned* const ctr = &g_tile_ctr[dyn ? p.tile_slot : 0][sh.part][0];
+    int drawn = dyn ? sched_draw_counted(ctr) : 0;
     dma_all_nmajor<NK>(w1img, p.w1, wave, lane);
     dma_all_nmajor<NK>(w2timg, p.w2t, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1028,7 +1053,6 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     // t + 1 are requested after tile t's hidden-chunk loop, BEFORE its epilogue stores, so their round trip runs under the epilogue's
     // arithmetic and the wait for them does not include those stores' acknowledgements.
     const int ntile = (p.M + 16 * MT - 1) / (16 * MT);
-    const int tstep = gridDim.x * 8;
     const float* rsp = p.rowscale ? p.rowscale : p.gamma;
     const float rsf = p.rowscale ? 1.0f : 0.0f;
     struct TileIn {
@@ -1053,10 +1077,15 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             if constexpr (LNB) ln_bwd_fetch<NK>(t.lr[mt], p, m, g);
         }
     };
-    int tile = blockIdx.x * 8 + wave;
+    const int xbase = sh.base, xcnt = sh.cnt, xwaves = 8 * sh.workers;
+    const int last_draw = xcnt + xwaves - 1;
+    int pos = dyn ? __builtin_amdgcn_readfirstlane(drawn) : sh.index * 8 + wave;
+    bool reset_ctr = dyn && pos == last_draw;
     TileIn cur;
-    if (tile < ntile) fetch_tile(cur, tile);
-    for (; tile < ntile; tile += tstep) {
+    if (pos < xcnt) fetch_tile(cur, xbase + pos);
+    int next = 0;
+    for (; pos < xcnt; pos = next) {
+        const int tile = xbase + pos;
         const int m_base = tile * (16 * MT);
         uint4 xf[MT][NK], zf[MT][NK];
         LnRow<NK> lrow[MT];
@@ -1087,6 +1116,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
             }
         }
+        if (dyn) drawn = sched_draw_counted(ctr);  // the tile after this one (behind this tile's dz stores, in front of the chunk loop's)
         f32x4_t dl[CT][MT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -1133,7 +1163,15 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
             }
             prod_tr_nmajor<NK, MT>(dl, lds0 + j * PART, s, g, pd);  // dln += dH . W1  (W1 read transposed)
         }
-        fetch_tile(cur, tile + tstep < ntile ? tile + tstep : tile);  // (the last tile fetches itself again: unconditional)
+        __builtin_amdgcn_sched_barrier(0);  // the draw's first use stays down here: it is older than every store of the chunk loop and the
+                                            // counter is in order, so the wait the compiler puts here lets those stores stay in flight
+        if (dyn) {
+            next = __builtin_amdgcn_readfirstlane(drawn);
+            reset_ctr = reset_ctr || next == last_draw;
+        } else {
+            next = pos + xwaves;
+        }
+        fetch_tile(cur, next < xcnt ? xbase + next : tile);  // (the last tile fetches itself again: unconditional)
         if constexpr (LNB) {
             ln_bwd_rows<NK, MT, 0>(p, dl, lrow[0], m_base + s, s, g, lws, dls);
             if constexpr (MT == 2) ln_bwd_rows<NK, MT, 1>(p, dl, lrow[MT - 1], m_base + 16 + s, s, g, lws, dls);
@@ -1168,6 +1206,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     for (int i = threadIdx.x; i < C; i += 512) atomicAdd(p.dgamma + i, dgs[i]);
     if constexpr (LNB)
         for (int i = threadIdx.x; i < 2 * C; i += 512) p.part[(int64_t)blockIdx.x * (2 * C) + i] = dls[i];
+    if (reset_ctr && lane == 0) sched_reset(ctr);
 }
 
 // dw[c] += sum over workgroups of part[wg][c], db[c] += ... of part[wg][C + c]: one thread per entry and slice of workgroups,
@@ -1204,6 +1243,13 @@ static int bwd_grid(int C, int M) {
     return cdiv(M, 16 * (nw8 ? 8 : 4));  // streamed-weight kernels: NW waves x 16 rows per workgroup
 }
 
+// workgroups a resident-weight (one per CU) launch may use: the CUs minus the margin, 256 at most (the partial-sum scratch is sized for that)
+static int res_room() {
+    const int cus = device_cus();
+    const int room = persistent_cus(cus > 0 ? cus : 256);
+    return room > 256 ? 256 : room;
+}
+
 template <int NK, bool LNF, bool SAVE>
 int launch_fwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
@@ -1213,8 +1259,11 @@ int launch_fwd_res_t(const CmP& p, hipStream_t st) {
         attr = true;
     }
     int grid = cdiv(cdiv(p.M, 32), 8);
-    if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF, SAVE>), dim3(grid), dim3(512), lds, st, p);
+    const int room = res_room();
+    if (grid > room) grid = room;
+    CmP q = p;
+    q.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF, SAVE>), dim3(grid), dim3(512), lds, st, q);
     return 0;
 }
 template <int NK>
@@ -1235,9 +1284,13 @@ int launch_bwd_res_t(const CmP& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    const int grid = bwd_grid(p.C, p.M);
-    if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
-    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB>), dim3(grid), dim3(512), lds, st, p);
+    int grid = bwd_grid(p.C, p.M);
+    if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;  // (checked against the unclamped grid: what lnx_convmlp_bwd_ws_floats reports)
+    const int room = res_room();
+    if (grid > room) grid = room;
+    CmP q = p;
+    q.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB>), dim3(grid), dim3(512), lds, st, q);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
 }
 template <int NK, int MT>

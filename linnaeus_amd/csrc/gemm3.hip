@@ -17,6 +17,18 @@
 // iteration's LDS-DMA pieces: the wait for slice k+1 (issued one iteration earlier) then has to skip exactly this
 // iteration's extras plus the six pieces of slice k+2 -- a compile-time count, because the HEAD / TAIL iterations are
 // peeled (straight-line code: no load sits under a branch).  K / 64 >= 6.
+//
+// Round 4: tiles come from per-XCD ATOMIC COUNTERS instead of `tile += gridDim.x`.  A persistent workgroup owns its CU's LDS and
+// registers; beside an RCCL kernel (data-parallel training: the gradient all-reduce of the previous backward segment is resident on
+// 32-64 CUs for hundreds of microseconds) the workgroups that find no free CU start only when a sibling has finished -- with a static
+// stride each of them still owes its whole share, the launch takes two rounds instead of (256 / free CUs) of one.  With a counter
+// the early workgroups eat the tiles and a latecomer finds none.  The XCD-local tile order is kept: XCD x owns the contiguous
+// logical range xcd_remap() gives it and a counter of its own (workgroup b runs on XCD b & 7 under round-robin dispatch); nothing
+// is stolen across XCDs (a collective's workgroups are dealt round-robin too).  Mechanics: wave 0 fetches the tile AFTER next with
+// one lane (global_atomic_add with return, issued in iteration 0 in front of the LDS-DMA pieces and counted like any other extra of
+// the in-order counter), publishes it through one LDS dword in iteration 1, every wave reads it in iteration 2 -- two iterations
+// before the first use (the ring refill at nk - 2).  The fetch that returns the range's last index is the last one the counter
+// will see in this launch: that workgroup zeroes it for the next launch.  LNX_TILE_SCHED=static restores the stride (A/B).
 #include "gemm_common.hpp"
 
 namespace lnxg {
@@ -76,11 +88,6 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
     // whose first two slices are issued by the last two iterations of the current tile -- the ring never drains
     typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));  // a register vector (an array selected at run time would go to scratch)
     u32x8_t src = {0, 0, 0, 0, 0, 0, 0, 0}, srcn = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {
-        const int logical = xcd_remap(tile, ntiles);
-        n0 = (logical % p.tiles_n) * BN7;
-        m0 = (logical / p.tiles_n) * BM7;
-    };
     auto piece_offset = [&](int j, int m0, int n0) __attribute__((always_inline)) -> uint32_t {
         const int i = wave + 8 * j;
         const int row = 8 * i + (lane >> 3);
@@ -146,9 +153,42 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
         }
     };
 
-    int tile = blockIdx.x, m0, n0;
-    if (tile >= ntiles) return;
-    tile_origin(tile, m0, n0);
+    // this workgroup's XCD range of logical tiles [xbase, xbase + xcnt) and its position `pos` in it (xcd_remap's arithmetic)
+    const TileShare sh = tile_share(ntiles);
+    const int xcnt = sh.cnt, xbase = sh.base, xgrid = sh.workers;  // (xgrid: workgroups of this launch on this XCD)
+    const bool dyn = p.tile_slot >= 0;
+    unsigned* const ctr = &g_tile_ctr[dyn ? p.tile_slot : 0][sh.part][0];
+    const uint32_t slot_addr = lds_base + NST7 * STAGE7;  // the LDS dword the fetched position travels through
+    bool reset_ctr = false;  // this workgroup drew the range's last fetch: it zeroes the counter on its way out
+    int pos = sh.index, m0, n0;
+    if (dyn) {
+        // EVERY tile is drawn, the first one too (0.6 us of L2 round trip per launch): a workgroup that starts late -- its CU was
+        // held by a collective kernel -- then owes nothing.  Draws per XCD and launch: one per tile + one failed draw per workgroup,
+        // so the draw that returns xcnt + xgrid - 1 is the last the counter sees.
+        if (wave == 0) {
+            const uint32_t one = 1u;
+            uint32_t first;
+            uint64_t save;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_waitcnt vmcnt(0)\n\tds_write_b32 %4, %0\n\ts_mov_b64 exec, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(first), "=&s"(save) : "v"(ctr), "v"(one), "v"(slot_addr) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        uint32_t seen0;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen0) : "v"(slot_addr) : "memory");
+        pos = __builtin_amdgcn_readfirstlane((int)seen0);
+        reset_ctr = pos == xcnt + xgrid - 1;
+        __builtin_amdgcn_s_barrier();  // everyone has read the slot before iteration 1 of the first tile may overwrite it
+    }
+    if (pos >= xcnt) {
+        if (reset_ctr && tid == 0) sched_reset(ctr);
+        return;
+    }
+    auto pos_origin = [&](int ps, int& mo, int& no) __attribute__((always_inline)) {
+        const int logical = xbase + ps;
+        no = (logical % p.tiles_n) * BN7;
+        mo = (logical / p.tiles_n) * BM7;
+    };
+    pos_origin(pos, m0, n0);
 #pragma unroll
     for (int j = 0; j < PIECES7; ++j) src[j] = piece_offset(j, m0, n0);
     issue(false, 0, 0);
@@ -165,9 +205,11 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
         const bool live = ncol0 < p.N;                      // column tiles beyond N (wave-uniform: N % 64 == 0): nothing to fetch or store
         const bool full = m0 + BM7 <= p.M;                  // only full tiles defer their stores (every lane then issues every store)
         const int nbc = live ? nb : 0;
-        const int next = tile + gridDim.x;
-        const bool has_next = next < ntiles;
+        // static stride: known now.  Counter: known after iteration 2 (has_next is first looked at in iteration nk - 2 >= 4)
+        int next = pos + xgrid;
+        bool has_next = !dyn && next < xcnt;
         int nm0 = 0, nn0 = 0;
+        uint32_t fetched = 0, seen = 0;  // wave 0 lane 0: the counter's answer; every lane: the published value
 
         // epilogue operands, fetched in the TAIL iterations: GELU' input (bf16) or fp32 residual, then (last group) the bias of
         // this lane's 16 columns and the DropPath scale of its 4 rows
@@ -211,8 +253,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
         // One K iteration.  ST / LD = index of the store / fetch group issued in its memory phase (-1: none).  Slice kt+2 (of
         // the next tile when kt+2 >= nk) is issued after the extras; the wait then lets exactly those younger operations stay
         // in flight, so slice kt+1 -- and everything older, the fetches of earlier iterations included -- has landed.
-        auto kstep = [&](int kt, auto ST, auto LD) __attribute__((always_inline)) {
-            constexpr int st_g = decltype(ST)::value, ld_g = decltype(LD)::value;
+        // FX (counter scheduling only): 1 = wave 0 draws the next position, 2 = it publishes the answer in LDS, 3 = everyone reads it
+        auto kstep = [&](int kt, auto ST, auto LD, auto FX) __attribute__((always_inline)) {
+            constexpr int st_g = decltype(ST)::value, ld_g = decltype(LD)::value, fx = decltype(FX)::value;
             constexpr int s_lo = st_g < 0 ? 0 : st_g * NSTORE / HEAD7, s_hi = st_g < 0 ? 0 : (st_g + 1) * NSTORE / HEAD7;
             constexpr int l_lo = ld_g < 0 ? 0 : ld_g * NLOAD / TAIL7, l_hi = ld_g < 0 ? 0 : (ld_g == TAIL7 - 1 ? NLOAD + NCONST : (ld_g + 1) * NLOAD / TAIL7);
             const uint32_t stg = lds_base + ring * STAGE7;
@@ -221,7 +264,10 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
             V7_READ4(af0, stg + a_off0);
             V7_READ4(wf1, stg + (w_off0 ^ 64u));
             V7_READ4(af1, stg + (a_off0 ^ 64u));
-            const bool do_st = s_hi > s_lo && pending && live;
+            if (fx == 3 && dyn) asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(slot_addr) : "memory");  // waited for with the fragments below
+            // (`pending` already says that the PREVIOUS tile's columns were inside N for this wave; this tile's `live` has nothing to
+            // do with it -- consecutive tiles of a workgroup sit in different column tiles since round 4's drawn order)
+            const bool do_st = s_hi > s_lo && pending;
             if (do_st) {
 #pragma unroll
                 for (int sl = s_lo; sl < s_hi; ++sl) store_slot(sl, false);
@@ -230,21 +276,33 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
 #pragma unroll
                 for (int sl = l_lo; sl < l_hi; ++sl) load_slot(sl);
             }
+            const bool draw = fx == 1 && dyn && wave == 0;  // wave-uniform (scalar) condition: one more operation on wave 0's counter
+            if (draw) sched_draw(fetched, ctr);
             asm volatile("" ::: "memory");  // extras stay in front of this iteration's LDS-DMA pieces
             const int stage2 = ring == 0 ? 2 : ring - 1;  // (ring + 2) % 3
             bool issued = true;
             if (kt + 2 < nk) issue(false, kt + 2, stage2);
             else if (has_next) issue(true, kt + 2 - nk, stage2);
             else issued = false;
+#define V7_WAIT(n)                                                                  \
+    do {                                                                            \
+        if (draw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) + 1) : "memory");    \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory");               \
+    } while (0)
             if (issued) {
                 if (s_hi > s_lo) {
-                    if (do_st) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES7 + (s_hi - s_lo)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES7) : "memory");
+                    if (do_st) V7_WAIT(PIECES7 + (s_hi - s_lo));
+                    else V7_WAIT(PIECES7);
                 } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES7 + (l_hi - l_lo)) : "memory");
+                    V7_WAIT(PIECES7 + (l_hi - l_lo));
                 }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // last tile of this workgroup, last two slices: nothing to keep in flight
+            }
+#undef V7_WAIT
+            if (fx == 2 && dyn && wave == 0) {  // iteration 1's wait retired the draw of iteration 0: hand it to the other waves
+                uint64_t save;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0" : "=&s"(save) : "v"(slot_addr), "v"(fetched) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -264,23 +322,31 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
             ring = ring == 2 ? 0 : ring + 1;
         };
 
-        kstep(0, IC<0>(), IC<-1>());
+        static_assert(HEAD7 >= 3, "the counter's answer travels through iterations 0-2");
+        kstep(0, IC<0>(), IC<-1>(), IC<1>());
+        kstep(1, IC<1>(), IC<-1>(), IC<2>());
+        kstep(2, IC<2>(), IC<-1>(), IC<3>());
+        if (dyn) {
+            next = __builtin_amdgcn_readfirstlane((int)seen);  // the counter's value before this workgroup's add = the position drawn
+            has_next = next < xcnt;
+            reset_ctr = reset_ctr || next == xcnt + xgrid - 1;  // nobody draws after the last of the xcnt + xgrid draws
+        }
         if (has_next) {  // where the next tile's operands are; needed from iteration nk-2 on
-            tile_origin(next, nm0, nn0);
+            pos_origin(next, nm0, nn0);
 #pragma unroll
             for (int j = 0; j < PIECES7; ++j) srcn[j] = piece_offset(j, nm0, nn0);
         }
 #define V7_HEAD(i) \
-    if constexpr (HEAD7 > i) kstep(i, IC<i>(), IC<-1>());
-        V7_HEAD(1) V7_HEAD(2) V7_HEAD(3) V7_HEAD(4) V7_HEAD(5) V7_HEAD(6) V7_HEAD(7)
+    if constexpr (HEAD7 > i) kstep(i, IC<i>(), IC<-1>(), IC<0>());
+        V7_HEAD(3) V7_HEAD(4) V7_HEAD(5) V7_HEAD(6) V7_HEAD(7)
 #undef V7_HEAD
-        for (int kt = HEAD7; kt < nk - TAIL7 - 1; ++kt) kstep(kt, IC<-1>(), IC<-1>());
+        for (int kt = HEAD7; kt < nk - TAIL7 - 1; ++kt) kstep(kt, IC<-1>(), IC<-1>(), IC<0>());
         // a fetch group only exists if it has something to fetch (the last one also carries the constants)
 #define V7_TAIL(i) \
-    if constexpr (TAIL7 > i) kstep(nk - 1 - TAIL7 + i, IC<-1>(), IC<((i == TAIL7 - 1 ? NLOAD + NCONST : NLOAD) > 0) ? i : -1>());
+    if constexpr (TAIL7 > i) kstep(nk - 1 - TAIL7 + i, IC<-1>(), IC<((i == TAIL7 - 1 ? NLOAD + NCONST : NLOAD) > 0) ? i : -1>(), IC<0>());
         V7_TAIL(0) V7_TAIL(1) V7_TAIL(2) V7_TAIL(3) V7_TAIL(4) V7_TAIL(5) V7_TAIL(6) V7_TAIL(7)
 #undef V7_TAIL
-        kstep(nk - 1, IC<-1>(), IC<-1>());  // its wait retired the fetches of the iterations before it
+        kstep(nk - 1, IC<-1>(), IC<-1>(), IC<0>());  // its wait retired the fetches of the iterations before it
 
         // ---- epilogue arithmetic (gemm_epilogue_fast's, result kept in registers); one barrier interval of its own: the other
         // wave group runs its MFMA phase beside it ----
@@ -342,11 +408,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v7_kernel(const GemmP p) {
         }
         if (!has_next) break;  // (waves 4-7 leave one barrier short: they made one more at the start)
         __builtin_amdgcn_s_barrier();
-        tile = next;
+        pos = next;
         m0 = nm0;
         n0 = nn0;
         src = srcn;
     }
+    if (reset_ctr && tid == 0) sched_reset(ctr);
 }
 
 bool nt_v7_ok(const GemmP& p, int f, bool out_f32) {
@@ -365,15 +432,12 @@ int launch_nt_v7(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     p.tiles_m = cdiv(p.M, BM7);
     p.tiles_n = cdiv(p.N, BN7);
     const int ntiles = p.tiles_m * p.tiles_n;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
-        cus = prop.multiProcessorCount;
-    }
-    const int grid = ntiles < cus ? ntiles : cus;  // persistent: one workgroup per CU (144 KiB of LDS each)
-    const size_t lds = NST7 * STAGE7;
+    const int cus = device_cus();
+    if (cus <= 0) return 1;
+    const int room = persistent_cus(cus);              // cus - LNX_CU_MARGIN / lnx_set_cu_margin()
+    const int grid = ntiles < room ? ntiles : room;    // persistent: one workgroup per CU (144 KiB of LDS each)
+    const size_t lds = NST7 * STAGE7 + 16;             // + the dword the next tile's position is published through
+    p.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
     const bool deep = p.K / BK7 >= 17;  // long K loops spread the deferred traffic over 8 + 8 iterations instead of 3 + 2
 #define V7_LAUNCH_(O, FF, H, T)                                                                                                      \
     do {                                                                                                                             \

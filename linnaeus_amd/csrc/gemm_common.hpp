@@ -39,7 +39,8 @@ struct GemmP {
     unsigned char* C8 = nullptr;    // F_MXOUT: MXFP8 copy of the bf16 output and its block scales [N/128][M][4]
     unsigned char* C8s = nullptr;
     int64_t ldc8 = 0;
-    int stagger = 0;  // gemm_nt_v5: start delay of the workgroup in the odd wave slot, in steps of ~1024 cycles
+    int stagger = 0;  // tools/experiments/gemm_nt_v5: start delay of the workgroup in the odd wave slot, in steps of ~1024 cycles
+    int tile_slot = -1;  // persistent kernels: which set of tile counters this launch draws from (-1: static stride)
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive logical tiles land on

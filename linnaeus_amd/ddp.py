@@ -34,8 +34,11 @@ class GradBucketReducer:
     """Average contiguous slices ("buckets") of one flat gradient tensor across ranks."""
 
     def __init__(self, arena: torch.Tensor, bounds: Dict[int, Tuple[int, int]], process_group=None, compress_bf16: bool = False,
-                 single_rank_collectives: bool = False):
+                 single_rank_collectives: bool = False, collective=None):
         self.arena = arena
+        # measurement seam: `collective(buf)` replaces dist.all_reduce on the communication stream (tools/bench_cu_hog.py puts a
+        # stand-in kernel there that occupies CUs and HBM the way a ring all-reduce would, on one GPU)
+        self.collective = collective
         self.force = single_rank_collectives  # issue the collectives even with one rank (exercises the stream logic on one GPU)
         self.bounds = dict(bounds)
         self.pg = process_group
@@ -65,7 +68,9 @@ class GradBucketReducer:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            if self.compress:
+            if self.collective is not None:
+                self.collective(buf)
+            elif self.compress:
                 sc = self._scratch.get(key)
                 if sc is None:
                     sc = self._scratch[key] = torch.empty(hi - lo, dtype=torch.bfloat16, device=buf.device)
@@ -102,9 +107,10 @@ class DataParallel(torch.nn.Module):
     """Wrap a linnaeus_amd mFormerV1 for one-process-per-GPU data parallelism."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, compress_bf16: bool = False, broadcast: bool = True,
-                 single_rank_collectives: bool = False):
+                 single_rank_collectives: bool = False, collective=None):
         super().__init__()
         self.module = module
+        self.collective = collective
         self.force = single_rank_collectives  # test hook: run the collectives with one rank too
         self.pg = process_group
         self.compress = compress_bf16
@@ -120,7 +126,7 @@ class DataParallel(torch.nn.Module):
             return
         m = self.module
         if self._reducer is None or self._reducer.arena.data_ptr() != m._grad_arena.data_ptr():
-            self._reducer = GradBucketReducer(m._grad_arena, m._segment_bounds, self.pg, self.compress, single_rank_collectives=self.force)
+            self._reducer = GradBucketReducer(m._grad_arena, m._segment_bounds, self.pg, self.compress, single_rank_collectives=self.force, collective=self.collective)
         self._reducer.reduce_bucket(seg)
         if seg == 3:
             self._reducer.finish()
