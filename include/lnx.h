@@ -151,10 +151,16 @@ typedef struct lnx_wgrad_args {
     int k_store;    /* >0: only columns k < k_store are stored (zero-padded K) */
     float* ws;      /* optional split-K workspace (device), NULL = atomics */
     int64_t ws_floats; /* its size; LNX_TN_WS_FLOATS always suffices */
+    int defer;      /* round 4.  != 0 (and ws given): the product leaves its split-K partial tiles in ws and the summation into dW / db
+                       is postponed to lnx_gemm_tn_flush(), which sums the partial tiles of ALL postponed products of this host thread
+                       in one launch (up to 8; a ninth, or one on another stream, flushes first).  Every pending product needs its
+                       own ws, untouched until the flush; dW / db are final only after it. */
 } lnx_wgrad_args;
 #define LNX_TN_WS_FLOATS (256 * (256 * 128 + 256))
 
 int lnx_gemm_tn(const lnx_wgrad_args* args, void* stream);
+/* sums the partial tiles of the products postponed with `defer` into their dW / db (no-op when nothing is pending) */
+int lnx_gemm_tn_flush(void* stream);
 
 
 /* ------------------------------------------------------------------------------------

@@ -470,9 +470,16 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     p.splits = cdiv(a->M, mps);
     p.m_per_split = mps;
     hipStream_t st = (hipStream_t)stream;
-    if (tn_v2_ok(p, a->dtype) && !g_force_v1) launch_tn_v2(p, a->splits, st);
+    static const bool no_defer = getenv("LNX_TN_NO_DEFER") != nullptr;  // A/B switch: every product reduces its own partial tiles at once
+    if (tn_v2_ok(p, a->dtype) && !g_force_v1) launch_tn_v2(p, a->splits, st, a->defer != 0 && !no_defer);
     else if (a->dtype == LNX_BF16) launch_tn<bf16_t>(p, st);
     else launch_tn<float>(p, st);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_gemm_tn_flush(void* stream) {
+    tn_flush((hipStream_t)stream);
     LNX_LAUNCH_CHECK();
     return 0;
 }

@@ -355,6 +355,14 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
         }
     }
     if (nt_v4_ok(p, f)) {
+        // LNX_NT_V9: 1 = the persistent 256x256 kernel wherever it can run, 0 = never, unset = with at least 1.5 tiles per CU (below
+        // that a workgroup has no second tile to hide the first one's epilogue under)
+        const char* e9 = getenv("LNX_NT_V9");
+        const int v9 = e9 ? atoi(e9) : -1;
+        if (v9 != 0 && nt_v9_ok(p, f, out_f32) && (v9 == 1 || (int64_t)cdiv(p.M, BM4) * (p.N / BN4) * 2 >= 3 * 256)) {
+            note_nt_kernel(LNX_NT_KERNEL_V9);
+            return launch_nt_v9(p, f, out_f32, st);
+        }
         note_nt_kernel(LNX_NT_KERNEL_V4);
         p.tiles_m = cdiv(p.M, BM4);
         p.tiles_n = p.N / BN4;
@@ -636,9 +644,8 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
 }
 
 // second stage of the workspace path: dW[n, col(k)] += sum over splits of the partial tiles, db likewise
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int RW, int CW) {
+__device__ __forceinline__ void tn_reduce_body(const WgradP& p, int RW, int CW, const int64_t idx) {
     const int kq = (p.k_store + 3) >> 2;  // float4 groups per output row
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int tiles = p.tiles_n * p.tiles_k;
     const size_t tile_floats = (size_t)RW * CW;
     if (idx < (int64_t)p.N * kq) {
@@ -716,11 +723,50 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const WgradP p, int RW, int CW) {
+    tn_reduce_body(p, RW, CW, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Round 4: the second stages of several weight-gradient products in ONE launch (lnx_wgrad_args.defer / lnx_gemm_tn_flush): the four
+// products of a RoPE block or the two of a ConvNeXt block leave their partial tiles in separate workspace regions and one kernel sums
+// them all -- 37 launches of ~11 us per step become 13, each with several times the parallelism of a single reduce.
+constexpr int TN_BATCH = 8;
+struct TnReduceDesc {
+    WgradP p;
+    int RW, CW, block_start;
+};
+struct TnReduceBatch {
+    TnReduceDesc d[TN_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(256) void gemm_tn_reduce_batch_kernel(const TnReduceBatch b) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < TN_BATCH; ++i)
+        if (i < b.n && (int)blockIdx.x >= b.d[i].block_start) j = i;
+    tn_reduce_body(b.d[j].p, b.d[j].RW, b.d[j].CW, (int64_t)((int)blockIdx.x - b.d[j].block_start) * 256 + threadIdx.x);
+}
+
+// deferred second stages of this host thread (one training loop = one thread = one stream; a product deferred on another stream
+// flushes what is pending first)
+static thread_local TnReduceBatch g_tn_pending = {};
+static thread_local int g_tn_pending_blocks = 0;
+static thread_local hipStream_t g_tn_pending_stream = nullptr;
+
+int tn_flush(hipStream_t st) {
+    (void)st;
+    if (g_tn_pending.n == 0) return 0;
+    hipLaunchKernelGGL(gemm_tn_reduce_batch_kernel, dim3((unsigned)g_tn_pending_blocks), dim3(256), 0, g_tn_pending_stream, g_tn_pending);
+    g_tn_pending.n = 0;
+    g_tn_pending_blocks = 0;
+    return 0;
+}
+
 bool tn_v2_ok(const WgradP& p, int dtype) {
     return dtype == LNX_BF16 && p.M % TBM == 0 && p.M >= 4096 && p.N >= 8 && p.K >= 8;
 }
 
-int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
+int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st, bool defer) {
     WgradP p = p0;
     // tile orientation with the least padding waste
     auto waste = [&](int rw, int cw) { return (double)cdiv(p.N, rw) * rw * cdiv(p.K, cw) * cw; };
@@ -770,7 +816,19 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st) {
 #undef TNV2_
     if (p.ws) {
         const int64_t work = (int64_t)p.N * ((p.k_store + 3) >> 2) + (p.db ? p.N : 0);
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, st, p, RW, CW);
+        const int blocks = (int)cdiv(work, 256);
+        if (defer) {
+            if (g_tn_pending.n > 0 && (g_tn_pending_stream != st || g_tn_pending.n == TN_BATCH)) tn_flush(g_tn_pending_stream);
+            TnReduceDesc& d = g_tn_pending.d[g_tn_pending.n++];
+            d.p = p;
+            d.RW = RW;
+            d.CW = CW;
+            d.block_start = g_tn_pending_blocks;
+            g_tn_pending_blocks += blocks;
+            g_tn_pending_stream = st;
+        } else {
+            hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, RW, CW);
+        }
     }
     return 0;
 }

@@ -456,6 +456,10 @@ struct WgradP {
 bool nt_v7_ok(const GemmP& p, int f, bool out_f32);
 int launch_nt_v7(const GemmP& p, int f, bool out_f32, hipStream_t st);
 
+// gemm5.hip: persistent 256x256 kernel (the v4 K loop, tiles drawn from the counters, ring never drained)
+bool nt_v9_ok(const GemmP& p, int f, bool out_f32);
+int launch_nt_v9(const GemmP& p, int f, bool out_f32, hipStream_t st);
+
 // measurement kernels live outside the product (tools/experiments/); their library registers a dispatcher here.  It returns 0
 // when it has launched the product, anything else to decline.  nullptr in the shipped library.
 typedef int (*nt_experiment_fn)(const GemmP& p, int f, bool out_f32, hipStream_t st);
@@ -471,7 +475,8 @@ int launch_nt_skinny(const GemmP& p, bool out_f32, hipStream_t st);
 // gemm2.hip: 256x128 LDS-DMA pipelined kernels (bf16)
 int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);
 bool nt_v2_ok(const GemmP& p, int dtype);
-int launch_tn_v2(const WgradP& p, int splits_hint, hipStream_t st);
+int launch_tn_v2(const WgradP& p, int splits_hint, hipStream_t st, bool defer);
+int tn_flush(hipStream_t st);  // launches the deferred second stages of this thread, if any
 bool tn_v2_ok(const WgradP& p, int dtype);
 
 }  // namespace lnxg

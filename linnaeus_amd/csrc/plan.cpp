@@ -82,6 +82,8 @@ struct Down {
 
 }  // namespace
 
+constexpr int TN_WS_SLOTS = 4;  // split-K workspace regions: the weight-gradient products of one block reduce in one launch
+
 struct lnx_plan {
     lnx_mformer_cfg c;
     int esz;  // sizeof(T)
@@ -667,7 +669,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     if (!inf) {
         p->o_lnws = cv.take(p->lnws_floats * 4);
         p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
-        p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4);
+        p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4 * TN_WS_SLOTS);  // one region per weight-gradient product of a block (their reduces run as one launch)
         // Fused conv-MLP blocks: the backward materialises act / dH ([M, 4C] each) for the two weight-gradient GEMMs (a
         // recomputing weight-gradient kernel existed in round 2 and was slower: DESIGN.md)
         p->o_sA = cv.take(maxM4C * esz);
@@ -966,7 +968,10 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     return lnx_layernorm_bwd(&a, c.st);
 }
 
-int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, int wparam, int bparam, int64_t lddw, int k_store = 0) {
+// `slot` >= 0: the product's split-K partial tiles go to workspace region `slot` and their summation into the gradient is postponed to
+// the block's tn_flush() (lnx_wgrad_args.defer); -1: summed at once
+int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, int wparam, int bparam, int64_t lddw, int k_store = 0,
+          int slot = -1) {
     lnx_wgrad_args a;
     memset(&a, 0, sizeof a);
     a.dtype = c.dt;
@@ -977,8 +982,9 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
     a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
     a.k_store = k_store;
     if (!(c.p->side != nullptr && c.st == (void*)c.p->side)) {  // one workspace: never from the side stream
-        a.ws = c.at<float>(c.p->o_tnws);
+        a.ws = c.at<float>(c.p->o_tnws) + (int64_t)(slot > 0 ? slot : 0) * LNX_TN_WS_FLOATS;
         a.ws_floats = LNX_TN_WS_FLOATS;
+        a.defer = slot >= 0 ? 1 : 0;
     }
     Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K, (double)c.p->esz * ((double)M * N + (double)M * K) + 8.0 * N * K);
     return lnx_gemm_tn(&a, c.st);
@@ -1357,13 +1363,13 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     // ---- MLP branch ----
     if (!have_dy) RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_fc2, p->inv_keep, M, C, c.st));  // through the dropout after fc2
-    RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid));
+    RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid, 0, 0));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = fp8_rows(p, M, C) ? LNX_ACT_GELU_BWD : LNX_ACT_MUL_AUX; a.aux = c.at<void>(k.hpre); a.ldaux = hid;  // what the forward left in hpre
     // fp8 plans: dY is quantised once, the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
     RUN(linear_dgrad(c, a, k.fc2, true, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     if (p->dmask) RUN(lnx_dropout_mul(sA, c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));  // through the dropout after the activation
-    RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C));
+    RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C, 0, 1));
     a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.fc1, false, p->o_h8, p->o_h8s));
     // norm2 backward adds into g and, in the same pass, writes the attention branch's dY (DropPath-scaled g in storage type)
@@ -1372,7 +1378,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_proj, p->inv_keep, M, C, c.st));  // through proj_drop
-    RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C));
+    RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C, 0, 2));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.proj, true, p->o_a8, p->o_a8s));
     lnx_attn_bwd_args ab;
@@ -1388,7 +1394,8 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
         Timed t(c, 3, 14.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_bwd(&ab, c.st));
     }
-    RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C));
+    RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C, 0, 3));
+    RUN(lnx_gemm_tn_flush(c.st));  // the four products' partial tiles -> their gradients, one launch
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
     RUN(gemm_nt_t(c, &a));
     // norm1 backward: g is final for this block; block i-1's MLP-branch dY goes into sC in place of this LN's dy (row-wise
@@ -1428,8 +1435,9 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
         }
-        RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C));
-        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
+        RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
+        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
+        RUN(lnx_gemm_tn_flush(c.st));
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));

@@ -330,7 +330,7 @@ def test_nt_specialised_epilogues(kind, N):
 M_SM = 256 * 199
 # (form, N, K) the B = 256 plan launches and the default dispatch is expected to give to the persistent kernels
 PLAN_PERSISTENT = {("plain", 384, 384), ("plain", 384, 1152), ("plain", 384, 1536), ("bias", 1152, 384), ("res_f32", 384, 384),
-                   ("res_f32", 384, 1536), ("mul_aux", 1536, 384)}
+                   ("res_f32", 384, 1536), ("mul_aux", 1536, 384), ("fc1d", 1536, 384)}
 
 
 def _gpu_randn(shape, seed, scale=1.0):
@@ -373,6 +373,15 @@ def _check_form(form, M, N, K, rows_per_sample=199):
         out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU, want_c2=True)
         torch.testing.assert_close(c2.double(), z, **bt)
         torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), rtol=1.2e-2, atol=1.2e-2)
+    elif form == "fc1d":  # what the training plan's fc1 launches: GELU(h) and GELU'(h)
+        out, c2 = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU_D, want_c2=True)
+        zz = z.clone().requires_grad_(True)
+        torch.nn.functional.gelu(zz).sum().backward()
+        torch.testing.assert_close(c2.double(), zz.grad, **bt)
+        torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **bt)
+    elif form == "bias_gelu":  # an inference plan's fc1: one output
+        out, _ = run_nt(A, W, L.BF16, False, bias=b, act=L.ACT_GELU)
+        torch.testing.assert_close(out.double(), torch.nn.functional.gelu(z), **bt)
     else:
         raise AssertionError(form)
     return L.lib().lnx_last_nt_kernel()
@@ -383,11 +392,12 @@ PERSISTENT = (L.NT_KERNEL_V7, L.NT_KERNEL_V9)
 
 @pytest.mark.parametrize("K", [384, 1152, 1536])
 @pytest.mark.parametrize("N", [384, 1152, 1536])
-@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1"])
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1", "fc1d"])
 def test_nt_persistent_kernel_at_benchmark_rows(form, N, K, monkeypatch):
     """Default dispatch at M = 50 944: the products of PLAN_PERSISTENT must really run on a persistent kernel (the dispatcher's
     own record, lnx_last_nt_kernel), every other (form, N, K) on whatever the dispatcher prefers -- all against fp64."""
     monkeypatch.delenv("LNX_NT_V7", raising=False)
+    monkeypatch.delenv("LNX_NT_V9", raising=False)
     kind = _check_form(form, M_SM, N, K)
     if (form, N, K) in PLAN_PERSISTENT:
         assert kind in PERSISTENT, (form, N, K, kind)
@@ -424,3 +434,76 @@ def test_tn_workspace_reduction(M, N, K, kpc):
         assert torch.equal(dW, dW2) and torch.equal(db, db2)  # well-filled tiles take the workspace path: fixed summation order
     else:
         torch.testing.assert_close(dW, dW2, rtol=1e-5, atol=1e-3)  # poorly filled tiles stay on atomics (fewer bytes)
+
+
+@pytest.mark.parametrize("M,N,K", [(M_SM, 1536, 384), (M_SM, 1536, 1536), (M_SM, 256, 256), (M_SM - 37, 512, 384), (128 * 199, 1536, 384), (13312, 768, 768),
+                                   (13312, 2304, 768), (13312, 3072, 768), (13312, 768, 3072), (1024, 256, 256), (2048, 512, 1024)])
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1", "fc1d", "bias_gelu"])
+def test_nt_v9_forced_every_form(form, M, N, K, monkeypatch):
+    """LNX_NT_V9=1: the persistent 256x256 kernel (gemm5.hip) wherever it can run -- every epilogue form, the shortest K loop it
+    accepts (8 slices of 32) and long ones, a ragged last row tile (which drains its stores instead of counting them), launches with
+    fewer than 8 workgroups (fewer tile shares than XCDs) and the stage-4 / xl-like shapes; against fp64."""
+    monkeypatch.setenv("LNX_NT_V9", "1")
+    monkeypatch.setenv("LNX_NT_V7", "0")
+    kind = _check_form(form, M, N, K, rows_per_sample=199 if M % 199 == 0 or M == M_SM - 37 else 52)
+    assert kind == L.NT_KERNEL_V9, kind
+
+
+def test_tn_deferred_reduces_in_one_launch():
+    """lnx_wgrad_args.defer + lnx_gemm_tn_flush (round 4): the four weight-gradient products of a RoPE block (mFormerV1_sm stage 3 at
+    the benchmark's M) leave their split-K partial tiles in separate workspace regions; nothing reaches dW / db before the flush, one
+    launch then sums them all -- same numbers as the immediate path, bit for bit (same partial tiles, same summation order).  A
+    ninth pending product flushes the first eight by itself."""
+    M = 256 * 199
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]  # fc2, fc1, proj, qkv: (N, K)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ops = []
+    for i, (N, K) in enumerate(shapes):
+        dY = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        ops.append((dY, A, N, K))
+    ws = [torch.full((L.TN_WS_FLOATS,), float("nan"), device="cuda") for _ in shapes]
+
+    def run(defer):
+        outs = []
+        for (dY, A, N, K), w in zip(ops, ws):
+            dW = torch.full((N, K), 0.25, device="cuda")
+            db = torch.full((N,), 0.25, device="cuda")
+            a = L.WgradArgs()
+            a.dtype, a.M, a.N, a.K = L.BF16, M, N, K
+            a.dY, a.lddy, a.A, a.lda = _ptr(dY), N, _ptr(A), K
+            a.dW, a.lddw, a.db = _ptr(dW), K, _ptr(db)
+            a.ws, a.ws_floats, a.defer = _ptr(w), w.numel(), int(defer)
+            L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+            outs.append((dW, db))
+        return outs
+
+    now = run(False)
+    torch.cuda.synchronize()
+    later = run(True)
+    torch.cuda.synchronize()
+    for dW, db in later:  # nothing summed yet
+        assert torch.equal(dW, torch.full_like(dW, 0.25)) and torch.equal(db, torch.full_like(db, 0.25))
+    L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")
+    torch.cuda.synchronize()
+    for (dW0, db0), (dW1, db1), (dY, A, N, K) in zip(now, later, ops):
+        assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+        torch.testing.assert_close(dW1.double(), dY.double().T @ A.double() + 0.25, rtol=1e-4, atol=2e-5 * M**0.5)
+    L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")  # nothing pending: a no-op
+    # nine pending products: the ninth makes the library flush the first eight
+    dY, A, N, K = ops[2]
+    many = []
+    for i in range(9):
+        dW = torch.zeros(N, K, device="cuda")
+        w = torch.empty(L.TN_WS_FLOATS, device="cuda")
+        a = L.WgradArgs()
+        a.dtype, a.M, a.N, a.K = L.BF16, M, N, K
+        a.dY, a.lddy, a.A, a.lda, a.dW, a.lddw = _ptr(dY), N, _ptr(A), K, _ptr(dW), K
+        a.ws, a.ws_floats, a.defer = _ptr(w), w.numel(), 1
+        L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+        many.append((dW, w))
+    torch.cuda.synchronize()
+    assert all(bool(dW.abs().sum() > 0) for dW, _ in many[:8]) and float(many[8][0].abs().sum()) == 0.0
+    L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")
+    torch.cuda.synchronize()
+    assert all(torch.equal(dW, many[0][0]) for dW, _ in many)

@@ -68,7 +68,7 @@ def test_forward_bf16_close_to_reference(name, golden_dir):
         err = np.abs(got - ref).max()
         worst = max(worst, err)
         scale = np.abs(ref).max()
-        assert err <= 0.04 * max(scale, 1.0), f"{task}: bf16 max-abs error {err:.4f} vs logit scale {scale:.3f}"
+        assert err <= 0.025 * max(scale, 1.0), f"{task}: bf16 max-abs error {err:.4f} vs logit scale {scale:.3f}"  # 3x the largest measured (0.008 of scale)
         srt = np.sort(ref, -1)
         margin = srt[:, -1] - srt[:, -2]
         safe = margin > 4 * err
@@ -96,10 +96,16 @@ def test_backward_matches_oracle(name, dtype, golden_dir):
         ck = f"head.{parts[3]}.fc.{parts[4]}" if (parts[0] == "head" and len(parts) >= 5 and parts[2] == "level_classifiers") else k
         got[ck] = p_.grad
     assert sorted(got) == names
-    # fp32: tight per-parameter bound.  bf16: operands/activations are rounded to 8 mantissa bits, so
-    # per-parameter relative error is bounded loosely (25 %: the batch-2 meta-head chains flip ReLU masks) and the whole gradient tightly (5 %).
-    rel_tol = 2e-3 if dtype == "fp32" else 0.25
+    # fp32: tight per-parameter bound.  bf16: operands/activations are rounded to 8 mantissa bits; per parameter 10 % (3x the largest
+    # measured outside the exception), the whole gradient 5 %.  The exception, by name: the metadata-head chains (meta_*_head_*:
+    # Linear -> ReLU -> LN -> ResNorm on a batch of 2-4 rows, mFormerV1.py:282-311) -- one pre-activation that rounds across zero flips
+    # a ReLU mask and with it a whole row's contribution: 25 %.
+    def rel_tol_of(name):
+        if dtype == "fp32":
+            return 2e-3
+        return 0.25 if name.startswith("meta_") else 0.10
     bad = []
+    worst = []
     tot_err = tot_ref = 0.0
     for i, k in enumerate(names):
         g = got[k].float().cpu()
@@ -110,8 +116,11 @@ def test_backward_matches_oracle(name, dtype, golden_dir):
         tot_ref += denom * denom
         if dtype == "fp32":  # the fixture pins the oracle; check the GPU against the reference's own numbers too
             assert abs(g.double().norm().item() - z["grad_norms"][i]) <= 5e-3 * max(z["grad_norms"][i], 1e-3), k
-        if err > rel_tol * max(denom, 1e-3 * (1 if dtype == "fp32" else 10)):
+        worst.append((err / max(denom, 1e-3 * (1 if dtype == "fp32" else 10)), k))
+        if err > rel_tol_of(k) * max(denom, 1e-3 * (1 if dtype == "fp32" else 10)):
             bad.append((k, err, denom))
+    worst.sort(reverse=True)
+    print(f"[{name}/{dtype}] worst per-parameter relative gradient errors: " + ", ".join(f"{k} {e:.3f}" for e, k in worst[:4]))
     assert not bad, bad[:8]
     glob = (tot_err / tot_ref) ** 0.5
     print(f"[{name}/{dtype}] global relative gradient error vs oracle: {glob:.2e}")
@@ -468,7 +477,7 @@ def test_sm_b24_production_dispatch_matches_oracle(dtype):
             torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * scale, msg=t)
             assert (got.argmax(-1) == ref.argmax(-1)).all(), t
         else:
-            assert err <= 0.04 * scale, (t, err, scale)
+            assert err <= 0.025 * scale, (t, err, scale)
             srt = ref.sort(-1).values
             safe = (srt[:, -1] - srt[:, -2]) > 4 * err
             assert (got.argmax(-1)[safe] == ref.argmax(-1)[safe]).all(), t
