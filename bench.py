@@ -217,10 +217,12 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
     from linnaeus_amd import _lib as L
 
     lib = L.lib()
-    st = model._active
     NC = 10
     x, meta, tg = state["x"], state["meta"], state["tg"]
     hook, model._segment_hook = model._segment_hook, None  # no collectives in the profiled steps
+    model.zero_grad(set_to_none=True)
+    loss_fn(model(x, meta), tg).backward()  # makes this leg's plan the active one (another leg may have run since)
+    st = model._active
 
     def run_steps(begin):
         L.check(begin(st["handle"]), "profile_begin")
@@ -235,6 +237,8 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
     sms, swork, _, scnt = run_steps(lib.lnx_plan_profile_begin_spans)
     model._segment_hook = hook
     n = args.profile_steps
+    if cnt[0] == 0 or ms[0] <= 0:
+        return None, {}, None
     kernels = {}
     names = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "dwconv7", "dwconv7_wgrad", "convmlp_fwd", "convmlp_bwd"]
     for i, nm in enumerate(names):

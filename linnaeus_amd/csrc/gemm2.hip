@@ -312,11 +312,29 @@ nt_experiment_fn g_nt_experiment = nullptr;
 // light (plain / bias / fp32 residual); it ties with the 256x256 kernel where that one applies (N % 256 == 0) and with the GELU
 // forms (their epilogue arithmetic, not their stores, is what the K loop waits for), and loses a few percent below two tiles
 // per CU.
+// Round 4: 256x256 or 256x128 tiles for a product whose N allows both?  Every tile of a launch costs the same, so a launch takes
+// ceil(tiles / CUs) rounds whatever the scheduler: 600 tiles of 256x256 on 256 CUs are three rounds for 2.3 rounds of work (the
+// N = 1536 products of BASELINE config 3's 128 images per GPU), the same product in 1200 tiles of 256x128 five half-size rounds.  The
+// big tile moves 1.5x fewer operand bytes per FLOP, which is worth ~3 % at K = 384 and ~12 % on long K loops (profiles/r03_bare_gemm.log).
+// LNX_NT_TILE_COST=0: the round-3 rule (big tile wherever N % 256 == 0).
+static bool big_tile_wins(const GemmP& p) {
+    static const bool off = getenv("LNX_NT_TILE_COST") && atoi(getenv("LNX_NT_TILE_COST")) == 0;
+    if (off) return true;
+    const int dc = device_cus();
+    const int cus = persistent_cus(dc > 0 ? dc : 256);
+    const int64_t rows = cdiv(p.M, 256);
+    const double big = (double)cdiv(rows * (p.N / BN4), (int64_t)cus) * 2.0 * (p.K <= 512 ? 0.97 : 0.88);
+    const double small = (double)cdiv(rows * cdiv(p.N, 128), (int64_t)cus);
+    return small >= 0.93 * big;  // (the small tile has to win by a margin: measured, a tie on paper goes to the big tile at sm / lg / xl)
+}
+
 static bool nt_v7_preferred(const GemmP& p, int f, bool out_f32) {
     const bool two_per_cu = (int64_t)cdiv(p.M, 256) * cdiv(p.N, 128) >= 512;
+    const bool big_better = p.N % BN4 == 0 && big_tile_wins(p);
     if (f == F_GELU_BWD && p.act == LNX_ACT_MUL_AUX) return two_per_cu;  // 121.6 -> 115.7 us at the sm fc2 data gradient, also against the 256x256 tile
+    if (f == F_GELU_BWD || f == (F_BIAS | F_C2 | F_GELU)) return two_per_cu && p.N % BN4 == 0 && !big_better;  // only instead of a badly filling big tile
     if (f != 0 && f != F_BIAS && !(out_f32 && f == (F_BIAS | F_RES))) return false;
-    if (p.N % BN4 == 0) return false;  // the 256x256 tile (half the fill traffic per FLOP) is the better kernel there
+    if (big_better) return false;  // the 256x256 tile (half the fill traffic per FLOP) is the better kernel there
     return two_per_cu;
 }
 
@@ -354,11 +372,11 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
             return launch_nt_v7(p, f, out_f32, st);
         }
     }
-    if (nt_v4_ok(p, f)) {
-        // LNX_NT_V9: 1 = the persistent 256x256 kernel wherever it can run, 0 = never, unset = with at least 1.5 tiles per CU (below
-        // that a workgroup has no second tile to hide the first one's epilogue under)
-        const char* e9 = getenv("LNX_NT_V9");
-        const int v9 = e9 ? atoi(e9) : -1;
+    // LNX_NT_V9: 1 = the persistent 256x256 kernel wherever it can run, 0 = never, unset = with at least 1.5 tiles per CU (below
+    // that a workgroup has no second tile to hide the first one's epilogue under) and where the big tile wins on rounds
+    const char* e9 = getenv("LNX_NT_V9");
+    const int v9 = e9 ? atoi(e9) : -1;
+    if (nt_v4_ok(p, f) && (v9 == 1 || big_tile_wins(p))) {
         if (v9 != 0 && nt_v9_ok(p, f, out_f32) && (v9 == 1 || (int64_t)cdiv(p.M, BM4) * (p.N / BN4) * 2 >= 3 * 256)) {
             note_nt_kernel(LNX_NT_KERNEL_V9);
             return launch_nt_v9(p, f, out_f32, st);

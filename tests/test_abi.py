@@ -73,6 +73,43 @@ def test_argument_validation_without_gpu():
     assert b"multiple" in lib.lnx_last_error()
 
 
+def test_fp8_gemm_rejects_the_activation_forms_it_does_not_carry():
+    """lnx_gemm_nt_fp8 / _mxfp8 carry NONE, GELU (+ pre-activation copy) and GELU_BWD.  GELU_D / MUL_AUX / ReLU map onto the same
+    epilogue feature masks as those, so they must be refused by name (they would silently compute something else, or load from a
+    NULL aux).  Checked on the host, before any launch: the pointers below are never dereferenced."""
+    lib = L.lib()
+    fake = C.c_void_p(0x1000)
+    for act in (L.ACT_GELU_D, L.ACT_MUL_AUX, L.ACT_RELU, L.ACT_RELU_BWD):
+        a = L.GemmArgs()
+        a.dtype, a.M, a.N, a.K = L.BF16, 256, 256, 256
+        a.A, a.lda, a.W, a.ldw, a.C, a.ldc = fake, 256, fake, 256, fake, 256
+        a.act = act
+        assert lib.lnx_gemm_nt_fp8(C.byref(a), None, None, None) != 0, act
+        assert b"not carried by the fp8 kernels" in lib.lnx_last_error(), lib.lnx_last_error()
+        assert lib.lnx_gemm_nt_mxfp8(C.byref(a), fake, fake, None) != 0, act
+        assert b"not carried by the fp8 kernels" in lib.lnx_last_error(), lib.lnx_last_error()
+
+
+def test_conv_mlp_scratch_size_comes_from_the_launcher():
+    """lnx_convmlp_bwd_ws_floats (what the plan sizes the fused-LayerNorm scratch with) = 2 C floats per workgroup of the launch the
+    library would make: resident-weight kernels (C <= 96) at most 256 workgroups of 8 waves x 16 (32 at C = 32) rows, streamed-weight
+    kernels one workgroup per 128 rows; unsupported widths report 0."""
+    lib = L.lib()
+    assert lib.lnx_convmlp_bwd_ws_floats(96, 256 * 56 * 56) == 256 * 2 * 96
+    assert lib.lnx_convmlp_bwd_ws_floats(96, 1000) == -(-1000 // 128) * 2 * 96
+    assert lib.lnx_convmlp_bwd_ws_floats(32, 1000) == -(-1000 // 256) * 2 * 32
+    assert lib.lnx_convmlp_bwd_ws_floats(100, 1000) == 0 and lib.lnx_convmlp_bwd_ws_floats(96, 0) == 0
+    if not os.environ.get("LNX_CM_NW"):
+        assert lib.lnx_convmlp_bwd_ws_floats(192, 256 * 28 * 28) == (256 * 28 * 28 // 128) * 2 * 192
+
+
+def test_cu_margin_is_validated():
+    lib = L.lib()
+    assert lib.lnx_set_cu_margin(-1) != 0 and b"lnx_set_cu_margin" in lib.lnx_last_error()
+    assert lib.lnx_set_cu_margin(200) != 0
+    assert lib.lnx_set_cu_margin(0) == 0
+
+
 def test_plan_create_validates_and_enumerates_parameters():
     from linnaeus_amd.model import _Cfg
 

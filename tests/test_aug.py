@@ -262,3 +262,26 @@ def test_pipeline_and_uint8_path(tmp_path):
     for (raw, *_), (f32, *_) in zip(raw_batches, f32_batches):
         assert raw.is_cuda and raw.dtype == torch.uint8
         assert torch.equal(u8hwc_to_f32chw(raw).cpu(), f32)
+
+
+@gpu
+def test_erase_rects_ignores_rectangles_outside_the_batch_or_the_image():
+    """lnx_erase_rects takes its rectangle list from device memory, so the host entry cannot validate it: a rectangle of an image
+    index outside [0, B), an empty one, or pixels left / above / right / below the image must be skipped, not written."""
+    import ctypes as C
+
+    from linnaeus_amd import _lib as L
+
+    B, Cn, H, W = 2, 3, 8, 8
+    guard = torch.full((4, Cn, H, W), 0.5, device="cuda")  # images 1..2 are the batch, 0 and 3 the canaries around it
+    x = guard[1:3]
+    rects = torch.tensor([[5, 0, 0, 4, 4], [-1, 0, 0, 4, 4], [0, -2, -3, 4, 5], [1, 6, 6, 5, 5], [1, 2, 2, 0, 3]], dtype=torch.int32, device="cuda")
+    vals = torch.arange(1, 1 + rects.shape[0] * Cn, dtype=torch.float32, device="cuda").reshape(-1, Cn)
+    L.check(L.lib().lnx_erase_rects(C.c_void_p(x.data_ptr()), B, Cn, H, W, C.c_void_p(rects.data_ptr()), C.c_void_p(vals.data_ptr()), rects.shape[0],
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lnx_erase_rects")
+    torch.cuda.synchronize()
+    want = torch.full((B, Cn, H, W), 0.5, device="cuda")
+    want[0, :, 0:2, 0:2] = vals[2][:, None, None]  # rows -2..1, columns -3..1 clipped to the image
+    want[1, :, 6:8, 6:8] = vals[3][:, None, None]
+    assert torch.equal(x, want)
+    assert torch.equal(guard[0], torch.full_like(guard[0], 0.5)) and torch.equal(guard[3], torch.full_like(guard[3], 0.5))

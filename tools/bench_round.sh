@@ -10,8 +10,7 @@ run dropin --drop-in --no-cpu-baseline &&
 run hostinput --host-input --no-cpu-baseline &&
 run flatfile --flat-file --no-cpu-baseline &&
 run eval --eval --no-cpu-baseline &&
-run dp_b256 --force-dp --no-cpu-baseline &&
-run dp_b128 --force-dp --batch 128 --no-cpu-baseline &&
+run dp --force-dp --no-cpu-baseline &&
 run recompute --recompute --no-cpu-baseline &&
 run lg384_b64 --arch lg --img 384 --batch 64 --no-cpu-baseline &&
 run xl_b128_bf16 --arch xl --batch 128 --no-cpu-baseline &&
