@@ -346,6 +346,17 @@ int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, const float
 int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* gamma, const float* rowscale,
                        int rows_per_sample, void* dz, float* dgamma, int M, int C, void* stream);
 
+/* Round 4.  The LayerScale gradient of a ConvNeXt block WITHOUT the saved pwconv2 output z (blocks/convnext.py:80-83: x = gamma * z,
+ * z = act . W2^T + b2).  dgamma[c] = sum_m rs g[m, c] z[m, c] = sum_k W2[c, k] (sum_m rs g act[m, k]) + b2[c] sum_m rs g, and the
+ * pwconv2 weight / bias gradients are gamma[c] times those two sums (their dY operand is dz = rs gamma g), so
+ *     dgamma[c] += sign * ( sum_k w[c, k] dw[c, k] + b[c] db[c] ) / gamma[c]
+ * with w, b the fp32 master weight / bias of pwconv2 and dw, db its accumulated gradient.  The expression is linear in (dw, db): the
+ * plan calls it with sign = -1 before the block's weight-gradient product and with sign = +1 after it, which adds exactly this
+ * backward's contribution whatever the gradient buffers held before (gradient accumulation).  With it the forward no longer writes z
+ * (1.4 GB / step at mFormerV1_sm, batch 256) and the backward kernels neither read it nor carry the column sums. */
+int lnx_layerscale_dgamma_from_wgrad(const float* w, const float* dw, int64_t ld, const float* b, const float* db, const float* gamma, float sign,
+                                     float* dgamma, int C, int K, void* stream);
+
 /* Dropout of the RoPE blocks' Linear outputs (MODEL.DROP_RATE: blocks/mlp.py:61-66 `self.drop`, rope_2d_mhsa.py:503
  * `proj_drop`), with the keep mask drawn by the caller (one byte per element, 1 = keep):
  *   lnx_dropout_mul       x[m, c] = mask[m, c] ? x[m, c] * inv_keep : 0            (in place; T or fp32; C % 8 == 0)
@@ -549,7 +560,8 @@ typedef struct lnx_convmlp_bwd_args {
     int dtype, M, C;
     const float* g;        /* [M, C] fp32 gradient of the block output */
     const void* ln;        /* [M, C] bf16 */
-    const void* z;         /* [M, C] bf16 saved by the forward */
+    const void* z;         /* [M, C] bf16 saved by the forward, or NULL (round 4): dgamma is then NOT produced here -- see
+                              lnx_layerscale_dgamma_from_wgrad */
     const void* w1;        /* [4C, C] bf16 */
     const float* b1;
     const void* w2t;       /* [4C, C] bf16 = pwconv2.weight^T */

@@ -582,7 +582,7 @@ extern "C" int lnx_dbg_convmlp_stamps(unsigned long long* out8) { return (int)hi
 // this kernel (ST = false: a caller that only wants the data gradient)
 // LNB: the LayerNorm backward runs in the epilogue (ln_bwd_rows): p.dln receives the gradient wrt the LayerNorm INPUT p.y, and
 // the workgroup's column sums for the LayerNorm weight / bias gradient go to p.part (summed by ln_partials_reduce_kernel)
-template <int NK, int MT, int NW, bool ST, bool LNB>
+template <int NK, int MT, int NW, bool ST, bool LNB, bool DG>
 __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -631,29 +631,31 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             g1v[ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
             a0v[ks] = *reinterpret_cast<const float4*>(p.gamma + c);
             a1v[ks] = *reinterpret_cast<const float4*>(p.gamma + c + 4);
-            zraw[ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
+            if constexpr (DG) zraw[ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
         }
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int c = ks * 32 + 8 * g;
             const float4 g0 = g0v[ks], g1 = g1v[ks], a0 = a0v[ks], a1 = a1v[ks];
             Vec16<bf16_t> zin, dzv;
-            zin.raw = zraw[ks];
+            if constexpr (DG) zin.raw = zraw[ks];
             const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float sg = rs * gv[j];
                 dzv.set(j, sg * av[j]);
-                // dgamma partial: this lane's 8 channels of its row; reduced over rows below
-                const float dgp = mvalid[mt] ? sg * zin.get(j) : 0.f;
-                // sum over the 16 rows (lanes s) of this m-tile that share g: xor-shuffle over the low 4 lane bits
-                float t = dgp;
-                t += __shfl_xor(t, 1, 64);
-                t += __shfl_xor(t, 2, 64);
-                t += __shfl_xor(t, 4, 64);
-                t += __shfl_xor(t, 8, 64);
-                if (s == 0) atomicAdd(&dgs[c + j], t);  // LDS atomic, 4 lanes per wave
+                if constexpr (DG) {
+                    // dgamma partial: this lane's 8 channels of its row; reduced over rows below
+                    const float dgp = mvalid[mt] ? sg * zin.get(j) : 0.f;
+                    // sum over the 16 rows (lanes s) of this m-tile that share g: xor-shuffle over the low 4 lane bits
+                    float t = dgp;
+                    t += __shfl_xor(t, 1, 64);
+                    t += __shfl_xor(t, 2, 64);
+                    t += __shfl_xor(t, 4, 64);
+                    t += __shfl_xor(t, 8, 64);
+                    if (s == 0) atomicAdd(&dgs[c + j], t);  // LDS atomic, 4 lanes per wave
+                }
             }
             zf[mt][ks] = dzv.raw;
             st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
@@ -744,7 +746,8 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 64 * NW) atomicAdd(p.dgamma + i, dgs[i]);
+    if constexpr (DG)
+        for (int i = threadIdx.x; i < C; i += 64 * NW) atomicAdd(p.dgamma + i, dgs[i]);
     if constexpr (LNB)
         for (int i = threadIdx.x; i < 2 * C; i += 64 * NW) p.part[(int64_t)blockIdx.x * (2 * C) + i] = dls[i];
 }
@@ -820,8 +823,9 @@ __device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], ui
 }
 
 template <bool V> struct BoolC { static constexpr bool value = V; };
-// SAVE: the outputs the backward needs are written -- z, and with LNF the normalised rows and the row statistics (all or none)
-template <int NK, bool LNF, bool SAVE>
+// SAVE: the outputs a backward needs are written: 1 = z and, with LNF, the normalised rows + row statistics; 2 (round 4, LNF) = the
+// LayerNorm outputs without z -- the LayerScale gradient then comes from the pwconv2 weight gradient (lnx_layerscale_dgamma_from_wgrad)
+template <int NK, bool LNF, int SAVE>
 __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     constexpr int MT = 2;
     constexpr int C = Geo<NK>::C;
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
                 float mu, rs;
                 ln_row_frags<NK>(xf[mt], lws, lbs, g, p.eps, mu, rs);
                 const int m = min(m_base + mt * 16 + s, p.M - 1);
-                if constexpr (SAVE) {
+                if constexpr (SAVE != 0) {
 #pragma unroll
                     for (int ks = 0; ks < NK; ++ks) st16(p.ln_out + ((int64_t)m * C + ks * 32 + 8 * g) * 2, xf[mt][ks]);
                     if (g == 0) {
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
                 const float4 gm = *reinterpret_cast<const float4*>(gms + c);
                 const float4 xr = xrv[mt][ct];
                 const float z0 = o[ct][mt][0] + b2.x, z1 = o[ct][mt][1] + b2.y, z2 = o[ct][mt][2] + b2.z, z3 = o[ct][mt][3] + b2.w;
-                if constexpr (SAVE) {
+                if constexpr (SAVE == 1) {
                     uint2 zz;
                     bf16_t* zh = reinterpret_cast<bf16_t*>(&zz);
                     zh[0] = (bf16_t)z0; zh[1] = (bf16_t)z1; zh[2] = (bf16_t)z2; zh[3] = (bf16_t)z3;
@@ -1006,7 +1010,9 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     if (reset_ctr && lane == 0) sched_reset(ctr);
 }
 
-template <int NK, int MT, bool ST, bool LNB>
+// DG: the LayerScale gradient dgamma[c] += sum_rows rs g z is formed here from the saved z (p.zin); false (round 4): z is neither saved
+// nor read -- dgamma follows from the pwconv2 weight gradient (lnx_layerscale_dgamma_from_wgrad)
+template <int NK, int MT, bool ST, bool LNB, bool DG>
 __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;
     constexpr int CT = Geo<NK>::CT;
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 t.x[mt][ks] = ld16(p.ln + ((int64_t)m * C + c) * 2);
                 t.g0[mt][ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c);
                 t.g1[mt][ks] = *reinterpret_cast<const float4*>(p.g + (int64_t)m * C + c + 4);
-                t.z[mt][ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
+                if constexpr (DG) t.z[mt][ks] = ld16(p.zin + ((int64_t)m * C + c) * 2);
             }
             t.rs[mt] = rsp[p.rowscale ? m / p.rps : 0];
             if constexpr (LNB) ln_bwd_fetch<NK>(t.lr[mt], p, m, g);
@@ -1103,14 +1109,14 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 const float4 g0 = cur.g0[mt][ks], g1 = cur.g1[mt][ks];
                 const float4 a0 = *reinterpret_cast<const float4*>(gms + c), a1 = *reinterpret_cast<const float4*>(gms + c + 4);
                 Vec16<bf16_t> zin, dzv;
-                zin.raw = cur.z[mt][ks];
+                if constexpr (DG) zin.raw = cur.z[mt][ks];
                 const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float sg = rs * gv[j];
                     dzv.set(j, sg * av[j]);
-                    dgp[ks][j] = fmaf(mv ? sg : 0.f, zin.get(j), dgp[ks][j]);
+                    if constexpr (DG) dgp[ks][j] = fmaf(mv ? sg : 0.f, zin.get(j), dgp[ks][j]);
                 }
                 zf[mt][ks] = dzv.raw;
                 st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
@@ -1191,19 +1197,22 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
         }
     }
     // dgamma: sum the 16 row-lanes (s) of each g, then LDS atomics across waves, then one global atomic per channel
+    if constexpr (DG) {
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks)
+        for (int ks = 0; ks < NK; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float t = dgp[ks][j];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            if (s == 0) atomicAdd(&dgs[ks * 32 + 8 * g + j], t);
-        }
+            for (int j = 0; j < 8; ++j) {
+                float t = dgp[ks][j];
+                t += __shfl_xor(t, 1, 64);
+                t += __shfl_xor(t, 2, 64);
+                t += __shfl_xor(t, 4, 64);
+                t += __shfl_xor(t, 8, 64);
+                if (s == 0) atomicAdd(&dgs[ks * 32 + 8 * g + j], t);
+            }
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 512) atomicAdd(p.dgamma + i, dgs[i]);
+    if constexpr (DG)
+        for (int i = threadIdx.x; i < C; i += 512) atomicAdd(p.dgamma + i, dgs[i]);
     if constexpr (LNB)
         for (int i = threadIdx.x; i < 2 * C; i += 512) p.part[(int64_t)blockIdx.x * (2 * C) + i] = dls[i];
     if (reset_ctr && lane == 0) sched_reset(ctr);
@@ -1250,7 +1259,7 @@ static int res_room() {
     return room > 256 ? 256 : room;
 }
 
-template <int NK, bool LNF, bool SAVE>
+template <int NK, bool LNF, int SAVE>
 int launch_fwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
@@ -1268,20 +1277,20 @@ int launch_fwd_res_t(const CmP& p, hipStream_t st) {
 }
 template <int NK>
 int launch_fwd_res(const CmP& p, hipStream_t st) {
-    if (p.y) return p.z ? launch_fwd_res_t<NK, true, true>(p, st) : launch_fwd_res_t<NK, true, false>(p, st);
-    return p.z ? launch_fwd_res_t<NK, false, true>(p, st) : launch_fwd_res_t<NK, false, false>(p, st);
+    if (p.y) return p.z ? launch_fwd_res_t<NK, true, 1>(p, st) : (p.ln_out ? launch_fwd_res_t<NK, true, 2>(p, st) : launch_fwd_res_t<NK, true, 0>(p, st));
+    return p.z ? launch_fwd_res_t<NK, false, 1>(p, st) : launch_fwd_res_t<NK, false, 0>(p, st);
 }
 // LNB launches: the workgroups' column sums (p.part) are folded into the LayerNorm weight / bias gradient right behind the kernel
 inline int reduce_ln_partials(const CmP& p, int nwg, hipStream_t st) {
     hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * p.C, 256), nwg >= 64 ? 64 : 1), dim3(256), 0, st, p.part, nwg, p.C, p.dlnw, p.dlnb);
     return 0;
 }
-template <int NK, int MT, bool ST, bool LNB>
+template <int NK, int MT, bool ST, bool LNB, bool DG>
 int launch_bwd_res_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * (4 * Geo<NK>::C / 64) * Geo<NK>::PART + 9 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_res_kernel<NK, MT, ST, LNB, DG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     int grid = bwd_grid(p.C, p.M);
@@ -1290,13 +1299,19 @@ int launch_bwd_res_t(const CmP& p, hipStream_t st) {
     if (grid > room) grid = room;
     CmP q = p;
     q.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
-    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB>), dim3(grid), dim3(512), lds, st, q);
+    hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB, DG>), dim3(grid), dim3(512), lds, st, q);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
 }
 template <int NK, int MT>
 int launch_bwd_res(const CmP& p, hipStream_t st) {
-    if (p.y) return p.act ? launch_bwd_res_t<NK, MT, true, true>(p, st) : launch_bwd_res_t<NK, MT, false, true>(p, st);
-    return p.act ? launch_bwd_res_t<NK, MT, true, false>(p, st) : launch_bwd_res_t<NK, MT, false, false>(p, st);
+    // (the plan's forms: act / dh written; with the block LayerNorm inside and without z, or neither -- the other combinations are
+    // for callers of the C entry point and for the A/B switches)
+    if (p.zin == nullptr) {
+        if (p.y) return p.act ? launch_bwd_res_t<NK, MT, true, true, false>(p, st) : launch_bwd_res_t<NK, MT, false, true, false>(p, st);
+        return p.act ? launch_bwd_res_t<NK, MT, true, false, false>(p, st) : launch_bwd_res_t<NK, MT, false, false, false>(p, st);
+    }
+    if (p.y) return p.act ? launch_bwd_res_t<NK, MT, true, true, true>(p, st) : launch_bwd_res_t<NK, MT, false, true, true>(p, st);
+    return p.act ? launch_bwd_res_t<NK, MT, true, false, true>(p, st) : launch_bwd_res_t<NK, MT, false, false, true>(p, st);
 }
 
 template <int NK, int MT, int NW, bool LNF>
@@ -1315,24 +1330,28 @@ int launch_fwd(const CmP& p, hipStream_t st) {
     return p.y ? launch_fwd_t<NK, MT, NW, true>(p, st) : launch_fwd_t<NK, MT, NW, false>(p, st);
 }
 
-template <int NK, int MT, int NW, bool ST, bool LNB>
+template <int NK, int MT, int NW, bool ST, bool LNB, bool DG>
 int launch_bwd_t(const CmP& p, hipStream_t st) {
     const size_t lds = 2 * 3 * Geo<NK>::PART + 8 * Geo<NK>::C * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convmlp_bwd_kernel<NK, MT, NW, ST, LNB, DG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     static_assert(MT == 1, "bwd_grid() assumes 16-row wave tiles in the streamed-weight backward");
     const int grid = bwd_grid(p.C, p.M);
     if (LNB && (int64_t)grid * 2 * p.C > p.part_floats) return -1;
-    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST, LNB>), dim3(grid), dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((convmlp_bwd_kernel<NK, MT, NW, ST, LNB, DG>), dim3(grid), dim3(64 * NW), lds, st, p);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
 }
 template <int NK, int MT, int NW>
 int launch_bwd(const CmP& p, hipStream_t st) {
-    if (p.y) return p.act ? launch_bwd_t<NK, MT, NW, true, true>(p, st) : launch_bwd_t<NK, MT, NW, false, true>(p, st);
-    return p.act ? launch_bwd_t<NK, MT, NW, true, false>(p, st) : launch_bwd_t<NK, MT, NW, false, false>(p, st);
+    if (p.zin == nullptr) {
+        if (p.y) return p.act ? launch_bwd_t<NK, MT, NW, true, true, false>(p, st) : launch_bwd_t<NK, MT, NW, false, true, false>(p, st);
+        return p.act ? launch_bwd_t<NK, MT, NW, true, false, false>(p, st) : launch_bwd_t<NK, MT, NW, false, false, false>(p, st);
+    }
+    if (p.y) return p.act ? launch_bwd_t<NK, MT, NW, true, true, true>(p, st) : launch_bwd_t<NK, MT, NW, false, true, true>(p, st);
+    return p.act ? launch_bwd_t<NK, MT, NW, true, false, true>(p, st) : launch_bwd_t<NK, MT, NW, false, false, true>(p, st);
 }
 
 }  // namespace
@@ -1348,8 +1367,8 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
     LNX_CHECK(a && (a->ln || a->y) && a->w1 && a->w2 && a->b1 && a->b2 && a->gamma && a->x && a->out, "lnx_convmlp_fwd: null operand");
     if (a->y) {
         LNX_CHECK(a->ln_w && a->ln_b && a->ln == nullptr, "lnx_convmlp_fwd: the fused LayerNorm form takes y, ln_w, ln_b and no ln");
-        LNX_CHECK((a->mean == nullptr) == (a->z == nullptr) && (a->rstd == nullptr) == (a->z == nullptr) && (a->ln_out == nullptr) == (a->z == nullptr),
-                  "lnx_convmlp_fwd: with y, the outputs z, ln_out, mean and rstd are written together (what a backward needs) or not at all");
+        LNX_CHECK((a->mean == nullptr) == (a->ln_out == nullptr) && (a->rstd == nullptr) == (a->ln_out == nullptr) && (a->z == nullptr || a->ln_out != nullptr),
+                  "lnx_convmlp_fwd: with y, the outputs ln_out, mean and rstd are written together (what a backward needs) or not at all; z only with them");
     }
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_fwd: unsupported dtype %d / C %d (bf16, C in {32,64,96,128,192})", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_fwd: empty");
@@ -1372,8 +1391,8 @@ extern "C" int lnx_convmlp_fwd(const lnx_convmlp_args* a, void* stream) {
 }
 
 extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
-    LNX_CHECK(a && a->g && a->ln && a->z && a->w1 && a->w2t && a->w1t && a->b1 && a->gamma && a->dz && a->dln && a->dgamma,
-              "lnx_convmlp_bwd: null operand");
+    LNX_CHECK(a && a->g && a->ln && a->w1 && a->w2t && a->w1t && a->b1 && a->gamma && a->dz && a->dln && (a->dgamma || !a->z),
+              "lnx_convmlp_bwd: null operand (z may be NULL: dgamma is then not produced here; with z, dgamma is required)");
     LNX_CHECK((a->act == nullptr) == (a->dh == nullptr), "lnx_convmlp_bwd: act and dh must both be given or both be NULL");
     LNX_CHECK(lnx_convmlp_supported(a->dtype, a->C), "lnx_convmlp_bwd: unsupported dtype %d / C %d", a->dtype, a->C);
     LNX_CHECK(a->M > 0, "lnx_convmlp_bwd: empty");

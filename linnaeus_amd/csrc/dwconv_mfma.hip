@@ -590,15 +590,13 @@ template <typename TX, typename TDY> int launch_wgrad(const MwP& p, int grid, hi
     return 0;
 }
 
+// CUs a launch of these one-workgroup-per-CU kernels may use: the device's minus the margin (LNX_CU_MARGIN / lnx_set_cu_margin).  Their
+// tiles stay statically partitioned -- a workgroup walks a CONTIGUOUS run of tiles so that the 6 halo columns it shares with the
+// previous tile are L2 hits, which a drawn order would give up; beside a resident collective kernel the cost was measured
+// (profiles/r04_cu_hog.log: the whole step loses 3 % with 32-96 CUs held for the duration of every bucket's all-reduce).
 int cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
+    const int n = device_cus();
+    return persistent_cus(n > 0 ? n : 256);
 }
 
 }  // namespace

@@ -387,6 +387,39 @@ extern "C" int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, 
     return 0;
 }
 
+// dgamma[c] += sign * (sum_k w[c, k] dw[c, k] + b[c] db[c]) / gamma[c]: one workgroup per channel (see include/lnx.h)
+__global__ __launch_bounds__(256) void dgamma_from_wgrad_kernel(const float* __restrict__ w, const float* __restrict__ dw, int64_t ld, const float* __restrict__ b,
+                                                                const float* __restrict__ db, const float* __restrict__ gamma, float sign, float* __restrict__ dgamma, int K) {
+    __shared__ float part[4];
+    const int c = blockIdx.x;
+    const float* wr = w + (int64_t)c * ld;
+    const float* dr = dw + (int64_t)c * ld;
+    float t = 0.f;
+    for (int k = threadIdx.x * 4; k < K; k += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(wr + k), d = *reinterpret_cast<const float4*>(dr + k);
+        t += a.x * d.x + a.y * d.y + a.z * d.z + a.w * d.w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = (part[0] + part[1]) + (part[2] + part[3]);
+        if (b) tot += b[c] * db[c];
+        dgamma[c] += sign * tot / gamma[c];
+    }
+}
+
+extern "C" int lnx_layerscale_dgamma_from_wgrad(const float* w, const float* dw, int64_t ld, const float* b, const float* db, const float* gamma, float sign,
+                                                float* dgamma, int C, int K, void* stream) {
+    LNX_CHECK(w && dw && gamma && dgamma && (b == nullptr) == (db == nullptr), "lnx_layerscale_dgamma_from_wgrad: null operand (b and db together)");
+    LNX_CHECK(C > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "lnx_layerscale_dgamma_from_wgrad: bad shape C=%d K=%d ld=%lld", C, K, (long long)ld);
+    LNX_CHECK(((((uintptr_t)w) | ((uintptr_t)dw)) & 15) == 0, "lnx_layerscale_dgamma_from_wgrad: w / dw must be 16-byte aligned");
+    hipLaunchKernelGGL(dgamma_from_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, w, dw, ld, b, db, gamma, sign, dgamma, K);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* gamma, const float* rowscale, int rows_per_sample, void* dz,
                                   float* dgamma, int M, int C, void* stream) {
     LNX_CHECK(g && z && gamma && dz && dgamma, "lnx_layerscale_bwd: null operand");

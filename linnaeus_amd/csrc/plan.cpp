@@ -55,6 +55,8 @@ struct OpW {          // a GEMM weight in the T-typed operand arena
 struct ConvBlk {
     bool fused = false;  // pwconv1 -> GELU -> pwconv2 -> LayerScale -> residual in one kernel (hidden tensor stays on chip)
     bool fused_ln = false;  // ... and the block LayerNorm (forward and backward) inside those kernels: no separate LayerNorm pass
+    bool keep_z = true;     // the pwconv2 output z is saved for the LayerScale gradient; false (fused blocks, round 4): dgamma comes from the
+                            // pwconv2 weight gradient instead (lnx_layerscale_dgamma_from_wgrad) and z is neither written nor read
     int gamma, dww, dwb, lnw, lnb, b1, b2;
     OpW w1, w2;
     int64_t w49;  // fp32 [49][C] in the arena
@@ -561,7 +563,8 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
                 k.hpre = share ? f.hpre : cv.take(M * 4 * C * esz);
                 k.act = share ? f.act : cv.take(M * 4 * C * esz);
             }
-            k.z = share ? f.z : cv.take(M * C * esz);
+            k.keep_z = !k.fused || getenv("LNX_CONV_Z") != nullptr;  // LNX_CONV_Z: A/B switch, z saved and read as in round 3
+            k.z = !k.keep_z ? 0 : (share ? f.z : cv.take(M * C * esz));
         }
         p->o_stage_out[s] = inf ? pp[nb & 1] : cv.take(M * C * 4);
         p->down[s].ln = cv.take(M * C * esz);
@@ -1068,7 +1071,7 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
         f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1]; f.w2 = c.wptr(k.w2); f.b2 = p->P[k.b2];
         f.gamma = p->P[k.gamma]; f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
         f.x = c.at<float>(k.xin); f.out = xout;
-        if (!p->c.inference) f.z = c.at<void>(k.z);  // (only the backward reads it)
+        if (!p->c.inference && k.keep_z) f.z = c.at<void>(k.z);  // (only the backward reads it)
         Timed t(c, 6, 2.0 * M * C * 4 * C * 2);
         RUN(lnx_convmlp_fwd(&f, c.st));
         return 0;
@@ -1422,7 +1425,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         lnx_convmlp_bwd_args f;
         memset(&f, 0, sizeof f);
         f.dtype = c.dt; f.M = M; f.C = C;
-        f.g = g; f.ln = c.at<void>(k.ln); f.z = c.at<void>(k.z); f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1];
+        f.g = g; f.ln = c.at<void>(k.ln); f.z = k.keep_z ? c.at<void>(k.z) : nullptr; f.w1 = c.wptr(k.w1); f.b1 = p->P[k.b1];
         f.w2t = c.wtptr(k.w2); f.w1t = c.wtptr(k.w1); f.gamma = p->P[k.gamma];
         f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
         f.act = sB; f.dh = sA; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
@@ -1435,9 +1438,15 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
         }
+        // LayerScale gradient without z: linear in the pwconv2 weight / bias gradient, so (after - before) of the expression is exactly
+        // this backward's share of it, whatever the gradient buffers held (include/lnx.h)
+        if (!k.keep_z)
+            RUN(lnx_layerscale_dgamma_from_wgrad(p->P[k.w2.param], p->G[k.w2.param], 4 * C, p->P[k.b2], p->G[k.b2], p->P[k.gamma], -1.0f, p->G[k.gamma], C, 4 * C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
         RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
         RUN(lnx_gemm_tn_flush(c.st));
+        if (!k.keep_z)
+            RUN(lnx_layerscale_dgamma_from_wgrad(p->P[k.w2.param], p->G[k.w2.param], 4 * C, p->P[k.b2], p->G[k.b2], p->P[k.gamma], 1.0f, p->G[k.gamma], C, 4 * C, c.st));
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));

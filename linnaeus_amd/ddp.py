@@ -107,10 +107,17 @@ class DataParallel(torch.nn.Module):
     """Wrap a linnaeus_amd mFormerV1 for one-process-per-GPU data parallelism."""
 
     def __init__(self, module: torch.nn.Module, process_group=None, compress_bf16: bool = False, broadcast: bool = True,
-                 single_rank_collectives: bool = False, collective=None):
+                 single_rank_collectives: bool = False, collective=None, cu_margin: int = 0):
         super().__init__()
         self.module = module
         self.collective = collective
+        if cu_margin:
+            # persistent kernels launch on (CUs - margin) workgroups: spares the dispatcher a queue of workgroups that cannot be placed
+            # beside the collective's.  Not needed for throughput -- they draw their tiles from atomic counters, so a late workgroup owes
+            # nothing (profiles/r04_cu_hog.log) -- hence 0 by default.
+            from . import _lib as L
+
+            L.check(L.lib().lnx_set_cu_margin(int(cu_margin)), "lnx_set_cu_margin")
         self.force = single_rank_collectives  # test hook: run the collectives with one rank too
         self.pg = process_group
         self.compress = compress_bf16

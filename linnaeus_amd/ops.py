@@ -308,6 +308,12 @@ def convmlp_fwd(ln, w1, b1, w2, b2, gamma, x, out, *, rowscale=None, rows_per_sa
     return out
 
 
+def layerscale_dgamma_from_wgrad(w, dw, b, db, gamma, sign, dgamma):
+    """dgamma[c] += sign * (sum_k w[c, k] dw[c, k] + b[c] db[c]) / gamma[c]  (include/lnx.h: the LayerScale gradient without z)."""
+    L.check(L.lib().lnx_layerscale_dgamma_from_wgrad(_p(w), _p(dw), C.c_int64(w.stride(0)), _p(b), _p(db), _p(gamma), C.c_float(sign), _p(dgamma),
+                                                     w.shape[0], w.shape[1], _stream()), "lnx_layerscale_dgamma_from_wgrad")
+
+
 def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, rowscale=None, rows_per_sample=0, y=None, ln_w=None, mean=None,
                 rstd=None, d_ln_w=None, d_ln_b=None, ws=None):
     """`y` given: the LayerNorm backward runs in the kernel too -- `dln` receives the gradient wrt y, d_ln_w / d_ln_b are accumulated."""

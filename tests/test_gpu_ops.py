@@ -470,6 +470,37 @@ def test_convmlp_fused_layernorm(C_, M):
         ops.convmlp_bwd(gout, ln1, z1, w1, b1, w2t, w1t, gam, act1, dh1, dz1, dy1, dg1, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, mean=mean1,
                         rstd=rstd1, d_ln_w=dw1, d_ln_b=db1, ws=ws[:C_])
 
+    # ---- round 4: the forms a training plan launches -- z neither written by the forward nor read by the backward ----
+    ln3 = torch.full((M, C_), float("nan"), device="cuda", dtype=bf)
+    mean3, rstd3 = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    out3 = torch.empty_like(out1)
+    ops.convmlp_fwd(None, w1, b1, w2, b2, gam, x, out3, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, ln_b=lb, ln_eps=1e-6, ln_out=ln3, mean=mean3, rstd=rstd3)
+    assert torch.equal(out3, out1) and torch.equal(ln3, ln1) and torch.equal(mean3, mean1) and torch.equal(rstd3, rstd1)
+    act3, dh3, dz3, dy3, _ = bufs()
+    dw3, db3 = torch.full((C_,), 3.0, device="cuda"), torch.full((C_,), -2.0, device="cuda")
+    ops.convmlp_bwd(gout, ln1, None, w1, b1, w2t, w1t, gam, act3, dh3, dz3, dy3, None, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, mean=mean1,
+                    rstd=rstd1, d_ln_w=dw3, d_ln_b=db3, ws=ws)
+    assert torch.equal(act3, act1) and torch.equal(dh3, dh1) and torch.equal(dz3, dz1) and torch.equal(dy3, dy1)
+    torch.testing.assert_close(dw3, dw1, rtol=1e-5, atol=1e-4 * scale)  # (column sums through atomics: order differs from launch to launch)
+    # ... and the LayerScale gradient from the pwconv2 weight gradient: dW2 = dz^T act, db2 = colsum(dz) as the TN GEMM would leave them,
+    # on top of what the buffers held before (the -1 / +1 pair of calls adds exactly this backward's share)
+    w2m, b2m = w2.float(), b2  # (the plan passes the fp32 master weights; here the bf16-rounded values ARE the masters)
+    before_w, before_b = torch.randn(C_, 4 * C_, generator=gen).cuda(), torch.randn(C_, generator=gen).cuda()
+    dgam = torch.full((C_,), 0.75, device="cuda")
+    dW2, db2g = before_w.clone(), before_b.clone()
+    ops.layerscale_dgamma_from_wgrad(w2m, dW2, b2m, db2g, gam, -1.0, dgam)
+    dW2 += dz1.float().t() @ act1.float()
+    db2g += dz1.float().sum(0)
+    ops.layerscale_dgamma_from_wgrad(w2m, dW2, b2m, db2g, gam, 1.0, dgam)
+    torch.cuda.synchronize()
+    # reference 1: the kernel that reads z (dg1, from the bf16 z the forward saved); reference 2: fp64 on the same operands
+    rsr = rs.double().repeat_interleave(rps)[:M, None]
+    zz = act1.double() @ w2.double().t() + b2.double()
+    dg_ref = (rsr * gout.double() * zz).sum(0)
+    gscale = max(1.0, dg_ref.abs().max().item())
+    torch.testing.assert_close((dgam - 0.75).double(), dg_ref, rtol=2e-2, atol=2e-2 * gscale)   # dz is bf16(rs gamma g): 2^-9 per term
+    torch.testing.assert_close(dgam - 0.75, dg1, rtol=2e-2, atol=2e-2 * gscale)
+
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
 @pytest.mark.parametrize("xd", [L.BF16, L.F32])
