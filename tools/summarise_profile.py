@@ -59,9 +59,9 @@ with open(os.path.join(dst, f"{tag}_hbm_traffic.csv"), "w") as f:
     f.write("kernel,launches_per_step,hbm_read_bytes_per_launch,hbm_write_bytes_per_launch\n")
     for k, n, rd, wr in rows:
         f.write(f"\"{k}\",{n:.2f},{rd:.0f},{wr:.0f}\n")
-nt = [(n, rd, wr) for k, n, rd, wr in rows if k.startswith(("gemm_nt_v2_kernel", "gemm_nt_v4_kernel", "gemm_nt_v7_kernel"))]
+nt = [(n, rd, wr) for k, n, rd, wr in rows if k.startswith(("gemm_nt_v2_kernel", "gemm_nt_v4_kernel", "gemm_nt_v7_kernel", "gemm_nt_v9_kernel"))]
 tot_n = sum(n for n, _, _ in nt)
-summary = {"kernel": "gemm_nt_v2 / v4 / v7 kernels (the pipelined bf16 NT GEMM, all tile shapes and epilogue forms)", "launches_per_step": round(tot_n, 2),
+summary = {"kernel": "gemm_nt_v2 / v4 / v7 / v9 kernels (the pipelined bf16 NT GEMM, all tile shapes and epilogue forms)", "launches_per_step": round(tot_n, 2),
            "hbm_read_bytes_per_launch": round(sum(n * rd for n, rd, _ in nt) / tot_n), "hbm_write_bytes_per_launch": round(sum(n * wr for n, _, wr in nt) / tot_n),
            "source": f"profiles/{tag}_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2)",
            "config": "bench.py --steps 10 --warmup 3, mFormerV1_sm bf16 batch 256"}
