@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/lnx.h"
 
@@ -46,9 +47,20 @@ bool tile_sched_static() {
     const char* e = getenv("LNX_TILE_SCHED");
     return e && strcmp(e, "static") == 0;
 }
-int next_tile_slot() {
-    static std::atomic<unsigned> seq{0};
-    return (int)(seq.fetch_add(1, std::memory_order_relaxed) % 64u);  // TILE_SLOTS of common.hpp
+int tile_slot_of(hipStream_t st) {
+    // stream handle -> slot, first come first served; more than 64 streams in one process share by hash (their kernels would have
+    // to overlap in time AND be persistent kernels of the same family to disturb each other)
+    static std::mutex mu;
+    static hipStream_t known[64];
+    static int n = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n; ++i)
+        if (known[i] == st) return i;
+    if (n < 64) {
+        known[n] = st;
+        return n++;
+    }
+    return (int)((reinterpret_cast<uintptr_t>(st) >> 6) % 64u);
 }
 int device_cus() {
     static std::atomic<int> cached{0};  // (one device per process: one process per GPU)

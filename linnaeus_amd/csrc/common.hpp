@@ -43,8 +43,9 @@ void lnx_set_error(const char* fmt, ...);
 // 32-64 CUs for hundreds of microseconds); with `tile += gridDim.x` such a workgroup still owes its whole share when it finally
 // starts and the launch takes two rounds.  Here every tile -- the first one too -- is DRAWN from an atomic counter: the
 // workgroups that run eat the tiles, a latecomer draws a position beyond the end and leaves.
-//   g_tile_ctr[slot][x]   counters of one launch (`slot` handed out round-robin by the host: TILE_SLOTS launches may be in flight), one
-//                         per XCD: workgroup b runs on XCD b & 7 (round-robin dispatch), XCD x owns a contiguous eighth of the
+//   g_tile_ctr[slot][x]   counters of one launch; `slot` belongs to the launch's STREAM (api.cpp: tile_slot_of -- a stream's kernels run one
+//                         after the other and every kernel leaves its counters at zero, so one set per stream is enough and two
+//                         streams never share one; TILE_SLOTS streams per process), one counter per XCD: workgroup b runs on XCD b & 7 (round-robin dispatch), XCD x owns a contiguous eighth of the
 //                         tiles and a counter that only its own CUs touch -- the line stays in that XCD's L2 (one counter for the
 //                         whole chip bounced between the eight L2s: +10 % on the conv-MLP kernels, 25 000 draws per launch).
 //                         Nothing is stolen across XCDs: a collective's workgroups are dealt round-robin too.  Zero at module
@@ -97,7 +98,7 @@ __device__ __forceinline__ TileShare tile_share(int n) {
 int persistent_cus(int cus);   // CUs a persistent launch may occupy: cus - margin
 void set_cu_margin(int m);
 bool tile_sched_static();      // LNX_TILE_SCHED=static, read per launch
-int next_tile_slot();
+int tile_slot_of(hipStream_t st);  // the counter set launches on this stream draw from (one per stream: a stream's kernels run one after the other)
 int device_cus();              // cached multiProcessorCount of the current device (0 on failure)
 
 // ---------------------------------------------------------------------------------

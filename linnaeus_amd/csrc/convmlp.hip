@@ -1271,7 +1271,7 @@ int launch_fwd_res_t(const CmP& p, hipStream_t st) {
     const int room = res_room();
     if (grid > room) grid = room;
     CmP q = p;
-    q.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    q.tile_slot = tile_sched_static() ? -1 : tile_slot_of(st);
     hipLaunchKernelGGL((convmlp_fwd_res_kernel<NK, LNF, SAVE>), dim3(grid), dim3(512), lds, st, q);
     return 0;
 }
@@ -1298,7 +1298,7 @@ int launch_bwd_res_t(const CmP& p, hipStream_t st) {
     const int room = res_room();
     if (grid > room) grid = room;
     CmP q = p;
-    q.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    q.tile_slot = tile_sched_static() ? -1 : tile_slot_of(st);
     hipLaunchKernelGGL((convmlp_bwd_res_kernel<NK, MT, ST, LNB, DG>), dim3(grid), dim3(512), lds, st, q);
     return LNB ? reduce_ln_partials(p, grid, st) : 0;
 }

@@ -437,7 +437,7 @@ int launch_nt_v7(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     const int room = persistent_cus(cus);              // cus - LNX_CU_MARGIN / lnx_set_cu_margin()
     const int grid = ntiles < room ? ntiles : room;    // persistent: one workgroup per CU (144 KiB of LDS each)
     const size_t lds = NST7 * STAGE7 + 16;             // + the dword the next tile's position is published through
-    p.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    p.tile_slot = tile_sched_static() ? -1 : tile_slot_of(st);
     const bool deep = p.K / BK7 >= 17;  // long K loops spread the deferred traffic over 8 + 8 iterations instead of 3 + 2
 #define V7_LAUNCH_(O, FF, H, T)                                                                                                      \
     do {                                                                                                                             \

@@ -263,7 +263,7 @@ int launch_nt_v9(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     const int room = persistent_cus(cus);
     const int grid = ntiles < room ? ntiles : room;
     const size_t lds = NST9 * STAGE9 + 16;
-    p.tile_slot = tile_sched_static() ? -1 : next_tile_slot();
+    p.tile_slot = tile_sched_static() ? -1 : tile_slot_of(st);
 #define V9_LAUNCH(O, FF)                                                                                                             \
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \
