@@ -347,15 +347,15 @@ int lnx_layerscale_bwd(const float* g, const void* z, int dtype, const float* ga
                        int rows_per_sample, void* dz, float* dgamma, int M, int C, void* stream);
 
 /* Round 4.  The LayerScale gradient of a ConvNeXt block WITHOUT the saved pwconv2 output z (blocks/convnext.py:80-83: x = gamma * z,
- * z = act . W2^T + b2).  dgamma[c] = sum_m rs g[m, c] z[m, c] = sum_k W2[c, k] (sum_m rs g act[m, k]) + b2[c] sum_m rs g, and the
- * pwconv2 weight / bias gradients are gamma[c] times those two sums (their dY operand is dz = rs gamma g), so
- *     dgamma[c] += sign * ( sum_k w[c, k] dw[c, k] + b[c] db[c] ) / gamma[c]
- * with w, b the fp32 master weight / bias of pwconv2 and dw, db its accumulated gradient.  The expression is linear in (dw, db): the
- * plan calls it with sign = -1 before the block's weight-gradient product and with sign = +1 after it, which adds exactly this
- * backward's contribution whatever the gradient buffers held before (gradient accumulation).  With it the forward no longer writes z
- * (1.4 GB / step at mFormerV1_sm, batch 256) and the backward kernels neither read it nor carry the column sums. */
-int lnx_layerscale_dgamma_from_wgrad(const float* w, const float* dw, int64_t ld, const float* b, const float* db, const float* gamma, float sign,
-                                     float* dgamma, int C, int K, void* stream);
+ * z = act . W2^T + b2).  dgamma[c] = sum_m rs g[m, c] z[m, c] = sum_k W2[c, k] S[c, k] + b2[c] T[c] with S = (rs g)^T act and
+ * T = colsum(rs g) -- and the pwconv2 weight / bias gradients are gamma[c] S[c, :] and gamma[c] T[c].  So the weight-gradient product
+ * runs on dY = rs g (lnx_convmlp_bwd_args.dz_plain) into ZEROED scratch s [C, K] / t [C] instead of the gradient buffers, and one launch does
+ *     dw[c, :] += gamma[c] s[c, :]      db[c] += gamma[c] t[c]      dgamma[c] += sum_k w[c, k] s[c, k] + b[c] t[c]
+ * with w, b the fp32 master weight / bias of pwconv2.  No division by gamma (gamma = 0 is an ordinary value), nothing about what the
+ * gradient buffers held before.  The forward then no longer writes z (1.4 GB / step at mFormerV1_sm, batch 256) and the backward kernels
+ * neither read it nor carry the column sums. */
+int lnx_layerscale_apply_wgrad(const float* s, const float* t, int64_t lds, const float* w, const float* b, int64_t ldw, const float* gamma, float* dw, float* db,
+                               int64_t lddw, float* dgamma, int C, int K, void* stream);
 
 /* Dropout of the RoPE blocks' Linear outputs (MODEL.DROP_RATE: blocks/mlp.py:61-66 `self.drop`, rope_2d_mhsa.py:503
  * `proj_drop`), with the keep mask drawn by the caller (one byte per element, 1 = keep):
@@ -584,6 +584,9 @@ typedef struct lnx_convmlp_bwd_args {
     float* d_ln_b;         /* [C] += */
     float* ws;             /* scratch for the per-workgroup column sums: lnx_convmlp_bwd_ws_floats(C, M) floats (2 C per workgroup */
     int64_t ws_floats;     /* of the launch this library would make for (C, M)); too small = error                              */
+    int dz_plain;          /* round 4.  != 0: the `dz` written to memory is rowscale * g, WITHOUT the LayerScale factor gamma (inside the
+                              kernel the data gradient keeps it): the dY operand of a pwconv2 weight-gradient product whose result
+                              lnx_layerscale_apply_wgrad multiplies by gamma afterwards (and reads the LayerScale gradient from) */
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
 /* floats of `ws` the fused-LayerNorm backward needs for (C, M), from the same grid choice the launcher makes (0: unsupported C) */

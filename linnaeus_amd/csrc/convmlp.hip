@@ -58,6 +58,8 @@ struct CmP {
     float* part;                // bwd: per-workgroup partial sums of dw | db, [gridDim.x][2C]
     int64_t part_floats;
     int tile_slot;              // resident-weight kernels: tile counter set of this launch (common.hpp), -1 = static stride
+    int dz_plain;               // bwd: the dz written to memory is rowscale * g WITHOUT the LayerScale factor (the data gradient inside the
+                                // kernel keeps it): operand of a pwconv2 weight gradient that lnx_layerscale_apply_wgrad scales afterwards
     float* dlnw;                // bwd: [C] += LayerNorm weight / bias gradient (host side of the launch: the reduce kernel's targets)
     float* dlnb;
 };
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
         for (int ks = 0; ks < NK; ++ks) {
             const int c = ks * 32 + 8 * g;
             const float4 g0 = g0v[ks], g1 = g1v[ks], a0 = a0v[ks], a1 = a1v[ks];
-            Vec16<bf16_t> zin, dzv;
+            Vec16<bf16_t> zin, dzv, dzs;
             if constexpr (DG) zin.raw = zraw[ks];
             const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
             for (int j = 0; j < 8; ++j) {
                 const float sg = rs * gv[j];
                 dzv.set(j, sg * av[j]);
+                dzs.set(j, p.dz_plain ? sg : sg * av[j]);  // what goes to memory for the weight-gradient product (see CmP::dz_plain)
                 if constexpr (DG) {
                     // dgamma partial: this lane's 8 channels of its row; reduced over rows below
                     const float dgp = mvalid[mt] ? sg * zin.get(j) : 0.f;
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(64 * NW) void convmlp_bwd_kernel(const CmP p) {
                 }
             }
             zf[mt][ks] = dzv.raw;
-            st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+            st16(p.dz + ((int64_t)m * C + c) * 2, dzs.raw);
         }
     }
     f32x4_t dl[CT][MT];
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 xf[mt][ks] = cur.x[mt][ks];
                 const float4 g0 = cur.g0[mt][ks], g1 = cur.g1[mt][ks];
                 const float4 a0 = *reinterpret_cast<const float4*>(gms + c), a1 = *reinterpret_cast<const float4*>(gms + c + 4);
-                Vec16<bf16_t> zin, dzv;
+                Vec16<bf16_t> zin, dzv, dzs;
                 if constexpr (DG) zin.raw = cur.z[mt][ks];
                 const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
                 const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -1116,10 +1119,11 @@ __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
                 for (int j = 0; j < 8; ++j) {
                     const float sg = rs * gv[j];
                     dzv.set(j, sg * av[j]);
+                    dzs.set(j, p.dz_plain ? sg : sg * av[j]);
                     if constexpr (DG) dgp[ks][j] = fmaf(mv ? sg : 0.f, zin.get(j), dgp[ks][j]);
                 }
                 zf[mt][ks] = dzv.raw;
-                st16(p.dz + ((int64_t)m * C + c) * 2, dzv.raw);
+                st16(p.dz + ((int64_t)m * C + c) * 2, dzs.raw);
             }
         }
         if (dyn) drawn = sched_draw_counted(ctr);  // the tile after this one (behind this tile's dz stores, in front of the chunk loop's)
@@ -1405,6 +1409,7 @@ extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
     p.w2t = (const unsigned char*)a->w2t; p.w1t = (const unsigned char*)a->w1t; p.b1 = a->b1; p.gamma = a->gamma; p.rowscale = a->rowscale;
     p.act = (unsigned char*)a->act; p.dh = (unsigned char*)a->dh; p.dz = (unsigned char*)a->dz; p.dln = (unsigned char*)a->dln; p.dgamma = a->dgamma;
     p.M = a->M; p.C = a->C; p.rps = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.dz_plain = a->dz_plain != 0;
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
     switch (a->C) {

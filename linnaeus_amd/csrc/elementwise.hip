@@ -387,35 +387,50 @@ extern "C" int lnx_scale_cast(const float* in, int64_t ldin, lnx_rowmap in_map, 
     return 0;
 }
 
-// dgamma[c] += sign * (sum_k w[c, k] dw[c, k] + b[c] db[c]) / gamma[c]: one workgroup per channel (see include/lnx.h)
-__global__ __launch_bounds__(256) void dgamma_from_wgrad_kernel(const float* __restrict__ w, const float* __restrict__ dw, int64_t ld, const float* __restrict__ b,
-                                                                const float* __restrict__ db, const float* __restrict__ gamma, float sign, float* __restrict__ dgamma, int K) {
+// dw[c, :] += gamma[c] s[c, :], db[c] += gamma[c] t[c], dgamma[c] += sum_k w[c, k] s[c, k] + b[c] t[c]: one workgroup per channel
+// (include/lnx.h: the LayerScale gradient without the saved z)
+__global__ __launch_bounds__(256) void layerscale_apply_wgrad_kernel(const float* __restrict__ sp, const float* __restrict__ tp, int64_t lds, const float* __restrict__ w,
+                                                                     const float* __restrict__ b, int64_t ldw, const float* __restrict__ gamma, float* __restrict__ dw,
+                                                                     float* __restrict__ db, int64_t lddw, float* __restrict__ dgamma, int K) {
     __shared__ float part[4];
     const int c = blockIdx.x;
-    const float* wr = w + (int64_t)c * ld;
-    const float* dr = dw + (int64_t)c * ld;
-    float t = 0.f;
+    const float gm = gamma[c];
+    const float* sr = sp + (int64_t)c * lds;
+    const float* wr = w + (int64_t)c * ldw;
+    float* dr = dw + (int64_t)c * lddw;
+    float acc = 0.f;
     for (int k = threadIdx.x * 4; k < K; k += 1024) {
-        const float4 a = *reinterpret_cast<const float4*>(wr + k), d = *reinterpret_cast<const float4*>(dr + k);
-        t += a.x * d.x + a.y * d.y + a.z * d.z + a.w * d.w;
+        const float4 sv = *reinterpret_cast<const float4*>(sr + k), wv = *reinterpret_cast<const float4*>(wr + k);
+        float4 d = *reinterpret_cast<const float4*>(dr + k);
+        acc += wv.x * sv.x + wv.y * sv.y + wv.z * sv.z + wv.w * sv.w;
+        d.x = fmaf(gm, sv.x, d.x);
+        d.y = fmaf(gm, sv.y, d.y);
+        d.z = fmaf(gm, sv.z, d.z);
+        d.w = fmaf(gm, sv.w, d.w);
+        *reinterpret_cast<float4*>(dr + k) = d;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         float tot = (part[0] + part[1]) + (part[2] + part[3]);
-        if (b) tot += b[c] * db[c];
-        dgamma[c] += sign * tot / gamma[c];
+        if (tp) {
+            tot = fmaf(b[c], tp[c], tot);
+            db[c] = fmaf(gm, tp[c], db[c]);
+        }
+        dgamma[c] += tot;
     }
 }
 
-extern "C" int lnx_layerscale_dgamma_from_wgrad(const float* w, const float* dw, int64_t ld, const float* b, const float* db, const float* gamma, float sign,
-                                                float* dgamma, int C, int K, void* stream) {
-    LNX_CHECK(w && dw && gamma && dgamma && (b == nullptr) == (db == nullptr), "lnx_layerscale_dgamma_from_wgrad: null operand (b and db together)");
-    LNX_CHECK(C > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && ld >= K, "lnx_layerscale_dgamma_from_wgrad: bad shape C=%d K=%d ld=%lld", C, K, (long long)ld);
-    LNX_CHECK(((((uintptr_t)w) | ((uintptr_t)dw)) & 15) == 0, "lnx_layerscale_dgamma_from_wgrad: w / dw must be 16-byte aligned");
-    hipLaunchKernelGGL(dgamma_from_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, w, dw, ld, b, db, gamma, sign, dgamma, K);
+extern "C" int lnx_layerscale_apply_wgrad(const float* s, const float* t, int64_t lds, const float* w, const float* b, int64_t ldw, const float* gamma, float* dw, float* db,
+                                          int64_t lddw, float* dgamma, int C, int K, void* stream) {
+    LNX_CHECK(s && w && gamma && dw && dgamma, "lnx_layerscale_apply_wgrad: null operand");
+    LNX_CHECK((t == nullptr) == (b == nullptr) && (t == nullptr) == (db == nullptr), "lnx_layerscale_apply_wgrad: t, b and db are given together or not at all");
+    LNX_CHECK(C > 0 && K > 0 && K % 4 == 0 && lds % 4 == 0 && ldw % 4 == 0 && lddw % 4 == 0 && lds >= K && ldw >= K && lddw >= K,
+              "lnx_layerscale_apply_wgrad: bad shape C=%d K=%d (K and the leading dimensions are multiples of 4)", C, K);
+    LNX_CHECK(((((uintptr_t)s) | ((uintptr_t)w) | ((uintptr_t)dw)) & 15) == 0, "lnx_layerscale_apply_wgrad: s / w / dw must be 16-byte aligned");
+    hipLaunchKernelGGL(layerscale_apply_wgrad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, s, t, lds, w, b, ldw, gamma, dw, db, lddw, dgamma, K);
     LNX_LAUNCH_CHECK();
     return 0;
 }

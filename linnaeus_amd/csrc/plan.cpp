@@ -129,6 +129,7 @@ struct lnx_plan {
     int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
     int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
+    int64_t o_lsws = 0, lsws_floats = 0;  // S | T scratch of the z-free LayerScale gradient
     int64_t o_gcos /* freqs-gradient partials of lnx_attn_bwd */, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
     // fp8 plans, forward scratch: MXFP8 copy (+ block scales) of the LayerNorm output feeding qkv / fc1, and of the MLP hidden
     // feeding fc2 (two buffers: fc1 reads the first while its epilogue writes the second)
@@ -672,7 +673,12 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     if (!inf) {
         p->o_lnws = cv.take(p->lnws_floats * 4);
         p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
-        p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4 * TN_WS_SLOTS);  // one region per weight-gradient product of a block (their reduces run as one launch)
+        p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4 * TN_WS_SLOTS);
+        {   // pwconv2 weight / bias gradient of dY = rs g, before the LayerScale factor (lnx_layerscale_apply_wgrad): [C, 4C] + [C] fp32
+            const int64_t cmax = D[0] > D[1] ? D[0] : D[1];
+            p->lsws_floats = cmax * 4 * cmax + cmax;
+            p->o_lsws = cv.take(p->lsws_floats * 4);
+        }  // one region per weight-gradient product of a block (their reduces run as one launch)
         // Fused conv-MLP blocks: the backward materialises act / dH ([M, 4C] each) for the two weight-gradient GEMMs (a
         // recomputing weight-gradient kernel existed in round 2 and was slower: DESIGN.md)
         p->o_sA = cv.take(maxM4C * esz);
@@ -973,16 +979,15 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
 
 // `slot` >= 0: the product's split-K partial tiles go to workspace region `slot` and their summation into the gradient is postponed to
 // the block's tn_flush() (lnx_wgrad_args.defer); -1: summed at once
-int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, int wparam, int bparam, int64_t lddw, int k_store = 0,
-          int slot = -1) {
+int wgrad_to(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, float* dW, float* db, int64_t lddw, int k_store, int slot) {
     lnx_wgrad_args a;
     memset(&a, 0, sizeof a);
     a.dtype = c.dt;
     a.M = M; a.N = N; a.K = K;
     a.dY = dY; a.lddy = lddy;
     a.A = A; a.lda = lda;
-    a.dW = c.p->G[wparam]; a.lddw = lddw;
-    a.db = bparam >= 0 ? c.p->G[bparam] : nullptr;
+    a.dW = dW; a.lddw = lddw;
+    a.db = db;
     a.k_store = k_store;
     if (!(c.p->side != nullptr && c.st == (void*)c.p->side)) {  // one workspace: never from the side stream
         a.ws = c.at<float>(c.p->o_tnws) + (int64_t)(slot > 0 ? slot : 0) * LNX_TN_WS_FLOATS;
@@ -991,6 +996,15 @@ int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const
     }
     Timed t(c, M >= 1024 ? 1 : -1, 2.0 * M * N * K, (double)c.p->esz * ((double)M * N + (double)M * K) + 8.0 * N * K);
     return lnx_gemm_tn(&a, c.st);
+}
+// ... into the gradient arena's slices of parameters `wparam` / `bparam`
+int wgrad(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, int wparam, int bparam, int64_t lddw, int k_store = 0,
+          int slot = -1) {
+    return wgrad_to(c, M, N, K, dY, lddy, A, lda, c.p->G[wparam], bparam >= 0 ? c.p->G[bparam] : nullptr, lddw, k_store, slot);
+}
+// ... into explicit buffers (the z-free LayerScale path's scratch)
+int wgrad_into(const Ctx& c, int M, int N, int K, const void* dY, int64_t lddy, const void* A, int64_t lda, float* dW, float* db, int64_t lddw, int slot) {
+    return wgrad_to(c, M, N, K, dY, lddy, A, lda, dW, db, lddw, 0, slot);
 }
 
 const lnx_rowmap IDM = {0, 0, 0};
@@ -1429,6 +1443,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         f.w2t = c.wtptr(k.w2); f.w1t = c.wtptr(k.w1); f.gamma = p->P[k.gamma];
         f.rowscale = p->drop_ptr(p->drop_conv[s][i]); f.rows_per_sample = H * W;
         f.act = sB; f.dh = sA; f.dz = sC; f.dln = sD; f.dgamma = p->G[k.gamma];
+        f.dz_plain = k.keep_z ? 0 : 1;  // z-free: sC = rs g for the pwconv2 weight gradient, which then goes through lnx_layerscale_apply_wgrad
         if (k.fused_ln) {  // sD then holds the gradient wrt the depthwise conv output
             f.y = c.at<void>(k.y); f.ln_w = p->P[k.lnw]; f.mean = c.at<float>(k.mean); f.rstd = c.at<float>(k.rstd);
             f.d_ln_w = p->G[k.lnw]; f.d_ln_b = p->G[k.lnb];
@@ -1438,15 +1453,21 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
         }
-        // LayerScale gradient without z: linear in the pwconv2 weight / bias gradient, so (after - before) of the expression is exactly
-        // this backward's share of it, whatever the gradient buffers held (include/lnx.h)
-        if (!k.keep_z)
-            RUN(lnx_layerscale_dgamma_from_wgrad(p->P[k.w2.param], p->G[k.w2.param], 4 * C, p->P[k.b2], p->G[k.b2], p->P[k.gamma], -1.0f, p->G[k.gamma], C, 4 * C, c.st));
-        RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
-        RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
-        RUN(lnx_gemm_tn_flush(c.st));
-        if (!k.keep_z)
-            RUN(lnx_layerscale_dgamma_from_wgrad(p->P[k.w2.param], p->G[k.w2.param], 4 * C, p->P[k.b2], p->G[k.b2], p->P[k.gamma], 1.0f, p->G[k.gamma], C, 4 * C, c.st));
+        if (k.keep_z) {
+            RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
+            RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
+            RUN(lnx_gemm_tn_flush(c.st));
+        } else {
+            // LayerScale gradient without z (include/lnx.h): the pwconv2 weight-gradient product runs on dY = rs g into zeroed scratch S | T,
+            // then ONE launch adds gamma S / gamma T to the gradients and reads dgamma = rowdot(W2, S) + b2 T off them
+            float* S = c.at<float>(p->o_lsws);
+            float* T = S + (int64_t)C * 4 * C;
+            HIPRUN(hipMemsetAsync(S, 0, ((size_t)C * 4 * C + C) * 4, (hipStream_t)c.st));
+            RUN(wgrad_into(c, M, C, 4 * C, sC, C, sB, 4 * C, S, T, 4 * C, 0));
+            RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
+            RUN(lnx_gemm_tn_flush(c.st));
+            RUN(lnx_layerscale_apply_wgrad(S, T, 4 * C, p->P[k.w2.param], p->P[k.b2], 4 * C, p->P[k.gamma], p->G[k.w2.param], p->G[k.b2], 4 * C, p->G[k.gamma], C, 4 * C, c.st));
+        }
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));

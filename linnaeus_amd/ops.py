@@ -308,14 +308,15 @@ def convmlp_fwd(ln, w1, b1, w2, b2, gamma, x, out, *, rowscale=None, rows_per_sa
     return out
 
 
-def layerscale_dgamma_from_wgrad(w, dw, b, db, gamma, sign, dgamma):
-    """dgamma[c] += sign * (sum_k w[c, k] dw[c, k] + b[c] db[c]) / gamma[c]  (include/lnx.h: the LayerScale gradient without z)."""
-    L.check(L.lib().lnx_layerscale_dgamma_from_wgrad(_p(w), _p(dw), C.c_int64(w.stride(0)), _p(b), _p(db), _p(gamma), C.c_float(sign), _p(dgamma),
-                                                     w.shape[0], w.shape[1], _stream()), "lnx_layerscale_dgamma_from_wgrad")
+def layerscale_apply_wgrad(s, t, w, b, gamma, dw, db, dgamma):
+    """dw[c, :] += gamma[c] s[c, :], db[c] += gamma[c] t[c], dgamma[c] += sum_k w[c, k] s[c, k] + b[c] t[c]  (include/lnx.h: the
+    LayerScale gradient without z; s / t = the pwconv2 weight / bias gradient of dY = rowscale * g, in zeroed scratch)."""
+    L.check(L.lib().lnx_layerscale_apply_wgrad(_p(s), _p(t), C.c_int64(s.stride(0)), _p(w), _p(b), C.c_int64(w.stride(0)), _p(gamma), _p(dw), _p(db),
+                                               C.c_int64(dw.stride(0)), _p(dgamma), w.shape[0], w.shape[1], _stream()), "lnx_layerscale_apply_wgrad")
 
 
 def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, rowscale=None, rows_per_sample=0, y=None, ln_w=None, mean=None,
-                rstd=None, d_ln_w=None, d_ln_b=None, ws=None):
+                rstd=None, d_ln_w=None, d_ln_b=None, ws=None, dz_plain=False):
     """`y` given: the LayerNorm backward runs in the kernel too -- `dln` receives the gradient wrt y, d_ln_w / d_ln_b are accumulated."""
     a = L.ConvMlpBwdArgs()
     a.dtype, a.M, a.C = code_of(ln), ln.shape[0], ln.shape[1]
@@ -324,4 +325,5 @@ def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, 
     a.act, a.dh, a.dz, a.dln, a.dgamma = _p(act), _p(dh), _p(dz), _p(dln), _p(dgamma)
     a.y, a.ln_w, a.mean, a.rstd, a.d_ln_w, a.d_ln_b = _p(y), _p(ln_w), _p(mean), _p(rstd), _p(d_ln_w), _p(d_ln_b)
     a.ws, a.ws_floats = _p(ws), (ws.numel() if ws is not None else 0)
+    a.dz_plain = int(dz_plain)
     L.check(L.lib().lnx_convmlp_bwd(C.byref(a), _stream()), "lnx_convmlp_bwd")

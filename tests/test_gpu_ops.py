@@ -482,24 +482,33 @@ def test_convmlp_fused_layernorm(C_, M):
                     rstd=rstd1, d_ln_w=dw3, d_ln_b=db3, ws=ws)
     assert torch.equal(act3, act1) and torch.equal(dh3, dh1) and torch.equal(dz3, dz1) and torch.equal(dy3, dy1)
     torch.testing.assert_close(dw3, dw1, rtol=1e-5, atol=1e-4 * scale)  # (column sums through atomics: order differs from launch to launch)
-    # ... and the LayerScale gradient from the pwconv2 weight gradient: dW2 = dz^T act, db2 = colsum(dz) as the TN GEMM would leave them,
-    # on top of what the buffers held before (the -1 / +1 pair of calls adds exactly this backward's share)
-    w2m, b2m = w2.float(), b2  # (the plan passes the fp32 master weights; here the bf16-rounded values ARE the masters)
-    before_w, before_b = torch.randn(C_, 4 * C_, generator=gen).cuda(), torch.randn(C_, generator=gen).cuda()
-    dgam = torch.full((C_,), 0.75, device="cuda")
-    dW2, db2g = before_w.clone(), before_b.clone()
-    ops.layerscale_dgamma_from_wgrad(w2m, dW2, b2m, db2g, gam, -1.0, dgam)
-    dW2 += dz1.float().t() @ act1.float()
-    db2g += dz1.float().sum(0)
-    ops.layerscale_dgamma_from_wgrad(w2m, dW2, b2m, db2g, gam, 1.0, dgam)
-    torch.cuda.synchronize()
-    # reference 1: the kernel that reads z (dg1, from the bf16 z the forward saved); reference 2: fp64 on the same operands
+    # ... with dz_plain the dz that reaches memory is rs * g without the LayerScale factor; nothing else changes
+    act4, dh4, dz4, dy4, _ = bufs()
+    dw4, db4 = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    ops.convmlp_bwd(gout, ln1, None, w1, b1, w2t, w1t, gam, act4, dh4, dz4, dy4, None, rowscale=rs, rows_per_sample=rps, y=y, ln_w=lw, mean=mean1,
+                    rstd=rstd1, d_ln_w=dw4, d_ln_b=db4, ws=ws, dz_plain=True)
+    assert torch.equal(act4, act1) and torch.equal(dh4, dh1) and torch.equal(dy4, dy1)
     rsr = rs.double().repeat_interleave(rps)[:M, None]
+    torch.testing.assert_close(dz4.double(), rsr * gout.double(), rtol=8e-3, atol=1e-6)
+    # ... and the LayerScale gradient comes out of the pwconv2 weight gradient (lnx_layerscale_apply_wgrad): S = (rs g)^T act and
+    # T = colsum(rs g) as the TN GEMM leaves them in zeroed scratch; dW2 += gamma S, db2 += gamma T, dgamma += rowdot(W2, S) + b2 T.
+    # A zero gamma is an ordinary value (no division anywhere).
+    gam0 = gam.clone()
+    gam0[3] = 0.0
+    S = dz4.float().t() @ act1.float()
+    T = dz4.float().sum(0)
+    dW2, db2g, dgam = torch.full((C_, 4 * C_), 0.5, device="cuda"), torch.full((C_,), -0.5, device="cuda"), torch.full((C_,), 0.75, device="cuda")
+    ops.layerscale_apply_wgrad(S, T, w2.float(), b2, gam0, dW2, db2g, dgam)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dW2, 0.5 + gam0[:, None] * S, rtol=1e-5, atol=1e-5 * max(1.0, S.abs().max().item()))
+    torch.testing.assert_close(db2g, -0.5 + gam0 * T, rtol=1e-5, atol=1e-5 * max(1.0, T.abs().max().item()))
+    # reference 1: fp64 on the operands the kernels saw; reference 2: the kernel that reads the saved bf16 z (dg1)
     zz = act1.double() @ w2.double().t() + b2.double()
     dg_ref = (rsr * gout.double() * zz).sum(0)
     gscale = max(1.0, dg_ref.abs().max().item())
-    torch.testing.assert_close((dgam - 0.75).double(), dg_ref, rtol=2e-2, atol=2e-2 * gscale)   # dz is bf16(rs gamma g): 2^-9 per term
+    torch.testing.assert_close((dgam - 0.75).double(), dg_ref, rtol=1e-2, atol=1e-2 * gscale)   # dz is bf16(rs g): 2^-9 per term
     torch.testing.assert_close(dgam - 0.75, dg1, rtol=2e-2, atol=2e-2 * gscale)
+    assert torch.isfinite(dgam).all()
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1000, 384, 512), (4096, 1152, 384 * 2), (513, 208, 1024)])
