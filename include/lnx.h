@@ -561,7 +561,7 @@ typedef struct lnx_convmlp_bwd_args {
     const float* g;        /* [M, C] fp32 gradient of the block output */
     const void* ln;        /* [M, C] bf16 */
     const void* z;         /* [M, C] bf16 saved by the forward, or NULL (round 4): dgamma is then NOT produced here -- see
-                              lnx_layerscale_dgamma_from_wgrad */
+                              lnx_layerscale_apply_wgrad */
     const void* w1;        /* [4C, C] bf16 */
     const float* b1;
     const void* w2t;       /* [4C, C] bf16 = pwconv2.weight^T */

@@ -827,7 +827,7 @@ __device__ __forceinline__ void prod_tr_nmajor(f32x4_t (&o)[Geo<NK>::CT][MT], ui
 
 template <bool V> struct BoolC { static constexpr bool value = V; };
 // SAVE: the outputs a backward needs are written: 1 = z and, with LNF, the normalised rows + row statistics; 2 (round 4, LNF) = the
-// LayerNorm outputs without z -- the LayerScale gradient then comes from the pwconv2 weight gradient (lnx_layerscale_dgamma_from_wgrad)
+// LayerNorm outputs without z -- the LayerScale gradient then comes from the pwconv2 weight gradient (lnx_layerscale_apply_wgrad)
 template <int NK, bool LNF, int SAVE>
 __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
     constexpr int MT = 2;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(512) void convmlp_fwd_res_kernel(const CmP p) {
 }
 
 // DG: the LayerScale gradient dgamma[c] += sum_rows rs g z is formed here from the saved z (p.zin); false (round 4): z is neither saved
-// nor read -- dgamma follows from the pwconv2 weight gradient (lnx_layerscale_dgamma_from_wgrad)
+// nor read -- dgamma follows from the pwconv2 weight gradient (lnx_layerscale_apply_wgrad)
 template <int NK, int MT, bool ST, bool LNB, bool DG>
 __global__ __launch_bounds__(512) void convmlp_bwd_res_kernel(const CmP p) {
     constexpr int C = Geo<NK>::C;

@@ -56,7 +56,7 @@ struct ConvBlk {
     bool fused = false;  // pwconv1 -> GELU -> pwconv2 -> LayerScale -> residual in one kernel (hidden tensor stays on chip)
     bool fused_ln = false;  // ... and the block LayerNorm (forward and backward) inside those kernels: no separate LayerNorm pass
     bool keep_z = true;     // the pwconv2 output z is saved for the LayerScale gradient; false (fused blocks, round 4): dgamma comes from the
-                            // pwconv2 weight gradient instead (lnx_layerscale_dgamma_from_wgrad) and z is neither written nor read
+                            // pwconv2 weight gradient instead (lnx_layerscale_apply_wgrad) and z is neither written nor read
     int gamma, dww, dwb, lnw, lnb, b1, b2;
     OpW w1, w2;
     int64_t w49;  // fp32 [49][C] in the arena
