@@ -1092,7 +1092,9 @@ int conv_block_fwd(const Ctx& c, int s, int i, const float* xin, float* xout) {
     }
     lnx_gemm_args g = gemm_base(c, M, 4 * C, C, c.at<void>(k.ln), C, c.wptr(k.w1), k.w1.ld, c.at<void>(k.act), 4 * C, false);
     g.bias = p->P[k.b1]; g.act = LNX_ACT_GELU;
-    if (!p->c.inference) {  // the pre-activation is the backward's
+    if (!p->c.inference) {  // the backward's second tensor: GELU'(h), evaluated here once (as in the RoPE blocks' fc1; LNX_CONV_HPRE: h, round 3)
+        static const bool keep_h = getenv("LNX_CONV_HPRE") != nullptr;
+        g.act = keep_h ? LNX_ACT_GELU : LNX_ACT_GELU_D;
         g.c2 = c.at<void>(k.hpre); g.ldc2 = 4 * C;
     }
     RUN(gemm_nt_t(c, &g));
@@ -1472,7 +1474,8 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
         lnx_gemm_args a = gemm_base(c, M, 4 * C, C, sC, C, c.wtptr(k.w2), k.w2.ld_t, sA, 4 * C, false);
-        a.act = LNX_ACT_GELU_BWD; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;
+        static const bool keep_h = getenv("LNX_CONV_HPRE") != nullptr;
+        a.act = keep_h ? LNX_ACT_GELU_BWD : LNX_ACT_MUL_AUX; a.aux = c.at<void>(k.hpre); a.ldaux = 4 * C;  // what the forward left in hpre
         RUN(gemm_nt_t(c, &a));
         RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C));
         a = gemm_base(c, M, C, 4 * C, sA, 4 * C, c.wtptr(k.w1), k.w1.ld_t, sD, C, false);
