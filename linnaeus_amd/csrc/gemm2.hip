@@ -261,18 +261,11 @@ __global__ __launch_bounds__(512) void gemm_nt_v4_kernel(const GemmP p) {
         uint4 wf[4], af0[4], af1[4];
         DS4_READ4(wf, st + w_off);
         DS4_READ4(af0, st + a_off);
-#ifdef V4_ABLATE_AF1  // diagnostic (tools/build_v4_ablate.sh, wrong results): a third fewer LDS fragment reads -- is the LDS port the limit?
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af1[i] = af0[i];
-#else
         DS4_READ4(af1, st + a_off + 64 * ROWB4);
-#endif
         // end of memory phase kt: own pieces of slice kt+1 landed, fragment reads of slice kt done; the slot refilled
         // in memory phase kt+1 (slice kt+4) is the one read in phase kt
         if (kt + 3 < nk) {
-#ifndef V4_ABLATE_DMA  // diagnostic (wrong results): no fill traffic in the loop -- how much of the time is the fill path?
             issue_stage(kt + 3, (kt + 3) % NST4);
-#endif
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else if (kt + 2 < nk) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
