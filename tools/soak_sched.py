@@ -1,0 +1,54 @@
+"""Soak of the drawn-tile schedulers: N training steps of mFormerV1_sm at batch 256 (the shapes on which gemm_nt_v7 / v9 and the resident
+conv-MLP kernels draw their tiles), same seed, once with LNX_TILE_SCHED=static and once with the atomic counters, each in its own process.
+A tile processed twice or never would show as a loss trajectory that leaves the other one (the two agree to summation-order rounding);
+a counter left non-zero would show as NaN / garbage from the next launch on.  usage: python tools/soak_sched.py [steps]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys, json, torch
+sys.path.insert(0, %r)
+import bench
+from linnaeus_amd.loss import multitask_cross_entropy
+from linnaeus_amd.optim import FusedAdamW
+class A: arch = "sm"; img = 224
+torch.manual_seed(0)
+cfg, model = bench.make_model(A)
+model = model.cuda(); model.set_compute_dtype("bf16"); model.train(); model.grad_mode = "direct"
+opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.05)
+B = 256
+g = torch.Generator(device="cuda").manual_seed(1)
+x = torch.rand(B, 3, 224, 224, device="cuda", generator=g); meta = torch.rand(B, 5, device="cuda", generator=g)
+tg = {t: torch.randint(1, c, (B,), device="cuda", generator=g) for t, c in bench.TASKS}
+model._inject_drop = None
+losses = []
+for i in range(int(sys.argv[1])):
+    torch.manual_seed(1000 + i)  # the DropPath draws of step i
+    model.zero_grad(set_to_none=True)
+    loss = multitask_cross_entropy(model(x, meta), tg)
+    loss.backward()
+    opt.step()
+    if i %% 10 == 0 or i < 3:
+        losses.append(loss.item())
+print(json.dumps(losses))
+''' % ROOT
+
+steps = sys.argv[1] if len(sys.argv) > 1 else "150"
+out = {}
+for sched in ("static", "atomic"):
+    env = dict(os.environ, LNX_TILE_SCHED=sched)
+    r = subprocess.run([sys.executable, "-c", CHILD, steps], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        print(r.stderr[-2000:])
+        sys.exit(1)
+    out[sched] = json.loads(r.stdout.strip().splitlines()[-1])
+a, b = out["static"], out["atomic"]
+rel = [abs(p - q) / max(abs(p), 1e-9) for p, q in zip(a, b)]
+print("static :", " ".join(f"{v:.4f}" for v in a))
+print("atomic :", " ".join(f"{v:.4f}" for v in b))
+print(f"max relative difference of the sampled losses: {max(rel):.3e} (first step {rel[0]:.3e}); all finite: {all(v == v and abs(v) < 1e6 for v in a + b)}")
+ok = all(v == v for v in a + b) and rel[0] < 1e-4 and max(rel) < 0.1 and b[-1] < b[0]
+sys.exit(0 if ok else 2)
