@@ -72,8 +72,8 @@ int device_cus() {
     return c > 0 ? c : 0;
 }
 extern "C" int lnx_set_cu_margin(int cus) {
-    if (cus < 0 || cus > 128) {
-        lnx_set_error("lnx_set_cu_margin: %d (0..128 compute units)", cus);
+    if (cus < 0 || cus > 1024) {  // (a launch always keeps at least 8 workgroups: persistent_cus)
+        lnx_set_error("lnx_set_cu_margin: %d (0..1024 compute units)", cus);
         return 1;
     }
     set_cu_margin(cus);

@@ -106,7 +106,7 @@ def test_conv_mlp_scratch_size_comes_from_the_launcher():
 def test_cu_margin_is_validated():
     lib = L.lib()
     assert lib.lnx_set_cu_margin(-1) != 0 and b"lnx_set_cu_margin" in lib.lnx_last_error()
-    assert lib.lnx_set_cu_margin(200) != 0
+    assert lib.lnx_set_cu_margin(5000) != 0
     assert lib.lnx_set_cu_margin(0) == 0
 
 

@@ -449,6 +449,35 @@ def test_nt_v9_forced_every_form(form, M, N, K, monkeypatch):
     assert kind == L.NT_KERNEL_V9, kind
 
 
+@pytest.mark.parametrize("margin", [0, 5, 248])
+def test_persistent_kernels_cover_every_tile_once_for_any_grid(margin, monkeypatch):
+    """The drawn-tile schedulers (common.hpp: per-XCD shares and counters) under odd tile counts and odd grids: lnx_set_cu_margin(5) gives a grid
+    that is not a multiple of 8 (uneven shares), 248 leaves 8 workgroups for hundreds of tiles (many draws per workgroup), random M / N put
+    ragged row tiles and 1..7 tiles into a share.  Every output element must come out right -- a tile drawn twice is harmless, a tile never
+    drawn is not -- and the launches that follow must find their counters at zero (the second loop re-uses the same stream's counter set)."""
+    import random
+
+    rnd = random.Random(1234 + margin)
+    L.check(L.lib().lnx_set_cu_margin(margin), "lnx_set_cu_margin")
+    try:
+        for force in ("LNX_NT_V7", "LNX_NT_V9"):
+            monkeypatch.setenv("LNX_NT_V7", "1" if force == "LNX_NT_V7" else "0")
+            monkeypatch.setenv("LNX_NT_V9", "1" if force == "LNX_NT_V9" else "0")
+            for _ in range(6):
+                M = rnd.randrange(1024, 40000)
+                N = rnd.choice([256, 512, 768, 1024]) if force == "LNX_NT_V9" else 64 * rnd.randrange(2, 20)
+                K = rnd.choice([384, 512, 1152])
+                A = _gpu_randn((M, K), M + N).bfloat16()
+                W = _gpu_randn((N, K), N + K, K**-0.5).bfloat16()
+                b = _gpu_randn((N,), 3)
+                out, _ = run_nt(A, W, L.BF16, False, bias=b)
+                assert L.lib().lnx_last_nt_kernel() == (L.NT_KERNEL_V7 if force == "LNX_NT_V7" else L.NT_KERNEL_V9), (force, M, N, K)
+                ref = A.float() @ W.float().t() + b
+                torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2, msg=lambda m: f"{force} M={M} N={N} K={K} margin={margin}: {m}")
+    finally:
+        L.check(L.lib().lnx_set_cu_margin(0), "lnx_set_cu_margin")
+
+
 def test_tn_deferred_reduces_in_one_launch():
     """lnx_wgrad_args.defer + lnx_gemm_tn_flush (round 4): the four weight-gradient products of a RoPE block (mFormerV1_sm stage 3 at
     the benchmark's M) leave their split-K partial tiles in separate workspace regions; nothing reaches dW / db before the flush, one

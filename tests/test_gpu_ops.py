@@ -393,6 +393,47 @@ def test_convmlp_fused_fwd_bwd(C_, M):
     torch.testing.assert_close(dgam2, dgam, rtol=2e-3, atol=2e-3)  # float atomics: summation order differs between launches
 
 
+@pytest.mark.parametrize("margin", [5, 250])
+def test_convmlp_resident_kernels_cover_every_row_for_any_grid(margin):
+    """The resident-weight conv-MLP kernels draw 32- / 16-row tiles per WAVE from per-XCD counters: with lnx_set_cu_margin the grid is no
+    multiple of 8 (uneven shares) or tiny (6 workgroups for thousands of tiles); forward and z-free backward must equal the default
+    grid's results bit for bit (the forward) / to atomics order (column sums)."""
+    C_, M = 96, 70001
+    gen = g(99)
+    bf = torch.bfloat16
+    y = (1.5 * torch.randn(M, C_, generator=gen) + 0.3).cuda().to(bf)
+    lw, lb = (1.0 + 0.2 * torch.randn(C_, generator=gen)).cuda(), (0.1 * torch.randn(C_, generator=gen)).cuda()
+    w1, b1 = (torch.randn(4 * C_, C_, generator=gen) / C_**0.5).cuda().to(bf), (0.2 * torch.randn(4 * C_, generator=gen)).cuda()
+    w2, b2 = (torch.randn(C_, 4 * C_, generator=gen) / (4 * C_) ** 0.5).cuda().to(bf), (0.2 * torch.randn(C_, generator=gen)).cuda()
+    gam = (0.5 + 0.3 * torch.randn(C_, generator=gen)).cuda()
+    x, gout = torch.randn(M, C_, generator=gen).cuda(), torch.randn(M, C_, generator=gen).cuda()
+    w2t, w1t = w2.t().contiguous(), w1.t().contiguous()
+    ws = torch.empty(256 * 2 * C_, device="cuda")
+
+    def both():
+        ln = torch.empty(M, C_, device="cuda", dtype=bf)
+        mean, rstd, out = torch.empty(M, device="cuda"), torch.empty(M, device="cuda"), torch.empty(M, C_, device="cuda")
+        ops.convmlp_fwd(None, w1, b1, w2, b2, gam, x, out, y=y, ln_w=lw, ln_b=lb, ln_eps=1e-6, ln_out=ln, mean=mean, rstd=rstd)
+        act, dh = torch.empty(M, 4 * C_, device="cuda", dtype=bf), torch.empty(M, 4 * C_, device="cuda", dtype=bf)
+        dz, dy = torch.empty(M, C_, device="cuda", dtype=bf), torch.full((M, C_), float("nan"), device="cuda", dtype=bf)
+        dw, db = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        ops.convmlp_bwd(gout, ln, None, w1, b1, w2t, w1t, gam, act, dh, dz, dy, None, y=y, ln_w=lw, mean=mean, rstd=rstd, d_ln_w=dw, d_ln_b=db, ws=ws, dz_plain=True)
+        torch.cuda.synchronize()
+        return out, ln, act, dh, dz, dy, dw, db
+
+    ref = both()
+    L.check(L.lib().lnx_set_cu_margin(margin), "lnx_set_cu_margin")
+    try:
+        for _ in range(2):  # twice: the second launch finds the counters the first one left
+            got = both()
+            for a, b_ in zip(ref[:6], got[:6]):
+                assert torch.equal(a, b_)
+            torch.testing.assert_close(got[6], ref[6], rtol=1e-4, atol=1e-3 * max(1.0, ref[6].abs().max().item()))
+            torch.testing.assert_close(got[7], ref[7], rtol=1e-4, atol=1e-3 * max(1.0, ref[7].abs().max().item()))
+    finally:
+        L.check(L.lib().lnx_set_cu_margin(0), "lnx_set_cu_margin")
+
+
 @pytest.mark.parametrize("C_,M", [(32, 200), (64, 130), (96, 777), (128, 100), (192, 333), (96, 50001), (192, 40000)])
 def test_convmlp_fused_layernorm(C_, M):
     """The conv-MLP kernels with the block LayerNorm inside (blocks/convnext.py:77,84: `x = self.norm(x)` in front of pwconv1):
