@@ -1,5 +1,6 @@
 """GEMM kernels (lnx_gemm_nt / lnx_gemm_tn) against plain PyTorch fp32 on the same op."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -476,6 +477,40 @@ def test_persistent_kernels_cover_every_tile_once_for_any_grid(margin, monkeypat
                 torch.testing.assert_close(out.float(), ref, rtol=1e-2, atol=1e-2, msg=lambda m: f"{force} M={M} N={N} K={K} margin={margin}: {m}")
     finally:
         L.check(L.lib().lnx_set_cu_margin(0), "lnx_set_cu_margin")
+
+
+def test_persistent_kernels_on_two_streams_do_not_share_counters():
+    """Two streams launching persistent NT products at the same time (what two plans in one process, or a plan beside a user's own
+    stream, do): each stream draws from its own counter set (api.cpp: tile_slot_of), so tiles of one launch are never handed to the
+    other.  40 interleaved launches per stream, every result checked."""
+    M, N, K = M_SM, 384, 1152
+    os.environ["LNX_NT_V7"] = "1"
+    try:
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        A1, A2 = _gpu_randn((M, K), 11).bfloat16(), _gpu_randn((M, K), 12).bfloat16()
+        W1, W2 = _gpu_randn((N, K), 13, K**-0.5).bfloat16(), _gpu_randn((2 * N, K), 14, K**-0.5).bfloat16()
+        ref1, ref2 = (A1.float() @ W1.float().t()), (A2.float() @ W2.float().t())
+        torch.cuda.synchronize()
+        outs1 = [torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+        outs2 = [torch.empty(M, 2 * N, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+
+        def launch(A, W, out, stream):
+            a = L.GemmArgs()
+            a.dtype, a.M, a.N, a.K = L.BF16, A.shape[0], W.shape[0], A.shape[1]
+            a.A, a.lda, a.W, a.ldw, a.C, a.ldc = _ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(out), out.stride(0)
+            L.check(L.lib().lnx_gemm_nt(C.byref(a), C.c_void_p(stream.cuda_stream)), "lnx_gemm_nt")
+
+        for i in range(40):
+            launch(A1, W1, outs1[i % 4], s1)
+            launch(A2, W2, outs2[i % 4], s2)
+        torch.cuda.synchronize()
+        assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_V7
+        for o in outs1:
+            torch.testing.assert_close(o.float(), ref1, rtol=1e-2, atol=1e-2)
+        for o in outs2:
+            torch.testing.assert_close(o.float(), ref2, rtol=1e-2, atol=1e-2)
+    finally:
+        os.environ.pop("LNX_NT_V7", None)
 
 
 def test_tn_deferred_reduces_in_one_launch():
