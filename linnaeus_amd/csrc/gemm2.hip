@@ -618,17 +618,21 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
     }
     if (p.ws) {
         // split-K partials: this workgroup's whole RW x CW tile, unmasked, to its slot of the workspace
+        // (round 4: in the lanes' own order -- slot ((wave 4 + ri) 4 + ci) 64 + lane holds the float4 acc[ri][ci], i.e. rows 4g .. 4g+3 of one
+        // column: one 1-KiB store per instruction instead of four 64-byte row segments; tn_reduce_body reads the same order)
         const int tiles = p.tiles_n * p.tiles_k;
-        float* wt = p.ws + (size_t)(split * tiles + tr * p.tiles_k + tc) * (RW * CW);
+        float4* wt = reinterpret_cast<float4*>(p.ws + (size_t)(split * tiles + tr * p.tiles_k + tc) * (RW * CW)) + (wave * 16) * 64 + lane;
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wr * 64 + ri * 16 + 4 * g + r;
+            for (int ci = 0; ci < 4; ++ci) wt[(ri * 4 + ci) * 64] = make_float4(acc[ri][ci][0], acc[ri][ci][1], acc[ri][ci][2], acc[ri][ci][3]);
+        if (do_bias && s == 0) {
 #pragma unroll
-                for (int ci = 0; ci < 4; ++ci) wt[row * CW + wc * 64 + ci * 16 + s] = acc[ri][ci][r];
-                if (do_bias && s == 0) p.ws[(size_t)p.splits * tiles * (RW * CW) + (size_t)(split * p.tiles_n + tr) * RW + row] = accb[ri][r];
-            }
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p.ws[(size_t)p.splits * tiles * (RW * CW) + (size_t)(split * p.tiles_n + tr) * RW + wr * 64 + ri * 16 + 4 * g + r] = accb[ri][r];
+        }
         return;
     }
 #pragma unroll
@@ -656,24 +660,29 @@ __global__ __launch_bounds__(512) void gemm_tn_v2_kernel(const WgradP p) {
 
 // second stage of the workspace path: dW[n, col(k)] += sum over splits of the partial tiles, db likewise
 __device__ __forceinline__ void tn_reduce_body(const WgradP& p, int RW, int CW, const int64_t idx) {
-    const int kq = (p.k_store + 3) >> 2;  // float4 groups per output row
     const int tiles = p.tiles_n * p.tiles_k;
+    const int tile_f4 = RW * CW / 4;  // float4 slots of a partial tile, in the producing lanes' order (gemm_tn_v2_kernel's epilogue)
     const size_t tile_floats = (size_t)RW * CW;
-    if (idx < (int64_t)p.N * kq) {
-        const int n = (int)(idx / kq), k = (int)(idx - (int64_t)n * kq) * 4;
-        const int tr = n / RW, tc = k / CW;
-        const float* src = p.ws + (size_t)(tr * p.tiles_k + tc) * tile_floats + (size_t)(n - tr * RW) * CW + (k - tc * CW);
+    if (idx < (int64_t)tiles * tile_f4) {
+        const int tile = (int)(idx / tile_f4), f = (int)(idx - (int64_t)tile * tile_f4);
+        const int tr = tile / p.tiles_k, tc = tile - tr * p.tiles_k;
+        const int lane = f & 63, ci = (f >> 6) & 3, ri = (f >> 8) & 3, wave = f >> 10;
+        const int WC = CW / 64, wr = wave / WC, wc = wave - wr * WC;
+        const int n0 = tr * RW + wr * 64 + ri * 16 + 4 * (lane >> 4);  // rows n0 .. n0 + 3
+        const int k = tc * CW + wc * 64 + ci * 16 + (lane & 15);
+        if (n0 >= p.N || k >= p.k_store) return;
+        const float4* src = reinterpret_cast<const float4*>(p.ws + (size_t)tile * tile_floats) + f;
         // eight independent loads in flight per thread; the summation order is fixed (partials of splits sp = j mod 8
         // are added in order, the remainder goes to sum 0, then the eight sums are combined pairwise)
         float4 part[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const size_t sstep = (size_t)tiles * tile_floats;
+        const size_t sstep = (size_t)tiles * tile_floats / 4;  // float4 units between the same tile of consecutive splits
         int sp = 0;
         for (; sp + 8 <= p.splits; sp += 8) {
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(src + (size_t)(sp + j) * sstep);
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sp + j) * sstep];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 part[j].x += v[j].x;
@@ -683,7 +692,7 @@ __device__ __forceinline__ void tn_reduce_body(const WgradP& p, int RW, int CW, 
             }
         }
         for (; sp < p.splits; ++sp) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)sp * sstep);
+            const float4 v = src[(size_t)sp * sstep];
             part[0].x += v.x;
             part[0].y += v.y;
             part[0].z += v.z;
@@ -698,32 +707,18 @@ __device__ __forceinline__ void tn_reduce_body(const WgradP& p, int RW, int CW, 
                 part[j].z += part[j + w].z;
                 part[j].w += part[j + w].w;
             }
-        const float4 a = part[0];
-        const float av[4] = {a.x, a.y, a.z, a.w};
-        float* drow = p.dW + (int64_t)n * p.lddw;
+        const float av[4] = {part[0].x, part[0].y, part[0].z, part[0].w};
+        int col = k;
         if (p.k_perm_c > 0) {
             const int P = p.K / p.k_perm_c;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = k + j;
-                if (kk >= p.k_store) break;
-                const int pq = kk / p.k_perm_c;
-                drow[(kk - pq * p.k_perm_c) * P + pq] += av[j];
-            }
-        } else if (k + 3 < p.k_store && ((((uintptr_t)(drow + k)) & 15) == 0)) {
-            float4 d = *reinterpret_cast<float4*>(drow + k);
-            d.x += a.x;
-            d.y += a.y;
-            d.z += a.z;
-            d.w += a.w;
-            *reinterpret_cast<float4*>(drow + k) = d;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j < p.k_store) drow[k + j] += av[j];
+            const int pq = k / p.k_perm_c;
+            col = (k - pq * p.k_perm_c) * P + pq;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < p.N) p.dW[(int64_t)(n0 + r) * p.lddw + col] += av[r];  // (16 lanes = 16 consecutive k: 64-byte segments per row)
     } else if (p.db != nullptr) {
-        const int64_t n = idx - (int64_t)p.N * kq;
+        const int64_t n = idx - (int64_t)tiles * tile_f4;
         if (n < p.N) {
             const int tr = (int)n / RW;
             const float* src = p.ws + (size_t)p.splits * tiles * tile_floats + (size_t)tr * RW + (n - tr * RW);
@@ -826,7 +821,7 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st, bool defer) 
 #undef TNV2
 #undef TNV2_
     if (p.ws) {
-        const int64_t work = (int64_t)p.N * ((p.k_store + 3) >> 2) + (p.db ? p.N : 0);
+        const int64_t work = (int64_t)tiles * (RW * CW / 4) + (p.db ? p.N : 0);  // one thread per float4 slot of a partial tile, then one per bias entry
         const int blocks = (int)cdiv(work, 256);
         if (defer) {
             if (g_tn_pending.n > 0 && (g_tn_pending_stream != st || g_tn_pending.n == TN_BATCH)) tn_flush(g_tn_pending_stream);
