@@ -98,16 +98,13 @@ int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 /* Which kernel family lnx_gemm_nt's dispatcher chose (host-side bookkeeping, no device work): the parity tests use it to prove
  * that a shape really ran on the kernel it is meant to cover (e.g. the persistent gemm_nt_v7 at the benchmark's M = 50 944).
  * lnx_last_nt_kernel(): family of the most recent NT launch of this process (any stream), 0 before the first.
- * lnx_nt_kernel_launches(kind): launches of that family since the library was loaded.
- * lnx_last_nt_tile_rows(): product rows per tile of the most recent LNX_NT_KERNEL_V9 launch -- 256, or 224 where that costs fewer
- *   rounds x rows on the CUs a launch may use (0 before the first). */
+ * lnx_nt_kernel_launches(kind): launches of that family since the library was loaded. */
 enum { LNX_NT_KERNEL_NONE = 0, LNX_NT_KERNEL_V1 = 1 /* 128x128 register-staged, both storage types */, LNX_NT_KERNEL_V2 = 2 /* 256x128 LDS-DMA ring */,
        LNX_NT_KERNEL_SKINNY = 3 /* M <= 256, one wave per tile */, LNX_NT_KERNEL_V4 = 4 /* 256x256 tile */,
        LNX_NT_KERNEL_V7 = 7 /* persistent 256x128, deferred stores */, LNX_NT_KERNEL_V9 = 9 /* persistent 256x256 (round 4) */,
        LNX_NT_KERNEL_EXPERIMENT = 15 /* a kernel of tools/experiments/ (never in the shipped library) */, LNX_NT_KERNEL_KINDS = 16 };
 int lnx_last_nt_kernel(void);
 int64_t lnx_nt_kernel_launches(int kind);
-int lnx_last_nt_tile_rows(void);
 
 /* fp8 operands (BASELINE config 5's "fp8 MFMA path"; the reference has no fp8 code: this is the MI355X form of its
  * bf16 Linear, mlp.py:46-66 / rope_2d_mhsa.py:432,500).  OCP e4m3fn storage, one dequantisation scale per tensor:

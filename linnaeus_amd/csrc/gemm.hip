@@ -342,10 +342,7 @@ void note_nt_kernel(int kind) {
     g_last_nt.store(kind, std::memory_order_relaxed);
     g_nt_launches[kind].fetch_add(1, std::memory_order_relaxed);
 }
-static std::atomic<int> g_last_nt_rows{0};
-void note_nt_tile_rows(int rows) { g_last_nt_rows.store(rows, std::memory_order_relaxed); }
 }  // namespace lnxg
-extern "C" int lnx_last_nt_tile_rows(void) { return lnxg::g_last_nt_rows.load(std::memory_order_relaxed); }
 extern "C" int lnx_last_nt_kernel(void) { return g_last_nt.load(std::memory_order_relaxed); }
 extern "C" int64_t lnx_nt_kernel_launches(int kind) {
     return (kind < 0 || kind >= LNX_NT_KERNEL_KINDS) ? -1 : (int64_t)g_nt_launches[kind].load(std::memory_order_relaxed);

@@ -316,15 +316,7 @@ static bool big_tile_wins(const GemmP& p) {
     const int dc = device_cus();
     const int cus = persistent_cus(dc > 0 ? dc : 256);
     const int64_t rows = cdiv(p.M, 256);
-    const int64_t tn = p.N / BN4;
-    double big_rounds = (double)cdiv(rows * tn, (int64_t)cus);
-    // where the persistent gemm_nt_v9 would run the product, its shorter tiles count (gemm5.hip: rounds x rows / 256)
-    static const bool v9_off = getenv("LNX_NT_V9") && atoi(getenv("LNX_NT_V9")) == 0;
-    if (!v9_off && p.K % 32 == 0 && p.K / 32 >= 8 && rows * tn * 2 >= 3 * 256) {
-        const int h = pick_v9_rows(p);
-        big_rounds = (double)cdiv((int64_t)cdiv(p.M, h) * tn, (int64_t)cus) * h / 256.0;
-    }
-    const double big = big_rounds * 2.0 * (p.K <= 512 ? 0.97 : 0.88);
+    const double big = (double)cdiv(rows * (p.N / BN4), (int64_t)cus) * 2.0 * (p.K <= 512 ? 0.97 : 0.88);
     const double small = (double)cdiv(rows * cdiv(p.N, 128), (int64_t)cus);
     return small >= 0.93 * big;  // (the small tile has to win by a margin: measured, a tie on paper goes to the big tile at sm / lg / xl)
 }

@@ -10,16 +10,6 @@
 // deferral of the stores into the next K loop: a 128x64 wave tile's results are 64-128 registers on top of 128 accumulator registers,
 // which the 256-register budget of two waves per SIMD does not hold (v7's 64x64 wave tiles do).
 //
-// Tile height (NM1).  Every tile of a launch costs the same, so a launch takes ceil(tiles / CUs) rounds: 400 tiles of 256x256 (xl's
-// N = 1024 products at 128 images) are two rounds for 1.56 rounds of work.  The LDS image always has 256 row slots per slice; a wave half
-// is one 64-row sub-tile plus a second one of NM1 = 4 or 3 sixteen-row fragments, so a tile covers 256 or 224 CONTIGUOUS rows of the
-// product (460 tiles of 224 rows: two rounds of 7/8 the work each).  The unused row slots of a short tile are filled with copies of a
-// neighbouring row and never read by an MFMA.  pick_v9_rows() chooses by rounds x height.  Measured (profiles/r04_v9_rows.log): the
-// gain is far below the 12.5 % of the arithmetic -- a last round that fills 56 % of the CUs runs them faster (clock and memory to
-// themselves) -- 1-3 % on xl / lg products with equal round counts, 7 % at xl's qkv data gradient, 11-14 % at sm's N = 1536 products
-// for 128 images (684 tiles in three rounds, where the 256-row tile's 600 lose to the 256x128 kernel); 192-row tiles (NM1 = 2, the
-// template takes it) lost 10-30 % wherever they added a round and won nowhere, so they are not instantiated.
-//
 // Scheduling: as gemm_nt_v7 -- wave 0 draws the position after next in iteration 0 (one more operation on ITS counter), publishes it
 // through an LDS dword in iteration 2, everyone reads it in iteration 3; first use in iteration nk - 3 >= 5.  K / 32 >= 8.
 #include "gemm_common.hpp"
@@ -46,17 +36,14 @@ __device__ __forceinline__ int key9(int row) { return (row & 16) ? 3 : 0; }
 
 // 16-byte stores one lane issues in the epilogue of a FULL tile (two 64x64 sub-tiles): what the first two iterations of the next
 // tile let stay in flight.  Checked against the compiled code by tools/audit_v9_stores.py (a smaller number is always safe).
-template <bool OUT_F32, int F, int NM1> struct EpiStores {
-    static constexpr int value = (4 + NM1) * ((OUT_F32 ? 4 : 2) + ((F & F_C2) ? 2 : 0));
+template <bool OUT_F32, int F> struct EpiStores {
+    static constexpr int value = 2 * (OUT_F32 ? 16 : 8) + ((F & F_C2) ? 16 : 0);
 };
 
-template <bool OUT_F32, int F, int NM1>
+template <bool OUT_F32, int F>
 __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
     typedef bf16_t T;
-    static_assert(NM1 >= 2 && NM1 <= 4, "second sub-tile: 2-4 fragments");
-    constexpr int HALF = 64 + 16 * NM1;  // product rows of one wave half
-    constexpr int BMT = 2 * HALF;        // product rows of a tile: 256 / 224 / 192
-    constexpr int NSTORE = EpiStores<OUT_F32, F, NM1>::value;
+    constexpr int NSTORE = EpiStores<OUT_F32, F>::value;
     static_assert(2 * PIECES9 + NSTORE + 1 <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST9][A 256 rows | W 256 rows][64 B] + one dword
 
@@ -84,15 +71,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
         const int row = 16 * i + (lane >> 2);
         const int slot = lane & 3;
         if (row < BM9) {
-            // row slot -> product row: slots 0-63 of a wave half are its first sub-tile; slot 64 + 16 a + q of the second one is row
-            // 64 + 4 NM1 a + q for q < 4 NM1 (what fragment q / 4 of lane s = 4 a + (q & 3) multiplies and the epilogue stores)
-            const int rr = row & 127;
-            int local = rr;
-            if (NM1 < 4 && rr >= 64) {
-                const int q = rr & 15;
-                local = 64 + ((rr - 64) >> 4) * (4 * NM1) + (q < 4 * NM1 ? q : 4 * NM1 - 1);
-            }
-            int m = m0 + (row >> 7) * HALF + local;
+            int m = m0 + row;
             if (m >= p.M) m = p.M - 1;
             return (uint32_t)(m * (int)p.lda + (slot ^ key9(row)) * 8) * 2u;
         }
@@ -139,7 +118,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
     auto pos_origin = [&](int ps, int& mo, int& no) __attribute__((always_inline)) {
         const int logical = xbase + ps;
         no = (logical % p.tiles_n) * BN9;
-        mo = (logical / p.tiles_n) * BMT;
+        mo = (logical / p.tiles_n) * BM9;
     };
     pos_origin(pos, m0, n0);
 #pragma unroll
@@ -174,13 +153,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
             uint4 wf[4], af0[4], af1[4];
             V9_READ4(wf, stg + w_off);
             V9_READ4(af0, stg + a_off);
-            {
-                const uint32_t a1_ = stg + a_off + 64 * ROWB9;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(af1[0]) : "v"(a1_) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(af1[1]) : "v"(a1_) : "memory");
-                if constexpr (NM1 > 2) asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(af1[2]) : "v"(a1_) : "memory");
-                if constexpr (NM1 > 3) asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(af1[3]) : "v"(a1_) : "memory");
-            }
+            V9_READ4(af1, stg + a_off + 64 * ROWB9);
             if (fx == 3 && dyn) asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(slot_addr) : "memory");
             const bool draw = fx == 1 && dyn && wave == 0;
             if (draw) sched_draw(fetched, ctr);
@@ -223,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < NM1; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
+                for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             ring = (ring + 1) & 3;
@@ -256,10 +229,10 @@ __global__ __launch_bounds__(512) void gemm_nt_v9_kernel(const GemmP p) {
         }
         // ---- epilogue: the one-shot kernels' (its loads wait for the counter to drain, i.e. also for the next tile's three slices --
         // which the next K loop needs at once anyway); its stores stay in flight into the next tile ----
-        gemm_epilogue_fast<T, OUT_F32, F, 4>(p, acc0, m0 + wm * HALF, n0 + wn * 64, lane);
-        gemm_epilogue_fast<T, OUT_F32, F, NM1>(p, acc1, m0 + wm * HALF + 64, n0 + wn * 64, lane);
+        gemm_epilogue_fast<T, OUT_F32, F>(p, acc0, m0 + wm * 128, n0 + wn * 64, lane);
+        gemm_epilogue_fast<T, OUT_F32, F>(p, acc1, m0 + wm * 128 + 64, n0 + wn * 64, lane);
         if (!has_next) break;
-        const bool full = m0 + BMT <= p.M;
+        const bool full = m0 + BM9 <= p.M;
         if (!full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rows beyond M: fewer stores than NSTORE were issued, count nothing
         stores_behind = full;
         asm volatile("" ::: "memory");
@@ -280,31 +253,9 @@ bool nt_v9_ok(const GemmP& p, int f, bool out_f32) {
     return f == 0 || f == F_BIAS || f == (F_BIAS | F_C2 | F_GELU) || f == (F_BIAS | F_GELU) || f == F_GELU_BWD;
 }
 
-// Rows per tile: 224 where that costs fewer rounds x rows than 256 (ties go to the taller tile, whose operand traffic per FLOP is
-// lower).  LNX_NT_V9_ROWS=256|224 forces one (A/B switch, tests).
-int pick_v9_rows(const GemmP& p) {
-    const char* fe = getenv("LNX_NT_V9_ROWS");  // (read per launch: the tests switch it)
-    const int forced = fe ? atoi(fe) : 0;
-    if (forced == 256 || forced == 224) return forced;
-    const int dc = device_cus();
-    const int64_t cus = persistent_cus(dc > 0 ? dc : 256);
-    const int64_t tn = p.N / BN9;
-    int best = 256;
-    int64_t best_cost = 0;
-    for (int rows = 256; rows >= 224; rows -= 32) {
-        const int64_t cost = cdiv((int64_t)cdiv(p.M, rows) * tn, cus) * rows;
-        if (rows == 256 || cost < best_cost) {
-            best = rows;
-            best_cost = cost;
-        }
-    }
-    return best;
-}
-
-template <int NM1>
-static int launch_nt_v9_t(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
+int launch_nt_v9(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     GemmP p = p0;
-    p.tiles_m = cdiv(p.M, 2 * (64 + 16 * NM1));
+    p.tiles_m = cdiv(p.M, BM9);
     p.tiles_n = p.N / BN9;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int cus = device_cus();
@@ -317,10 +268,10 @@ static int launch_nt_v9_t(const GemmP& p0, int f, bool out_f32, hipStream_t st) 
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \
         if (!attr) {                                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v9_kernel<O, FF, NM1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v9_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr = true;                                                                                                             \
         }                                                                                                                            \
-        hipLaunchKernelGGL((gemm_nt_v9_kernel<O, FF, NM1>), dim3(grid), dim3(512), lds, st, p);                                      \
+        hipLaunchKernelGGL((gemm_nt_v9_kernel<O, FF>), dim3(grid), dim3(512), lds, st, p);                                           \
     } while (0)
     if (out_f32) V9_LAUNCH(true, F_BIAS | F_RES);
     else if (f == 0) V9_LAUNCH(false, 0);
@@ -330,13 +281,6 @@ static int launch_nt_v9_t(const GemmP& p0, int f, bool out_f32, hipStream_t st) 
     else V9_LAUNCH(false, F_GELU_BWD);
 #undef V9_LAUNCH
     return 0;
-}
-
-int launch_nt_v9(const GemmP& p, int f, bool out_f32, hipStream_t st) {
-    const int rows = pick_v9_rows(p);
-    note_nt_tile_rows(rows);
-    if (rows == 224) return launch_nt_v9_t<3>(p, f, out_f32, st);
-    return launch_nt_v9_t<4>(p, f, out_f32, st);
 }
 
 }  // namespace lnxg

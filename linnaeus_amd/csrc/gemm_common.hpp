@@ -259,15 +259,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4_t (&acc)[4][
 // offsets < 2^31.
 enum { F_BIAS = 1, F_C2 = 2, F_GELU = 4, F_GELU_BWD = 8, F_RES = 16, F_MXOUT = 32, F_GENERIC = 1 << 10 };
 
-// NMI: 16-row fragments of the sub-tile (4: the 64 rows mrow0 .. mrow0 + 63; 3 / 2: a 48- / 32-row sub-tile whose fragment mi holds rows
-// mrow0 + (s >> 2) * 4 NMI + (s & 3) + 4 mi -- gemm_nt_v9's short tiles; acc[..][mi >= NMI] is not read)
-template <typename T, bool OUT_F32, int F, int NMI = 4>
+template <typename T, bool OUT_F32, int F>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc)[4][4], int mrow0, int ncol0, int lane) {
     constexpr int EPV = TT<T>::EPV;
     const int s = lane & 15, g = lane >> 4;
     const int nb = ncol0 + g * 16;
     if (nb >= p.N) return;
-    const int mbase = mrow0 + (s >> 2) * (4 * NMI) + (s & 3);  // row of slot mi = mbase + 4 mi
+    const int mbase = mrow0 + (s >> 2) * 16 + (s & 3);  // row of slot mi = mbase + 4 mi
     float bias[16];
     if (F & F_BIAS) {
 #pragma unroll
@@ -284,7 +282,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
     float rs[4];
     if (F & F_GELU_BWD) {
 #pragma unroll
-        for (int mi = 0; mi < NMI; ++mi) {
+        for (int mi = 0; mi < 4; ++mi) {
             const int m = min(mbase + 4 * mi, p.M - 1);
             const T* ax = reinterpret_cast<const T*>(p.aux) + (m * (int)p.ldaux + nb);
 #pragma unroll
@@ -302,7 +300,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
         const int q0 = scaled ? mrow0 / p.rows_per_sample : 0;
         const int edge = (q0 + 1) * p.rows_per_sample;
 #pragma unroll
-        for (int mi = 0; mi < NMI; ++mi) {
+        for (int mi = 0; mi < 4; ++mi) {
             const int m = min(mbase + 4 * mi, p.M - 1);
             rs[mi] = 1.f;
             if (scaled) rs[mi] = p.rows_per_sample >= 64 ? p.rowscale[q0 + (m >= edge ? 1 : 0)] : p.rowscale[m / p.rows_per_sample];
@@ -318,7 +316,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmP& p, f32x4_t (&acc
         }
     }
 #pragma unroll
-    for (int mi = 0; mi < NMI; ++mi) {
+    for (int mi = 0; mi < 4; ++mi) {
         const int m = mbase + 4 * mi;
         if (m >= p.M) continue;
         float v[16];
@@ -461,7 +459,6 @@ int launch_nt_v7(const GemmP& p, int f, bool out_f32, hipStream_t st);
 // gemm5.hip: persistent 256x256 kernel (the v4 K loop, tiles drawn from the counters, ring never drained)
 bool nt_v9_ok(const GemmP& p, int f, bool out_f32);
 int launch_nt_v9(const GemmP& p, int f, bool out_f32, hipStream_t st);
-int pick_v9_rows(const GemmP& p);  // rows per tile (256 / 224 / 192) gemm_nt_v9 will use for this product
 
 // measurement kernels live outside the product (tools/experiments/); their library registers a dispatcher here.  It returns 0
 // when it has launched the product, anything else to decline.  nullptr in the shipped library.
@@ -470,7 +467,6 @@ extern nt_experiment_fn g_nt_experiment;
 
 // which NT kernel family a launch took (lnx_last_nt_kernel / lnx_nt_kernel_launches: the tests' proof of dispatch)
 void note_nt_kernel(int kind);
-void note_nt_tile_rows(int rows);
 
 // gemm_skinny.hip: M <= 256 (one wave per 32x32 output tile, operands straight from L2)
 bool nt_skinny_ok(const GemmP& p, int dtype, bool out_f32);

@@ -450,40 +450,6 @@ def test_nt_v9_forced_every_form(form, M, N, K, monkeypatch):
     assert kind == L.NT_KERNEL_V9, kind
 
 
-@pytest.mark.parametrize("M,N,K", [(25600, 1024, 1024), (25600 - 37, 1024, 4096), (37120, 768, 768), (M_SM - 37, 512, 384), (6784, 2048, 2048), (1024, 256, 256),
-                                   (2048 + 16, 512, 1024)])
-@pytest.mark.parametrize("rows", [224])
-@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1", "fc1d", "bias_gelu"])
-def test_nt_v9_short_tiles_every_form(form, rows, M, N, K, monkeypatch):
-    """gemm_nt_v9's 224-row tiles (LNX_NT_V9_ROWS forces the height): the second sub-tile of each wave half has 3 fragments, its row
-    slots map to contiguous product rows, the epilogue stores 7/8 of the count.  xl's (M = 128 x 200) and lg@384's (64 x 580) row
-    counts, ragged last tiles (M % rows in every residue class that matters: 0 < r < 64, 64 < r, r % 16 != 0), one- and two-tile launches;
-    every epilogue form, against fp64."""
-    monkeypatch.setenv("LNX_NT_V9", "1")
-    monkeypatch.setenv("LNX_NT_V7", "0")
-    monkeypatch.setenv("LNX_NT_V9_ROWS", str(rows))
-    kind = _check_form(form, M, N, K, rows_per_sample=200 if M % 200 == 0 else 52)
-    assert kind == L.NT_KERNEL_V9, kind
-    assert L.lib().lnx_last_nt_tile_rows() == rows
-
-
-def test_nt_v9_tile_height_follows_rounds():
-    """The height gemm_nt_v9 picks by itself: rounds x rows on 256 CUs.  xl at 128 images (M = 25 600): N = 1024 -> 460 tiles of 224 rows in two
-    rounds instead of 400 of 256 (also two rounds); N = 3072 and 4096 stay at 256 (six rounds against five, eight against seven: no fewer
-    rounds x rows).  lg@384 at 64 images (M = 37 120): N = 768 and 2304 -> 224.  sm at 128 images: the N = 1536 products take 684 tiles
-    of 224 rows (three rounds) where 600 of 256 rows lose to the 256x128 kernel."""
-    if L.lib().lnx_device_cus() != 256:
-        pytest.skip("the expected heights are for 256 CUs")
-    for M, N, K, want in [(25600, 1024, 1024, 224), (25600, 3072, 1024, 256), (25600, 4096, 1024, 256), (37120, 768, 768, 224), (37120, 2304, 768, 224),
-                          (M_SM, 1536, 384, 256), (25472, 1536, 384, 224)]:
-        A = _gpu_randn((M, K), 1).bfloat16()
-        W = _gpu_randn((N, K), 2, K**-0.5).bfloat16()
-        out, _ = run_nt(A, W, L.BF16, False)
-        assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_V9, (M, N, K)
-        assert L.lib().lnx_last_nt_tile_rows() == want, (M, N, K, L.lib().lnx_last_nt_tile_rows())
-        torch.testing.assert_close(out.float(), A.float() @ W.float().t(), rtol=1e-2, atol=1e-2)
-
-
 @pytest.mark.parametrize("margin", [0, 5, 248])
 def test_persistent_kernels_cover_every_tile_once_for_any_grid(margin, monkeypatch):
     """The drawn-tile schedulers (common.hpp: per-XCD shares and counters) under odd tile counts and odd grids: lnx_set_cu_margin(5) gives a grid

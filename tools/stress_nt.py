@@ -13,7 +13,6 @@ for it in range(160):
     os.environ["LNX_NT_V7"] = "1" if kind == "v7" else "0"
     os.environ["LNX_NT_V9"] = "1" if kind == "v9" else "0"
     os.environ["LNX_TILE_SCHED"] = rnd.choice(["atomic", "atomic", "static"])
-    os.environ["LNX_NT_V9_ROWS"] = rnd.choice(["0", "256", "224"])  # (0: the dispatcher's own choice)
     M = rnd.randrange(1024, 30000)
     N = rnd.choice([256, 512, 768, 1280]) if kind == "v9" else 64 * rnd.randrange(1, 24)
     K = rnd.choice([256, 384, 512, 640, 1152, 2048]) if kind == "v9" else rnd.choice([384, 448, 512, 1152, 1536])
