@@ -212,8 +212,10 @@ def cpu_baseline(args, cfg):
 
 def live_profile(args, model, state, loss_fn, ips_per_gpu):
     """Untimed extra steps on rank 0 with HIP events on the launch stream.  Pass 1: an event pair around every launch of the timed
-    kernel classes (time, FLOPs, algorithmic HBM bytes per class).  Pass 2: an event pair around every whole RoPE block and
-    nothing inside it (what the attention + MLP blocks cost in the step -> north-star's own fraction)."""
+    kernel classes (time, FLOPs, algorithmic HBM bytes per class) -- with the backward's weight-gradient stream switched OFF
+    (lnx_plan_set_wgrad_stream), so that a kernel's duration is its own and not its share of two kernels running side by side.
+    Pass 1b: the same with the stream on, as the timed steps run (gemm_nt / gemm_tn only: `overlapped`).  Pass 2: an event pair around
+    every whole RoPE block and nothing inside it, stream on (what the attention + MLP blocks cost in the step -> north-star's own fraction)."""
     from linnaeus_amd import _lib as L
 
     lib = L.lib()
@@ -233,7 +235,11 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
         L.check(lib.lnx_plan_profile_end_ex(st["handle"], ms, work, byts, cnt), "profile_end_ex")
         return ms, work, byts, cnt
 
+    was = lib.lnx_plan_set_wgrad_stream(st["handle"], 0)
     ms, work, byts, cnt = run_steps(lib.lnx_plan_profile_begin)
+    if was < 0 or lib.lnx_plan_set_wgrad_stream(st["handle"], was) < 0:
+        L.check(1, "lnx_plan_set_wgrad_stream")
+    oms, _, _, ocnt = run_steps(lib.lnx_plan_profile_begin) if was == 1 else (None, None, None, None)
     sms, swork, _, scnt = run_steps(lib.lnx_plan_profile_begin_spans)
     model._segment_hook = hook
     n = args.profile_steps
@@ -253,6 +259,12 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
             per["algorithmic_gb_per_step"] = round(byts[i] / n / 1e9, 3)
             per["algorithmic_gbs"] = round(byts[i] / (ms[i] * 1e-3) / 1e9, 1)
         kernels[nm] = per
+    if oms is not None:
+        # the same classes as the timed steps run them: weight-gradient products beside the data-gradient chain (each kernel's span then
+        # covers time it shares with the other stream's kernel -- the sum over classes exceeds the wall time)
+        kernels["overlapped"] = {"what": "per-launch HIP-event time with the weight-gradient stream ON (the timed steps' mode); the classes above are "
+                                         "timed with it OFF (lnx_plan_set_wgrad_stream(plan, 0)): a kernel alone on the chip",
+                                 "gemm_nt_ms_per_step": round(oms[0] / n, 4), "gemm_tn_ms_per_step": round(oms[1] / n, 4)}
     for i, nm in ((8, "rope_block_spans"), (9, "conv_block_spans")):
         if scnt[i]:
             kernels[nm] = {"ms_per_step": round(sms[i] / n, 4), "spans_per_step": scnt[i] // n, "tflops": round(swork[i] / (sms[i] * 1e-3) / 1e12, 2)}
@@ -281,7 +293,12 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                 "launches_per_step": kernels["gemm_nt"]["launches_per_step"], "flops_per_step": work[0] / n, "hbm": hbm,
                 "note": "frac = achieved / dense bf16 MFMA peak.  The class's FLOP per algorithmic byte is below the ridge, so by its own bytes it is HBM-bound: "
-                        "its MFMA fraction cannot exceed hbm.mfma_frac_ceiling_* at the stated bandwidths"}
+                        "its MFMA fraction cannot exceed hbm.mfma_frac_ceiling_* at the stated bandwidths",
+                "measured_with": "HIP events around every launch of the class, extra untimed steps, weight-gradient stream OFF (each kernel alone on the chip: "
+                                 "rocprofv3 --kernel-trace of `LNX_WGRAD_STREAM=0 python3 bench.py ...` agrees, profiles/*_kernel_stats.csv).  In the timed steps the "
+                                 "weight-gradient products run beside these kernels on a second stream: kernels.overlapped has the class's time in that mode"}
+    if oms is not None and ocnt[0]:
+        roofline["overlapped_avg_launch_us"] = round(oms[0] * 1e3 / ocnt[0], 2)
     rope = None
     if scnt[8]:
         # north-star: ">= 60 % of MFMA peak on the attention + MLP blocks".  FLOPs = the plan's own count for the RoPE blocks

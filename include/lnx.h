@@ -694,6 +694,13 @@ int lnx_plan_profile_end(lnx_plan* p, double* ms, double* work, int* launches);
 #define LNX_PROFILE_CLASSES_EX 10
 int lnx_plan_profile_begin_spans(lnx_plan* p);
 int lnx_plan_profile_end_ex(lnx_plan* p, double* ms, double* work, double* bytes, int* launches);
+/* Round 4: the backward's weight-gradient stream.  By default a plan runs the RoPE blocks' weight-gradient products (+ their batched
+ * split-K reduce) and the fused ConvNeXt blocks' pointwise weight gradients (+ the LayerScale step) on a HIP stream of its own, forked
+ * behind the kernel that wrote each product's dY and joined before that buffer's next writer and at the end of every block -- the
+ * same kernels, the same sums in the same order (bit-equal gradients), ramps and tails of one chain under the body of the other.
+ * lnx_plan_set_wgrad_stream(p, 0) puts everything back on the launch stream (what bench.py's per-kernel timing pass does, so that a
+ * kernel's duration is its own); returns the previous setting (0 / 1), negative on error.  LNX_WGRAD_STREAM=0 never creates the stream. */
+int lnx_plan_set_wgrad_stream(lnx_plan* p, int on);
 /* indices of the parameters whose gradient is final after `segment`; returns their count.  The metadata heads' backward
  * runs on the plan's side stream and is joined one segment after the one that forks it, so the stage-4 heads report
  * segment 1 and the stage-3 heads segment 2 (a caller that stops early must run the following segment, or -1, to join). */

@@ -132,7 +132,7 @@ EXPORTS = [
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_bwd_ws_floats",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",
-    "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end", "lnx_plan_profile_begin_spans", "lnx_plan_profile_end_ex",
+    "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end", "lnx_plan_profile_begin_spans", "lnx_plan_profile_end_ex", "lnx_plan_set_wgrad_stream",
 ]
 
 

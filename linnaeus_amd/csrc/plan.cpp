@@ -152,6 +152,14 @@ struct lnx_plan {
     // backward (backward) instead of serialising ~100 small launches on the main stream
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_meta = nullptr, ev_bfork[2] = {nullptr, nullptr}, ev_bjoin[2] = {nullptr, nullptr};
+    // Weight-gradient stream (round 4; LNX_WGRAD_STREAM=0 / lnx_plan_set_wgrad_stream(p, 0): everything on the launch stream): the
+    // RoPE blocks' four weight-gradient products + their batched reduce, and the fused ConvNeXt blocks' two + the LayerScale step, run on a
+    // stream of their own beside the data-gradient chain / the depthwise backward.  Each product forks behind the kernel that wrote its dY
+    // and is joined before that buffer's next writer; every block ends with a join, so a segment's gradients are complete when it returns.
+    // The kernels do not share CUs (one workgroup per CU by LDS) -- what overlaps is one kernel's ramp and tail with the other's body.
+    hipStream_t wgs = nullptr;
+    bool wgs_on = true;
+    hipEvent_t ev_wf[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wj[4] = {nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
     bool profile = false;
     bool profile_spans = false;  // block-level spans only (classes 8 / 9: whole RoPE / ConvNeXt blocks), no per-launch events
@@ -761,6 +769,14 @@ extern "C" void lnx_plan_destroy(lnx_plan* p) {
             (void)hipEventDestroy(p->ev_bjoin[i]);
         }
     }
+    if (p->wgs) {
+        (void)hipStreamSynchronize(p->wgs);
+        (void)hipStreamDestroy(p->wgs);
+        for (int i = 0; i < 4; ++i) {
+            (void)hipEventDestroy(p->ev_wf[i]);
+            (void)hipEventDestroy(p->ev_wj[i]);
+        }
+    }
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
 }
@@ -852,6 +868,13 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
         for (int i = 0; i < 2; ++i) {
             HIPRUN(hipEventCreateWithFlags(&p->ev_bfork[i], hipEventDisableTiming));
             HIPRUN(hipEventCreateWithFlags(&p->ev_bjoin[i], hipEventDisableTiming));
+        }
+    }
+    if (p->wgs == nullptr && !(getenv("LNX_WGRAD_STREAM") && atoi(getenv("LNX_WGRAD_STREAM")) == 0)) {
+        HIPRUN(hipStreamCreateWithFlags(&p->wgs, hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) {
+            HIPRUN(hipEventCreateWithFlags(&p->ev_wf[i], hipEventDisableTiming));
+            HIPRUN(hipEventCreateWithFlags(&p->ev_wj[i], hipEventDisableTiming));
         }
     }
     HIPRUN(hipMemcpy(p->ws + p->o_descs, d.data(), d.size() * sizeof(lnx_prep_desc), hipMemcpyHostToDevice));
@@ -1370,6 +1393,28 @@ namespace {
 
 // have_dy: the caller's last LayerNorm backward already left this block's MLP-branch dY (DropPath-scaled g in storage
 // type) in sC; on return sC holds the same for block i-1 (written by this block's norm1 backward), if there is one
+// Weight-gradient stream (lnx_plan::wgs): wg_fork(j) = product j may start (its operands are written), wg_done(j) marks its end on that
+// stream, wg_join(j) = the main stream goes on only when product j is done (its dY buffer is about to be overwritten, or the block's
+// gradients are about to count as written).  Without the stream all three do nothing and wg_ctx() is the caller's own context.
+static inline bool wg_on(const lnx_plan* p) { return p->wgs != nullptr && p->wgs_on; }
+Ctx wg_ctx(const Ctx& c) { return Ctx{c.p, wg_on(c.p) ? (void*)c.p->wgs : c.st, c.dt}; }
+int wg_fork(const Ctx& c, int j) {
+    if (!wg_on(c.p)) return 0;
+    HIPRUN(hipEventRecord(c.p->ev_wf[j], (hipStream_t)c.st));
+    HIPRUN(hipStreamWaitEvent(c.p->wgs, c.p->ev_wf[j], 0));
+    return 0;
+}
+int wg_done(const Ctx& c, int j) {
+    if (!wg_on(c.p)) return 0;
+    HIPRUN(hipEventRecord(c.p->ev_wj[j], c.p->wgs));
+    return 0;
+}
+int wg_join(const Ctx& c, int j) {
+    if (!wg_on(c.p)) return 0;
+    HIPRUN(hipStreamWaitEvent((hipStream_t)c.st, c.p->ev_wj[j], 0));
+    return 0;
+}
+
 int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     lnx_plan* p = c.p;
     RopeBlk& k = p->rope[s][i];
@@ -1379,27 +1424,39 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
     Timed span(c, 8, 2.0 * rope_block_flops(B, N, C, hid, heads));
+    const Ctx cw = wg_ctx(c);
+    auto wfork = [&](int j) { return wg_fork(c, j); };
+    auto wdone = [&](int j) { return wg_done(c, j); };
+    auto wjoin = [&](int j) { return wg_join(c, j); };
     // ---- MLP branch ----
     if (!have_dy) RUN(lnx_scale_cast(g, C, IDM, p->drop_ptr(p->drop_mlp[s][i]), N, sC, c.dt, C, M, C, c.st));
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_fc2, p->inv_keep, M, C, c.st));  // through the dropout after fc2
-    RUN(wgrad(c, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid, 0, 0));
+    RUN(wfork(0));
+    RUN(wgrad(cw, M, C, hid, sC, C, c.at<void>(k.act), hid, k.fc2.param, k.fc2b, hid, 0, 0));
+    RUN(wdone(0));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = fp8_rows(p, M, C) ? LNX_ACT_GELU_BWD : LNX_ACT_MUL_AUX; a.aux = c.at<void>(k.hpre); a.ldaux = hid;  // what the forward left in hpre
     // fp8 plans: dY is quantised once, the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
     RUN(linear_dgrad(c, a, k.fc2, true, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
     if (p->dmask) RUN(lnx_dropout_mul(sA, c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));  // through the dropout after the activation
-    RUN(wgrad(c, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C, 0, 1));
+    RUN(wfork(1));
+    RUN(wgrad(cw, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C, 0, 1));
+    RUN(wdone(1));
     a = gemm_base(c, M, C, hid, sA, hid, c.wtptr(k.fc1), k.fc1.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.fc1, false, p->o_h8, p->o_h8s));
+    RUN(wjoin(0));  // norm2 backward overwrites sC
     // norm2 backward adds into g and, in the same pass, writes the attention branch's dY (DropPath-scaled g in storage type)
     Dx2 d2;
     d2.p = sC; d2.rowscale = p->drop_ptr(p->drop_attn[s][i]); d2.rps = N;
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_proj, p->inv_keep, M, C, c.st));  // through proj_drop
-    RUN(wgrad(c, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C, 0, 2));
+    RUN(wfork(2));
+    RUN(wgrad(cw, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C, 0, 2));
+    RUN(wdone(2));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
     RUN(linear_dgrad(c, a, k.proj, true, p->o_a8, p->o_a8s));
+    RUN(wjoin(1));  // the attention backward overwrites sA
     lnx_attn_bwd_args ab;
     memset(&ab, 0, sizeof ab);
     ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
@@ -1413,8 +1470,11 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
         Timed t(c, 3, 14.0 * B * heads * (double)N * N * 64);
         RUN(lnx_attn_bwd(&ab, c.st));
     }
-    RUN(wgrad(c, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C, 0, 3));
-    RUN(lnx_gemm_tn_flush(c.st));  // the four products' partial tiles -> their gradients, one launch
+    RUN(wfork(3));
+    RUN(wgrad(cw, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C, 0, 3));
+    RUN(lnx_gemm_tn_flush(cw.st));  // the four products' partial tiles -> their gradients, one launch
+    RUN(wdone(3));
+    RUN(wjoin(2));  // the qkv data gradient overwrites sC
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
     RUN(gemm_nt_t(c, &a));
     // norm1 backward: g is final for this block; block i-1's MLP-branch dY goes into sC in place of this LN's dy (row-wise
@@ -1424,6 +1484,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
         d1.p = sC; d1.rowscale = p->drop_ptr(p->drop_mlp[s][i - 1]); d1.rps = N;
     }
     RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false, d1));
+    RUN(wjoin(3));  // the next kernel of the main stream may overwrite sA, and the block's gradients count as written from here on
     return 0;
 }
 
@@ -1455,21 +1516,25 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
             RUN(lnx_convmlp_bwd(&f, c.st));
         }
+        const Ctx cw = wg_ctx(c);
+        RUN(wg_fork(c, 0));  // the two pointwise weight gradients (and the LayerScale step behind them) beside the depthwise backward
         if (k.keep_z) {
-            RUN(wgrad(c, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
-            RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
-            RUN(lnx_gemm_tn_flush(c.st));
+            RUN(wgrad(cw, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
+            RUN(wgrad(cw, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
+            RUN(lnx_gemm_tn_flush(cw.st));
         } else {
             // LayerScale gradient without z (include/lnx.h): the pwconv2 weight-gradient product runs on dY = rs g into zeroed scratch S | T,
             // then ONE launch adds gamma S / gamma T to the gradients and reads dgamma = rowdot(W2, S) + b2 T off them
             float* S = c.at<float>(p->o_lsws);
             float* T = S + (int64_t)C * 4 * C;
-            HIPRUN(hipMemsetAsync(S, 0, ((size_t)C * 4 * C + C) * 4, (hipStream_t)c.st));
-            RUN(wgrad_into(c, M, C, 4 * C, sC, C, sB, 4 * C, S, T, 4 * C, 0));
-            RUN(wgrad(c, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
-            RUN(lnx_gemm_tn_flush(c.st));
-            RUN(lnx_layerscale_apply_wgrad(S, T, 4 * C, p->P[k.w2.param], p->P[k.b2], 4 * C, p->P[k.gamma], p->G[k.w2.param], p->G[k.b2], 4 * C, p->G[k.gamma], C, 4 * C, c.st));
+            HIPRUN(hipMemsetAsync(S, 0, ((size_t)C * 4 * C + C) * 4, (hipStream_t)cw.st));
+            RUN(wgrad_into(cw, M, C, 4 * C, sC, C, sB, 4 * C, S, T, 4 * C, 0));
+            RUN(wgrad(cw, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
+            RUN(lnx_gemm_tn_flush(cw.st));
+            RUN(lnx_layerscale_apply_wgrad(S, T, 4 * C, p->P[k.w2.param], p->P[k.b2], 4 * C, p->P[k.gamma], p->G[k.w2.param], p->G[k.b2], 4 * C, p->G[k.gamma], C, 4 * C, cw.st));
         }
+        RUN(wg_done(c, 0));
+        if (!k.fused_ln) RUN(wg_join(c, 0));  // the LayerNorm backward below overwrites sC
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
@@ -1503,6 +1568,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         Timed t(c, 4, (double)M * C * (8 + p->esz));  // bytes: read T dy + fp32 g, write fp32 g
         RUN(lnx_dwconv7_fwd(&d, c.st));
     }
+    RUN(wg_join(c, 0));  // the next block's kernels overwrite sA / sB / sC, and this block's gradients count as written from here on
     return 0;
 }
 
@@ -1759,6 +1825,17 @@ extern "C" int lnx_plan_profile_begin(lnx_plan* p) {
     p->spans.clear();
     p->ev_used = 0;
     return 0;
+}
+
+extern "C" int lnx_plan_set_wgrad_stream(lnx_plan* p, int on) {
+    if (!p || (on != 0 && on != 1)) {
+        lnx_set_error("lnx_plan_set_wgrad_stream: %s", !p ? "null plan" : "on must be 0 or 1");
+        return -1;
+    }
+    const int was = wg_on(p) ? 1 : 0;
+    if (p->wgs) (void)hipStreamSynchronize(p->wgs);  // (every block joins before it returns: nothing is pending unless a call failed half-way)
+    p->wgs_on = on != 0;
+    return was;
 }
 
 extern "C" int lnx_plan_profile_begin_spans(lnx_plan* p) {

@@ -795,6 +795,58 @@ def test_recompute_plan_equals_kept_activations(name, dtype, golden_dir):
     assert not any(k[-1] for k in list(model._plans)[n_plans:])
 
 
+@pytest.mark.parametrize("dtype,B", [("bf16", 64), ("fp32", 24)])
+def test_weight_gradient_stream_changes_no_gradient(dtype, B):
+    """The backward's weight-gradient stream (include/lnx.h lnx_plan_set_wgrad_stream; on by default): sm @224 at the production dispatch,
+    one training step with the stream on and one with everything on the launch stream, same forward.  The products, their split-K
+    partial sums and the order they are added in are the same either way, so every gradient whose reduction order is fixed must be
+    bit-equal (asserted for the RoPE blocks' Linear weights, counted for the rest) -- a missing join (a weight-gradient product
+    reading a dY buffer its next writer already reached) or a block's gradients handed on before its stream finished shows up as a
+    large difference, and twice over two backwards of one forward.  Gradients that accumulate by atomics (sparsely filled
+    weight-gradient tiles, LayerNorm partial sums, the metadata-head chains on their side stream) compare to 1e-5."""
+    from linnaeus_amd import _lib as L
+
+    spec = O.Spec(heads=(("taxa_L10", 1000), ("taxa_L20", 300)), drop_path_rate=0.2)
+    sd = O.seeded_state_dict(O.param_shapes(spec), 41)
+    x, meta = O.seeded_inputs(spec, B, 224, 42)
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    model.train(True)
+    model._inject_drop = _drop_scales(spec, B, 43)
+    xs, ms = x.cuda(), meta.cuda()
+    out = model(xs, ms)
+    loss = O.probe_loss(out)
+    handle = model._active["handle"]
+    was = L.lib().lnx_plan_set_wgrad_stream(handle, 1)
+    assert was == 1, "the weight-gradient stream is on by default"
+    loss.backward(retain_graph=True)
+    g_on = _grads(model)
+    model.zero_grad(set_to_none=True)
+    assert L.lib().lnx_plan_set_wgrad_stream(handle, 0) == 1
+    try:
+        loss.backward(retain_graph=True)
+        g_off = _grads(model)
+        model.zero_grad(set_to_none=True)
+    finally:
+        assert L.lib().lnx_plan_set_wgrad_stream(handle, 1) == 0
+    loss.backward()
+    g_on2 = _grads(model)
+    exact = 0
+    for k in g_off:
+        for g in (g_on[k], g_on2[k]):
+            assert (g - g_off[k]).norm().item() <= 1e-5 * g_off[k].norm().item() + 1e-7, (k, (g - g_off[k]).abs().max().item())
+        same = torch.equal(g_on[k], g_off[k]) and torch.equal(g_on2[k], g_off[k])
+        exact += same
+        # the RoPE blocks' Linear weights: well-filled split-K tiles through the workspace, summed in split order by the batched reduce
+        if k.startswith("stages.2.") and k.endswith((".qkv.weight", ".proj.weight", ".fc1.weight", ".fc2.weight")):
+            assert same, (k, (g_on[k] - g_off[k]).abs().max().item())
+    assert exact >= len(g_off) // 2, (exact, len(g_off))
+    assert L.lib().lnx_plan_set_wgrad_stream(handle, 2) < 0  # rejected, setting unchanged
+    assert L.lib().lnx_plan_set_wgrad_stream(handle, 1) == 1
+
+
 def test_recompute_sm_b24_production_dispatch_and_config_flag():
     """The recompute plan at the production dispatch (sm@224, B = 24, bf16, DropPath on), selected the way the reference's
     train loop selects it (TRAIN.GRADIENT_CHECKPOINTING.ENABLED_NORMAL_STEPS / model.use_checkpoint, train.py:93-110),

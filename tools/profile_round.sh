@@ -7,6 +7,10 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
 mkdir -p $O
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0"
+# the step as it is timed: weight-gradient products on their own stream beside the data-gradient chain (kernel durations overlap)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o r -- python3 $R/bench.py $ARGS > $O/trace_overlap.log 2>&1 &&
+# every kernel alone on the chip (what bench.py's roofline object times; the PMC passes serialise the kernels anyway)
+export LNX_WGRAD_STREAM=0 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o r -- python3 $R/bench.py $ARGS > $O/trace.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o r -- python3 $R/bench.py $ARGS > $O/fetch.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o r -- python3 $R/bench.py $ARGS > $O/write.log 2>&1 &&
@@ -15,5 +19,5 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o r -
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o r -- python3 $R/bench.py $ARGS > $O/mfma.log 2>&1
 echo rc=$?
 rm -f $O/mfma/r_kernel_trace.csv.keep; cp $O/mfma/r_kernel_trace.csv $O/mfma_kernel_trace.csv 2>/dev/null
-rm -f $O/trace/r_kernel_trace.csv  # large; the stats file is what is kept
+rm -f $O/trace/r_kernel_trace.csv $O/trace_overlap/r_kernel_trace.csv  # large; the stats files are what is kept
 ls -la $O/*

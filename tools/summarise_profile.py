@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_round/ (tools/profile_round.sh) into the summaries committed under profiles/.
 
-  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per kernel: calls, total, average)
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per kernel: calls, total, average), LNX_WGRAD_STREAM=0: each kernel alone
+  profiles/<tag>_overlap_kernel_stats.csv   the same of the default run (weight-gradient stream on: durations of kernels that ran side by side overlap)
   profiles/<tag>_hbm_traffic.csv    per kernel: launches/step, HBM read and write bytes per launch from the PMC passes
                                     (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B; WRITE_SIZE as read;
                                     both counters are in KiB -- MI355X_MICROARCH.md, HBM section)
@@ -23,6 +24,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_round")
 dst = os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, "trace", "r_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "trace_overlap", "r_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "trace_overlap", "r_kernel_stats.csv"), os.path.join(dst, f"{tag}_overlap_kernel_stats.csv"))
 
 
 def short(name):
