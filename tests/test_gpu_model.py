@@ -839,10 +839,11 @@ def test_weight_gradient_stream_changes_no_gradient(dtype, B):
             assert (g - g_off[k]).norm().item() <= 1e-5 * g_off[k].norm().item() + 1e-7, (k, (g - g_off[k]).abs().max().item())
         same = torch.equal(g_on[k], g_off[k]) and torch.equal(g_on2[k], g_off[k])
         exact += same
-        # the RoPE blocks' Linear weights: well-filled split-K tiles through the workspace, summed in split order by the batched reduce
-        if k.startswith("stages.2.") and k.endswith((".qkv.weight", ".proj.weight", ".fc1.weight", ".fc2.weight")):
+        # the RoPE blocks' Linear weights in bf16: well-filled split-K tiles through the workspace, summed in split order by the batched
+        # reduce (the fp32 plans' weight-gradient kernel adds its splits by atomics: order not fixed, 5e-10 apart)
+        if dtype == "bf16" and k.startswith("stages.2.") and k.endswith((".qkv.weight", ".proj.weight", ".fc1.weight", ".fc2.weight")):
             assert same, (k, (g_on[k] - g_off[k]).abs().max().item())
-    assert exact >= len(g_off) // 2, (exact, len(g_off))
+    assert dtype != "bf16" or exact >= len(g_off) // 2, (exact, len(g_off))
     assert L.lib().lnx_plan_set_wgrad_stream(handle, 2) < 0  # rejected, setting unchanged
     assert L.lib().lnx_plan_set_wgrad_stream(handle, 1) == 1
 
