@@ -225,12 +225,6 @@ typedef struct lnx_ln_bwd_args {
     int64_t lddx2;
     const float* dx2_rowscale;
     int dx2_rows_per_sample;
-    /* round 4, optional (both or neither; needs ws): the second stage of the dw / db reduction -- a few-microsecond kernel that only the
-     * gradients wait for -- is launched on `reduce_stream` (a hipStream_t) behind `reduce_event` (a hipEvent_t of the caller, recorded by
-     * this call on `stream` right after the main kernel), instead of on `stream` in front of the caller's next kernel.  The caller orders
-     * the reduce before the next writer of ws and before it reads dw / db (lnx_plan: its weight-gradient stream and that stream's joins). */
-    void* reduce_stream;
-    void* reduce_event;
 } lnx_ln_bwd_args;
 int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
 

@@ -477,7 +477,7 @@ void launch_fwd(const LnP& p, hipStream_t st) {
 constexpr int LN_WS_WGS = 2048;  // workgroups the partial-sum workspace is sized for
 
 template <typename TDY, typename TX, typename TDX>
-void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats, hipStream_t rst, hipEvent_t rev) {
+void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats) {
     int G, V;
     pick_gv(p.C, G, V);
     const int rows_per_wg = 4 * (64 / G);
@@ -523,9 +523,7 @@ void launch_bwd(LnBwdP p, hipStream_t st, int64_t ws_floats, hipStream_t rst, hi
     else { if (p.C / 4 == 64 * 3) hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3, 1, true>), g, b, 0, st, p); else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX, TDX, 64, 3, 1, false>), g, b, 0, st, p); }
     if (p.part) {
         const int slices = grid >= 64 ? 64 : 1;
-        hipStream_t rs = st;
-        if (rst && rev && hipEventRecord(rev, st) == hipSuccess && hipStreamWaitEvent(rst, rev, 0) == hipSuccess) rs = rst;  // (lnx_ln_bwd_args.reduce_stream)
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * p.C, 256), slices), dim3(256), 0, rs, p.part, grid, p.C, p.dw, p.db);
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(2 * p.C, 256), slices), dim3(256), 0, st, p.part, grid, p.C, p.dw, p.db);
     }
 }
 
@@ -578,20 +576,16 @@ extern "C" int lnx_layernorm_bwd(const lnx_ln_bwd_args* a, void* stream) {
     p.part = a->ws;
     const int64_t wsf = a->ws ? a->ws_floats : 0;
     hipStream_t st = (hipStream_t)stream;
-    LNX_CHECK((a->reduce_stream == nullptr) == (a->reduce_event == nullptr), "lnx_layernorm_bwd: reduce_stream and reduce_event go together");
-    LNX_CHECK(a->reduce_stream == nullptr || a->ws != nullptr, "lnx_layernorm_bwd: reduce_stream needs the ws scratch (without it there is no second stage)");
-    hipStream_t rst = (hipStream_t)a->reduce_stream;
-    hipEvent_t rev = (hipEvent_t)a->reduce_event;
     const int code = a->dy_dtype * 4 + a->x_dtype * 2 + a->dx_dtype;
     switch (code) {
-        case 0: launch_bwd<float, float, float>(p, st, wsf, rst, rev); break;
-        case 1: launch_bwd<float, float, bf16_t>(p, st, wsf, rst, rev); break;
-        case 2: launch_bwd<float, bf16_t, float>(p, st, wsf, rst, rev); break;
-        case 3: launch_bwd<float, bf16_t, bf16_t>(p, st, wsf, rst, rev); break;
-        case 4: launch_bwd<bf16_t, float, float>(p, st, wsf, rst, rev); break;
-        case 5: launch_bwd<bf16_t, float, bf16_t>(p, st, wsf, rst, rev); break;
-        case 6: launch_bwd<bf16_t, bf16_t, float>(p, st, wsf, rst, rev); break;
-        case 7: launch_bwd<bf16_t, bf16_t, bf16_t>(p, st, wsf, rst, rev); break;
+        case 0: launch_bwd<float, float, float>(p, st, wsf); break;
+        case 1: launch_bwd<float, float, bf16_t>(p, st, wsf); break;
+        case 2: launch_bwd<float, bf16_t, float>(p, st, wsf); break;
+        case 3: launch_bwd<float, bf16_t, bf16_t>(p, st, wsf); break;
+        case 4: launch_bwd<bf16_t, float, float>(p, st, wsf); break;
+        case 5: launch_bwd<bf16_t, float, bf16_t>(p, st, wsf); break;
+        case 6: launch_bwd<bf16_t, bf16_t, float>(p, st, wsf); break;
+        case 7: launch_bwd<bf16_t, bf16_t, bf16_t>(p, st, wsf); break;
         default: LNX_CHECK(false, "lnx_layernorm_bwd: bad dtypes");
     }
     LNX_LAUNCH_CHECK();

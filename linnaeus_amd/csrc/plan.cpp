@@ -160,7 +160,6 @@ struct lnx_plan {
     hipStream_t wgs = nullptr;
     bool wgs_on = true;
     hipEvent_t ev_wf[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wj[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_ln = nullptr;  // hand-over of a RoPE-block LayerNorm backward's column-sum reduce to that stream (lnx_ln_bwd_args.reduce_event)
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
     bool profile = false;
     bool profile_spans = false;  // block-level spans only (classes 8 / 9: whole RoPE / ConvNeXt blocks), no per-launch events
@@ -777,7 +776,6 @@ extern "C" void lnx_plan_destroy(lnx_plan* p) {
             (void)hipEventDestroy(p->ev_wf[i]);
             (void)hipEventDestroy(p->ev_wj[i]);
         }
-        (void)hipEventDestroy(p->ev_ln);
     }
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
@@ -878,7 +876,6 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
             HIPRUN(hipEventCreateWithFlags(&p->ev_wf[i], hipEventDisableTiming));
             HIPRUN(hipEventCreateWithFlags(&p->ev_wj[i], hipEventDisableTiming));
         }
-        HIPRUN(hipEventCreateWithFlags(&p->ev_ln, hipEventDisableTiming));
     }
     HIPRUN(hipMemcpy(p->ws + p->o_descs, d.data(), d.size() * sizeof(lnx_prep_desc), hipMemcpyHostToDevice));
     HIPRUN(hipDeviceSynchronize());
@@ -983,10 +980,8 @@ struct Dx2 {
     const float* rowscale = nullptr;
     int rps = 0;
 };
-// reduce_on_wgs: the dw / db second stage goes to the plan's weight-gradient stream (the caller joins that stream before the scratch's
-// next writer and at the end of its block)
 int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, lnx_rowmap dym, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi,
-           int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu, Dx2 d2 = Dx2(), bool reduce_on_wgs = false) {
+           int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu, Dx2 d2 = Dx2()) {
     lnx_ln_bwd_args a;
     memset(&a, 0, sizeof a);
     a.dx2 = d2.p; a.dx2_dtype = c.dt; a.lddx2 = C; a.dx2_rowscale = d2.rowscale; a.dx2_rows_per_sample = d2.rps;
@@ -1002,10 +997,6 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     const bool on_side = c.p->side != nullptr && c.st == (void*)c.p->side;
     a.ws = c.at<float>(on_side ? c.p->o_lnws_side : c.p->o_lnws);
     a.ws_floats = on_side ? c.p->lnws_side_floats : c.p->lnws_floats;
-    if (reduce_on_wgs && !on_side && c.p->wgs != nullptr && c.p->wgs_on && a.ws_floats >= 2 * (int64_t)C) {
-        a.reduce_stream = (void*)c.p->wgs;
-        a.reduce_event = (void*)c.p->ev_ln;
-    }
     return lnx_layernorm_bwd(&a, c.st);
 }
 
@@ -1457,8 +1448,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     // norm2 backward adds into g and, in the same pass, writes the attention branch's dY (DropPath-scaled g in storage type)
     Dx2 d2;
     d2.p = sC; d2.rowscale = p->drop_ptr(p->drop_attn[s][i]); d2.rps = N;
-    // (its column-sum reduce goes to the weight-gradient stream: done before norm1's backward reuses the scratch -- wjoin(2) -- and the block ends)
-    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2, true));
+    RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_proj, p->inv_keep, M, C, c.st));  // through proj_drop
     RUN(wfork(2));
@@ -1483,6 +1473,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     RUN(wfork(3));
     RUN(wgrad(cw, M, 3 * C, C, sA, 3 * C, c.at<void>(k.n1), C, k.qkv.param, k.qkvb, C, 0, 3));
     RUN(lnx_gemm_tn_flush(cw.st));  // the four products' partial tiles -> their gradients, one launch
+    RUN(wdone(3));
     RUN(wjoin(2));  // the qkv data gradient overwrites sC
     a = gemm_base(c, M, C, 3 * C, sA, 3 * C, c.wtptr(k.qkv), k.qkv.ld_t, sC, C, false);
     RUN(gemm_nt_t(c, &a));
@@ -1492,9 +1483,8 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     if (i > 0) {
         d1.p = sC; d1.rowscale = p->drop_ptr(p->drop_mlp[s][i - 1]); d1.rps = N;
     }
-    RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false, d1, true));
-    RUN(wdone(3));  // behind everything this block put on the weight-gradient stream: the qkv product, the batched reduce, both LayerNorm reduces
-    RUN(wjoin(3));  // the next kernel of the main stream may overwrite sA / the LayerNorm scratch, and the block's gradients count as written from here on
+    RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false, d1));
+    RUN(wjoin(3));  // the next kernel of the main stream may overwrite sA, and the block's gradients count as written from here on
     return 0;
 }
 
@@ -1597,19 +1587,15 @@ int downsample_bwd(const Ctx& c, int i, const float* gout, int64_t ldg, lnx_rowm
     w.dtype = c.dt; w.M = Mout; w.N = Cout; w.K = 4 * Cin;
     w.dY = sC; w.lddy = Cout; w.A = c.at<void>(d.ln); w.a_mode = LNX_ADDR_PATCH2; w.Hin = Hin; w.Win = Win; w.Cin = Cin;
     w.dW = p->G[d.w.param]; w.lddw = 4 * Cin; w.k_perm_c = Cin; w.db = p->G[d.cb];
-    w.ws = c.at<float>(p->o_tnws); w.ws_floats = LNX_TN_WS_FLOATS;  // split-K partials through the workspace + reduce kernel, not by atomics
-    const Ctx cw = wg_ctx(c);  // ... beside the data gradient and the LayerNorm backward below; joined before sC's next writer (the caller's next block)
-    RUN(wg_fork(c, 0));
+    w.ws = c.at<float>(p->o_tnws); w.ws_floats = LNX_TN_WS_FLOATS;  // split-K partials through the workspace + reduce kernel, not by atomics (main stream only)
     {
-        Timed t(cw, 1, 2.0 * Mout * Cout * 4 * Cin);
-        RUN(lnx_gemm_tn(&w, cw.st));
+        Timed t(c, 1, 2.0 * Mout * Cout * 4 * Cin);
+        RUN(lnx_gemm_tn(&w, c.st));
     }
-    RUN(wg_done(c, 0));
     lnx_gemm_args a = gemm_base(c, Mout, 4 * Cin, Cout, sC, Cout, c.wtptr(d.w), d.w.ld_t, sA, 0, false);
     a.c_mode = LNX_ADDR_PATCH2; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
     RUN(gemm_nt_t(c, &a));
     RUN(ln_bwd(c, Min, Cin, sA, c.dt, Cin, IDM, x, xdt, ldx, xm, d.lnw, d.lnb, c.at<float>(d.mean), c.at<float>(d.rstd), nullptr, dx, dxdt, lddx, false));
-    RUN(wg_join(c, 0));
     return 0;
 }
 
