@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -757,11 +758,25 @@ extern "C" int lnx_plan_set_dropout(lnx_plan* p, const unsigned char* masks, flo
     return 0;
 }
 
+// The plans' two extra streams (metadata-head chains; weight-gradient products) exist ONCE per device and process, shared by every plan:
+// plans run one after the other on their caller's stream and join everything they forked before they return, and a process with several
+// plans (train + eval, bench.py's two legs, one per batch size) would otherwise hold two more streams per plan -- measured with a second plan
+// alive: its 256-image step 20.9 ms instead of 19.6 (more streams than hardware queues: a forked stream then shares a queue with the stream it
+// forked from and the two serialise, with the fork / join packets on top).  Never destroyed (two streams per device for the process's life).
+static hipStream_t shared_stream(int which) {
+    static std::mutex mu;
+    static hipStream_t tab[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tab[which][dev] && hipStreamCreateWithFlags(&tab[which][dev], hipStreamNonBlocking) != hipSuccess) tab[which][dev] = nullptr;
+    return tab[which][dev];
+}
+
 extern "C" void lnx_plan_destroy(lnx_plan* p) {
     if (!p) return;
     if (p->side) {
-        (void)hipStreamSynchronize(p->side);
-        (void)hipStreamDestroy(p->side);
+        (void)hipStreamSynchronize(p->side);  // (shared_stream: not destroyed)
         (void)hipEventDestroy(p->ev_fork);
         (void)hipEventDestroy(p->ev_meta);
         for (int i = 0; i < 2; ++i) {
@@ -770,8 +785,7 @@ extern "C" void lnx_plan_destroy(lnx_plan* p) {
         }
     }
     if (p->wgs) {
-        (void)hipStreamSynchronize(p->wgs);
-        (void)hipStreamDestroy(p->wgs);
+        (void)hipStreamSynchronize(p->wgs);  // (shared_stream: not destroyed)
         for (int i = 0; i < 4; ++i) {
             (void)hipEventDestroy(p->ev_wf[i]);
             (void)hipEventDestroy(p->ev_wj[i]);
@@ -862,7 +876,8 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
     p->n_descs_f = (int64_t)d.size() - p->n_descs_t;
     p->prep_blocks_f = blk;
     if (p->side == nullptr && p->c.n_meta > 0 && getenv("LNX_NO_SIDE_STREAM") == nullptr) {
-        HIPRUN(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+        p->side = shared_stream(0);
+        if (!p->side) FAIL("lnx_plan: no side stream");
         HIPRUN(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
         HIPRUN(hipEventCreateWithFlags(&p->ev_meta, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) {
@@ -871,7 +886,8 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
         }
     }
     if (p->wgs == nullptr && !(getenv("LNX_WGRAD_STREAM") && atoi(getenv("LNX_WGRAD_STREAM")) == 0)) {
-        HIPRUN(hipStreamCreateWithFlags(&p->wgs, hipStreamNonBlocking));
+        p->wgs = shared_stream(1);
+        if (!p->wgs) FAIL("lnx_plan: no weight-gradient stream");
         for (int i = 0; i < 4; ++i) {
             HIPRUN(hipEventCreateWithFlags(&p->ev_wf[i], hipEventDisableTiming));
             HIPRUN(hipEventCreateWithFlags(&p->ev_wj[i], hipEventDisableTiming));
