@@ -225,6 +225,13 @@ typedef struct lnx_ln_bwd_args {
     int64_t lddx2;
     const float* dx2_rowscale;
     int dx2_rows_per_sample;
+    /* round 4, optional (fp8 plans with MXFP8 data gradients): the MXFP8 copy of dx2 -- e4m3 elements [M, C] with leading dimension
+     * lddx2_8 (bytes = elements) and E8M0 block scales in lnx_quantize_mxfp8's layout for an [M, C] operand -- bit-identical to
+     * lnx_quantize_mxfp8 of the bf16 dx2, written by the same pass, so the next branch's data-gradient product needs no quantise pass
+     * over its dY.  Needs dx2 in bf16, x in fp32, C % 128 == 0, 4-byte aligned rows. */
+    void* dx2_8;
+    void* dx2_8_scales;
+    int64_t lddx2_8;
 } lnx_ln_bwd_args;
 int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
 

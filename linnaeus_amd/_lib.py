@@ -159,6 +159,7 @@ class LnBwdArgs(C.Structure):
         ("dw", C.c_void_p), ("db", C.c_void_p), ("relu_mask", C.c_int),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("dx2", C.c_void_p), ("dx2_dtype", C.c_int), ("lddx2", C.c_int64), ("dx2_rowscale", C.c_void_p), ("dx2_rows_per_sample", C.c_int),
+        ("dx2_8", C.c_void_p), ("dx2_8_scales", C.c_void_p), ("lddx2_8", C.c_int64),
     ]
 
 

@@ -223,6 +223,9 @@ struct LnBwdP {
     const float* rs2;
     int64_t lddx2;
     int rps2, dx2_f32;
+    unsigned char* dx2_8;   // optional MXFP8 copy of the bf16 dx2 (lnx_ln_bwd_args.dx2_8): elements, E8M0 block scales
+    unsigned char* dx2_8s;
+    int64_t lddx2_8;
 };
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w,  xhat = (x - mean) * rstd
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
 #pragma unroll
         for (int i = 0; i < V; i += PAIR) {
             const int c4 = col[i] >> 2;
+            float4 q8 = make_float4(0.f, 0.f, 0.f, 0.f);  // the bf16-rounded dx2 values of this slot (MXFP8 copy; zeros beyond the row)
             if (ok[i]) {
                 float4 ov[PAIR];
 #pragma unroll
@@ -332,6 +336,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdP p) {
                         bf16_t* o2 = reinterpret_cast<bf16_t*>(p.dx2) + (int64_t)m * p.lddx2 + 4 * c4;
                         if constexpr (PAIR == 2) store4x2<bf16_t>(o2, ov[0], ov[1]);
                         else store4<bf16_t>(o2, ov[0]);
+                        q8 = make_float4((float)(bf16_t)ov[0].x, (float)(bf16_t)ov[0].y, (float)(bf16_t)ov[0].z, (float)(bf16_t)ov[0].w);
+                    }
+                }
+            }
+            if constexpr (PAIR == 1 && G % 8 == 0) {
+                if (p.dx2_8) {  // kernel-uniform.  ln_fwd_kernel's MX block on the stored (rounded) values: 8 consecutive lanes = one 32-element block
+                    const float am = max8(fmaxf(fmaxf(fabsf(q8.x), fabsf(q8.y)), fmaxf(fabsf(q8.z), fabsf(q8.w))));
+                    const uint32_t bits = __float_as_uint(am);
+                    int e = (int)(bits >> 23) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+                    e = e < 0 ? 0 : (e > 254 ? 254 : e);
+                    const float inv = __uint_as_float((uint32_t)(254 - e) << 23);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(q8.x * inv, -448.f), 448.f), fminf(fmaxf(q8.y * inv, -448.f), 448.f), 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(q8.z * inv, -448.f), 448.f), fminf(fmaxf(q8.w * inv, -448.f), 448.f), pk, true);
+                    if (ok[i]) {
+                        *reinterpret_cast<int*>(p.dx2_8 + (int64_t)m * p.lddx2_8 + col[i]) = pk;
+                        const int kb = col[i] >> 5;
+                        if ((sub & 7) == 0) p.dx2_8s[((int64_t)(kb >> 2) * p.M + m) * 4 + (kb & 3)] = (unsigned char)e;
                     }
                 }
             }
@@ -572,6 +593,13 @@ extern "C" int lnx_layernorm_bwd(const lnx_ln_bwd_args* a, void* stream) {
         LNX_CHECK(a->lddx2 % 4 == 0 && (a->dx2_dtype == LNX_F32 || a->dx2_dtype == LNX_BF16), "lnx_layernorm_bwd: bad dx2 layout");
         LNX_CHECK(a->dx2_dtype == LNX_F32 || ((uintptr_t)a->dx2 % 16 == 0 && (a->lddx2 * 2) % 16 == 0), "lnx_layernorm_bwd: dx2 must be 16-byte aligned");
         if (a->dx2_rowscale) LNX_CHECK(a->dx2_rows_per_sample > 0, "lnx_layernorm_bwd: dx2_rowscale needs dx2_rows_per_sample");
+    }
+    p.dx2_8 = nullptr; p.dx2_8s = nullptr; p.lddx2_8 = 0;
+    if (a->dx2_8) {
+        LNX_CHECK(a->dx2 && a->dx2_dtype == LNX_BF16 && a->dx2_8_scales && a->x_dtype == LNX_F32 && a->C % 128 == 0 && a->lddx2_8 % 4 == 0 &&
+                      (((uintptr_t)a->dx2_8) & 3) == 0,
+                  "lnx_layernorm_bwd: the MXFP8 copy of dx2 needs dx2 in bf16, x in fp32, C %% 128 == 0 and 4-byte aligned rows");
+        p.dx2_8 = (unsigned char*)a->dx2_8; p.dx2_8s = (unsigned char*)a->dx2_8_scales; p.lddx2_8 = a->lddx2_8;
     }
     p.part = a->ws;
     const int64_t wsf = a->ws ? a->ws_floats : 0;

@@ -160,6 +160,7 @@ struct lnx_plan {
     // The kernels do not share CUs (one workgroup per CU by LDS) -- what overlaps is one kernel's ramp and tail with the other's body.
     hipStream_t wgs = nullptr;
     bool wgs_on = true;
+    bool dy8_ready = false;  // backward, fp8 plans: o_a8 / o_a8s hold the MXFP8 copy of the dY in sC (written by the LayerNorm backward that wrote sC)
     hipEvent_t ev_wf[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wj[4] = {nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
     bool profile = false;
@@ -995,12 +996,17 @@ struct Dx2 {
     void* p = nullptr;
     const float* rowscale = nullptr;
     int rps = 0;
+    void* p8 = nullptr;   // fp8 plans with MXFP8 data gradients: the MXFP8 copy of p (elements, block scales), written by the same pass
+    void* p8s = nullptr;
 };
 int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, lnx_rowmap dym, const void* x, int xdt, int64_t ldx, lnx_rowmap xm, int wi,
            int bi, const float* mean, const float* rstd, const float* gin, void* dx, int dxdt, int64_t lddx, bool relu, Dx2 d2 = Dx2()) {
     lnx_ln_bwd_args a;
     memset(&a, 0, sizeof a);
     a.dx2 = d2.p; a.dx2_dtype = c.dt; a.lddx2 = C; a.dx2_rowscale = d2.rowscale; a.dx2_rows_per_sample = d2.rps;
+    if (d2.p && d2.p8) {
+        a.dx2_8 = d2.p8; a.dx2_8_scales = d2.p8s; a.lddx2_8 = C;
+    }
     a.M = M; a.C = C;
     a.dy = dy; a.dy_dtype = dydt; a.lddy = lddy; a.dy_map = dym;
     a.x = x; a.x_dtype = xdt; a.ldx = ldx; a.x_map = xm;
@@ -1452,8 +1458,12 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     RUN(wdone(0));
     lnx_gemm_args a = gemm_base(c, M, hid, C, sC, C, c.wtptr(k.fc2), k.fc2.ld_t, sA, hid, false);
     a.act = fp8_rows(p, M, C) ? LNX_ACT_GELU_BWD : LNX_ACT_MUL_AUX; a.aux = c.at<void>(k.hpre); a.ldaux = hid;  // what the forward left in hpre
-    // fp8 plans: dY is quantised once, the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
-    RUN(linear_dgrad(c, a, k.fc2, true, p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
+    // fp8 plans: dY comes in MXFP8 from the LayerNorm backward that wrote it (the block above's norm1 backward; quantised here when
+    // there was none, or a dropout mask went over it since), the GELU' epilogue hands dH on in MXFP8 as well as in bf16 (the weight gradients read bf16)
+    const bool qpass = getenv("LNX_FP8_DGRAD_QPASS") != nullptr;  // A/B switch (read per call: the tests flip it): separate quantise passes over dY
+    const bool mx_dgrad = c.dt == LNX_BF16 && fp8_rows(p, M, C) && k.fc2.off8ts != 0 && k.proj.off8ts != 0 && !p->dmask && C % 128 == 0 && !qpass;
+    RUN(linear_dgrad(c, a, k.fc2, !(have_dy && p->dy8_ready), p->o_a8, p->o_a8s, p->o_h8, p->o_h8s));
+    p->dy8_ready = false;
     if (p->dmask) RUN(lnx_dropout_mul(sA, c.dt, p->dmask + k.dm_hid, p->inv_keep, M, hid, c.st));  // through the dropout after the activation
     RUN(wfork(1));
     RUN(wgrad(cw, M, hid, C, sA, hid, c.at<void>(k.n2), C, k.fc1.param, k.fc1b, C, 0, 1));
@@ -1464,6 +1474,9 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     // norm2 backward adds into g and, in the same pass, writes the attention branch's dY (DropPath-scaled g in storage type)
     Dx2 d2;
     d2.p = sC; d2.rowscale = p->drop_ptr(p->drop_attn[s][i]); d2.rps = N;
+    if (mx_dgrad) {
+        d2.p8 = c.at<void>(p->o_a8); d2.p8s = c.at<void>(p->o_a8s);
+    }
     RUN(ln_bwd(c, M, C, sD, c.dt, C, IDM, c.at<float>(k.xmid), LNX_F32, C, IDM, k.n2w, k.n2b, c.at<float>(k.mean2), c.at<float>(k.rstd2), g, g, LNX_F32, C, false, d2));
     // ---- attention branch ----
     if (p->dmask) RUN(lnx_dropout_mul(sC, c.dt, p->dmask + k.dm_proj, p->inv_keep, M, C, c.st));  // through proj_drop
@@ -1471,7 +1484,7 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     RUN(wgrad(cw, M, C, C, sC, C, c.at<void>(k.o), C, k.proj.param, k.projb, C, 0, 2));
     RUN(wdone(2));
     a = gemm_base(c, M, C, C, sC, C, c.wtptr(k.proj), k.proj.ld_t, sD, C, false);
-    RUN(linear_dgrad(c, a, k.proj, true, p->o_a8, p->o_a8s));
+    RUN(linear_dgrad(c, a, k.proj, !mx_dgrad, p->o_a8, p->o_a8s));
     RUN(wjoin(1));  // the attention backward overwrites sA
     lnx_attn_bwd_args ab;
     memset(&ab, 0, sizeof ab);
@@ -1498,6 +1511,10 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     Dx2 d1;
     if (i > 0) {
         d1.p = sC; d1.rowscale = p->drop_ptr(p->drop_mlp[s][i - 1]); d1.rps = N;
+        if (mx_dgrad) {  // block i - 1's fc2 data gradient reads it (same stage, same shapes: its own mx_dgrad is this one)
+            d1.p8 = c.at<void>(p->o_a8); d1.p8s = c.at<void>(p->o_a8s);
+            p->dy8_ready = true;
+        }
     }
     RUN(ln_bwd(c, M, C, sC, c.dt, C, IDM, c.at<float>(k.xin), LNX_F32, C, IDM, k.n1w, k.n1b, c.at<float>(k.mean1), c.at<float>(k.rstd1), g, g, LNX_F32, C, false, d1));
     RUN(wjoin(3));  // the next kernel of the main stream may overwrite sA, and the block's gradients count as written from here on
@@ -1673,6 +1690,7 @@ int rope_block_restore(const Ctx& c, int s, int i) {
     if (!p->c.recompute || p->resident[2 + s] == i) return 0;
     const int nb = p->c.rope_depths[s];
     float* xout = i + 1 < nb ? c.at<float>(p->rope[s][i + 1].xin) : c.at<float>(p->o_stage_out[2 + s]);
+    p->dy8_ready = false;  // (the re-forward's LayerNorms write their MXFP8 activation copies into the same scratch)
     return rope_block_fwd(c, s, i, xout);
 }
 
@@ -1690,6 +1708,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     if (!p->fwd_done) FAIL("lnx_plan_backward: no forward to differentiate");
     if (segment < -1 || segment > 3) FAIL("lnx_plan_backward: bad segment %d", segment);
     const lnx_mformer_cfg& cf = p->c;
+    if (segment <= 0) p->dy8_ready = false;
     Ctx c{p, stream, cf.dtype};
     hipStream_t st = (hipStream_t)stream;
     const int B = cf.batch;

@@ -700,6 +700,48 @@ def test_layernorm_fused_mxfp8_output(M, C):
     torch.testing.assert_close(mean, x.mean(-1), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,C,rps", [(1000, 384, 50), (777, 768, 7), (300, 1024, 100), (513, 2048, 53), (64, 128, 64), (130, 1536, 13), (2001, 1280, 200)])
+def test_layernorm_bwd_second_output_and_its_mxfp8_copy(M, C, rps):
+    """LayerNorm backward with the second output (dx2 = DropPath scale of the row's sample x dx in bf16: the dY the next branch's GEMMs read)
+    and, round 4, its MXFP8 copy for fp8 plans' data-gradient products: dx and the column sums are what they are without the second
+    output, dx2 equals the scaled dx rounded to bf16, and the fp8 bytes / block scales equal lnx_quantize_mxfp8 of that bf16 tensor exactly
+    (every LayerNorm width of the RoPE stages: G = 32 / 64 lanes per row with 3, 4, 6 or 8 slots, a partly filled last slot at C = 1280)."""
+    gen = g(M * 3 + C)
+    x = (torch.randn(M, C, generator=gen) * 2 + 0.5).cuda()
+    dy = (torch.randn(M, C, generator=gen) * torch.exp2(torch.randint(-6, 3, (M, 1), generator=gen).float())).cuda().bfloat16()
+    w = (torch.rand(C, generator=gen) + 0.5).cuda()
+    gin = torch.randn(M, C, generator=gen).cuda()
+    rs = ((torch.rand(-(-M // rps), generator=gen) > 0.2).float() / 0.8).cuda()
+    mean = x.mean(-1)
+    rstd = (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    ws = torch.empty(2048 * 2 * C, device="cuda")
+    dx0, dw0, db0 = torch.empty(M, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx0, gin=gin, dw=dw0, db=db0, ws=ws)
+    dx1, dw1, db1 = torch.empty(M, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    d2 = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    d8 = torch.zeros(M, C, device="cuda", dtype=torch.uint8)
+    sc = torch.zeros(C // 128, M, 4, device="cuda", dtype=torch.uint8)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx1, gin=gin, dw=dw1, db=db1, ws=ws, dx2=d2, dx2_rowscale=rs, dx2_rows_per_sample=rps, dx2_8=d8, dx2_8_scales=sc)
+    assert torch.equal(dx0, dx1)
+    torch.testing.assert_close(dw1, dw0, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-4)
+    want = (dx1 * rs.repeat_interleave(rps)[:M, None]).bfloat16()
+    assert torch.equal(d2, want)
+    r8, rsc = ops.quantize_mxfp8(d2)
+    assert torch.equal(sc, rsc)
+    assert torch.equal(d8, r8.view(torch.uint8))
+    # the plain second output without the copy is the same tensor
+    d2b = torch.empty_like(d2)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx1, gin=gin, ws=ws, dx2=d2b, dx2_rowscale=rs, dx2_rows_per_sample=rps)
+    assert torch.equal(d2b, d2)
+    # C % 128 != 0 is refused with the copy, accepted without
+    if C == 384:
+        xs, dys = x[:, :96].contiguous(), dy[:, :96].contiguous()
+        with pytest.raises(L.LnxError, match="MXFP8 copy"):
+            ops.layernorm_bwd(dys, xs, w[:96].contiguous(), mean, rstd, torch.empty(M, 96, device="cuda"), dx2=torch.empty(M, 96, device="cuda", dtype=torch.bfloat16),
+                              dx2_8=d8, dx2_8_scales=sc)
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout", [(3, 3, 56, 72, 96), (2, 3, 32, 32, 192), (1, 4, 16, 20, 128), (2, 1, 64, 64, 256), (40, 3, 224, 224, 96)])
 def test_fused_stem_matches_conv_and_layernorm(B, Cin, H, W, Cout):
     """lnx_stem_fwd (round 3) against torch: conv2d 4x4/4 on bf16-rounded operands, output rounded to bf16, channels-first
