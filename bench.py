@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--eval-iters", type=int, default=100)
     ap.add_argument("--eval-warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sched-calibration", action="store_true",
+                    help="skip the warm-up comparison of the two backward schedules (weight-gradient stream on / off) and keep the library default (on)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--profile-steps", type=int, default=3)
     return ap.parse_args()
@@ -518,6 +520,36 @@ def main():
         log(f"leg {name}: batch {B}/GPU on {dev}; warm-up {args.warmup} steps")
         for _ in range(args.warmup):
             step()
+        # Backward schedule, chosen during warm-up (untimed): the library's default runs the weight-gradient products on a second stream
+        # beside the data-gradient chain (+1...3 % on one GPU); whether that still pays beside a real collective's streams cannot be
+        # rehearsed on one GPU, so both schedules are timed here over a few steps -- all ranks, the slowest rank counts -- and the
+        # default is kept unless the plain schedule is more than 1 % faster.  Same gradients either way (include/lnx.h).
+        sched = None
+        if not args.no_sched_calibration and os.environ.get("LNX_WGRAD_STREAM") != "0":
+            def few(n=4):
+                step()
+                torch.cuda.synchronize()
+                if dist:
+                    dist.barrier(device_ids=[local])
+                t = time.perf_counter()
+                for _ in range(n):
+                    step()
+                torch.cuda.synchronize()
+                t = (time.perf_counter() - t) / n
+                if dist:
+                    tt = torch.tensor([t], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    t = tt.item()
+                return t
+            model.set_wgrad_stream(True)
+            t_on = few()
+            model.set_wgrad_stream(False)
+            t_off = few()
+            keep_on = t_on <= 1.01 * t_off
+            model.set_wgrad_stream(keep_on)
+            step()
+            sched = {"weight_gradient_stream": "on" if keep_on else "off", "calibration_ms_on": round(t_on * 1e3, 3), "calibration_ms_off": round(t_off * 1e3, 3),
+                     "what": "4 untimed steps each during warm-up, max over ranks; 'on' (the library default) unless 'off' is > 1 % faster"}
         torch.cuda.synchronize()
         if dist:
             dist.barrier(device_ids=[local])
@@ -537,7 +569,7 @@ def main():
             dt = tt.item()
         res = {"name": name, "per_gpu_batch": B, "global_batch": B * world, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "images_per_sec": round(world * B * args.steps / dt, 2), "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-               "loss": round(float(loss.item()), 4), "step": step, "state": state}
+               "loss": round(float(loss.item()), 4), "step": step, "state": state, "backward_schedule": sched}
         log(f"leg {name}: timed {args.steps} steps: {res['ms_per_step']:.2f} ms/step, {res['images_per_sec']:.0f} img/s")
         # ---- data parallel only: n1_equiv = what ONE GPU does alone at this per-GPU batch (the same steps under no_sync: no
         # gradient collective is issued), exposed_allreduce_ms = step time with collectives - without, and
@@ -580,6 +612,8 @@ def main():
 
     # ---- live per-kernel-class timing (untimed extra steps, rank 0 only) ----
     roofline, kernels, rope = None, {}, None
+    if head["backward_schedule"]:  # (a later leg's calibration may have left the other schedule set)
+        model.set_wgrad_stream(head["backward_schedule"]["weight_gradient_stream"] == "on")
     if rank == 0 and args.profile_steps > 0:
         roofline, kernels, rope = live_profile(args, model, state, multitask_cross_entropy, ips / world)
 
@@ -615,7 +649,7 @@ def main():
         # FLOP_PER_IMG is the sm @224 figure: other architectures / sizes report no whole-step fraction
         "step_mfma_roofline_frac": round(ips / world * FLOP_PER_IMG / (PEAK_BF16_TFLOPS * 1e12), 4) if (args.arch == "sm" and args.img == 224) else None,
         "rope_blocks_mfma_frac": rope["frac"] if rope else None, "rope_blocks": rope,
-        "loss": head["loss"],
+        "loss": head["loss"], "backward_schedule": head["backward_schedule"],
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }
     dp_keys = ("ms_per_step_no_sync", "exposed_allreduce_ms", "n1_equiv_images_per_sec", "scaling_efficiency")

@@ -336,6 +336,16 @@ class mFormerV1(nn.Module):
         self._dtype_code = L.BF16 if self._fp8 else _DTYPES[name]
         self.release_plans()
 
+    def set_wgrad_stream(self, on: bool) -> None:
+        """Backward scheduling of this model's native plans, present and future (include/lnx.h lnx_plan_set_wgrad_stream): True (the
+        default) runs the weight-gradient products on a second HIP stream beside the data-gradient chain, False keeps everything on the
+        launch stream.  Same gradients either way; which one is faster depends on what else holds the GPU's hardware queues (bench.py
+        times both during warm-up and keeps the faster one)."""
+        self._wgrad_stream = bool(on)
+        for st in self._plans.values():
+            if st.get("handle") is not None and L.lib().lnx_plan_set_wgrad_stream(st["handle"], int(self._wgrad_stream)) < 0:
+                L.check(1, "lnx_plan_set_wgrad_stream")
+
     def _destroy_plan(self, st) -> None:
         if st.get("destroyed"):
             return
@@ -469,6 +479,8 @@ class mFormerV1(nn.Module):
             tasks = self._task_list()
             handle = C.c_void_p()
             L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
+            if not getattr(self, "_wgrad_stream", True) and lib.lnx_plan_set_wgrad_stream(handle, 0) < 0:
+                L.check(1, "lnx_plan_set_wgrad_stream")
             lib.lnx_plan_workspace_bytes.restype = C.c_int64
             lib.lnx_plan_param_name.restype = C.c_char_p
             lib.lnx_plan_param_numel.restype = C.c_int64

@@ -846,6 +846,15 @@ def test_weight_gradient_stream_changes_no_gradient(dtype, B):
     assert dtype != "bf16" or exact >= len(g_off) // 2, (exact, len(g_off))
     assert L.lib().lnx_plan_set_wgrad_stream(handle, 2) < 0  # rejected, setting unchanged
     assert L.lib().lnx_plan_set_wgrad_stream(handle, 1) == 1
+    # the module-level switch reaches the plans that exist and the ones created later
+    model.set_wgrad_stream(False)
+    assert L.lib().lnx_plan_set_wgrad_stream(handle, 0) == 0
+    model._inject_drop = _drop_scales(spec, 8, 44)
+    model(xs[:8], ms[:8])  # another batch size: a new plan
+    h2 = model._active["handle"]
+    assert h2 is not handle and L.lib().lnx_plan_set_wgrad_stream(h2, 0) == 0
+    model.set_wgrad_stream(True)
+    assert L.lib().lnx_plan_set_wgrad_stream(h2, 1) == 1 and L.lib().lnx_plan_set_wgrad_stream(handle, 1) == 1
 
 
 def test_recompute_sm_b24_production_dispatch_and_config_flag():
