@@ -1,7 +1,10 @@
 """Soak of the drawn-tile schedulers: N training steps of mFormerV1_sm at batch 256 (the shapes on which gemm_nt_v7 / v9 and the resident
 conv-MLP kernels draw their tiles), same seed, once with LNX_TILE_SCHED=static and once with the atomic counters, each in its own process.
 A tile processed twice or never would show as a loss trajectory that leaves the other one (the two agree to summation-order rounding);
-a counter left non-zero would show as NaN / garbage from the next launch on.  usage: python tools/soak_sched.py [steps]"""
+a counter left non-zero would show as NaN / garbage from the next launch on.
+`wgrad` as second argument: the same soak for the backward's weight-gradient stream (LNX_WGRAD_STREAM=0 against the default) -- a missing
+join would let a weight-gradient product read a buffer its next writer already reached: wrong gradients from some step on.
+usage: python tools/soak_sched.py [steps] [sched|wgrad] [batch]"""
 import json
 import os
 import subprocess
@@ -19,7 +22,7 @@ torch.manual_seed(0)
 cfg, model = bench.make_model(A)
 model = model.cuda(); model.set_compute_dtype("bf16"); model.train(); model.grad_mode = "direct"
 opt = FusedAdamW(model.parameters(), lr=3e-4, weight_decay=0.05)
-B = 256
+B = int(sys.argv[2])
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.rand(B, 3, 224, 224, device="cuda", generator=g); meta = torch.rand(B, 5, device="cuda", generator=g)
 tg = {t: torch.randint(1, c, (B,), device="cuda", generator=g) for t, c in bench.TASKS}
@@ -37,18 +40,24 @@ print(json.dumps(losses))
 ''' % ROOT
 
 steps = sys.argv[1] if len(sys.argv) > 1 else "150"
+what = sys.argv[2] if len(sys.argv) > 2 else "sched"
+batch = sys.argv[3] if len(sys.argv) > 3 else "256"
+names = ("static", "atomic") if what == "sched" else ("serial", "stream")
 out = {}
-for sched in ("static", "atomic"):
-    env = dict(os.environ, LNX_TILE_SCHED=sched)
-    r = subprocess.run([sys.executable, "-c", CHILD, steps], env=env, capture_output=True, text=True, timeout=600)
+for sched in names:
+    env = dict(os.environ, LNX_TILE_SCHED=sched) if what == "sched" else dict(os.environ, LNX_WGRAD_STREAM="0" if sched == "serial" else "1")
+    r = subprocess.run([sys.executable, "-c", CHILD, steps, batch], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         print(r.stderr[-2000:])
         sys.exit(1)
     out[sched] = json.loads(r.stdout.strip().splitlines()[-1])
-a, b = out["static"], out["atomic"]
+a, b = out[names[0]], out[names[1]]
 rel = [abs(p - q) / max(abs(p), 1e-9) for p, q in zip(a, b)]
-print("static :", " ".join(f"{v:.4f}" for v in a))
-print("atomic :", " ".join(f"{v:.4f}" for v in b))
+print(f"{names[0]:7s}:", " ".join(f"{v:.4f}" for v in a))
+print(f"{names[1]:7s}:", " ".join(f"{v:.4f}" for v in b))
 print(f"max relative difference of the sampled losses: {max(rel):.3e} (first step {rel[0]:.3e}); all finite: {all(v == v and abs(v) < 1e6 for v in a + b)}")
-ok = all(v == v for v in a + b) and rel[0] < 1e-4 and max(rel) < 0.1 and b[-1] < b[0]
+# (two runs of ONE schedule decorrelate as well once the loss is small -- DESIGN 8b': atomics + Adam; 200 steps at batch 128 gave 12 % at
+# one sample with 0.4412 / 0.4430 at the end -- so the bound on the later samples is loose; the first steps are the sharp check)
+early = max(rel[:3])
+ok = all(v == v for v in a + b) and early < 1e-4 and max(rel) < 0.3 and b[-1] < 0.2 * b[0] and a[-1] < 0.2 * a[0]
 sys.exit(0 if ok else 2)
