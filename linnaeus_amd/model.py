@@ -351,7 +351,7 @@ class mFormerV1(nn.Module):
             return
         st["destroyed"] = True
         try:
-            L.lib().lnx_plan_destroy(st["handle"])  # synchronises and destroys the plan's side stream and events
+            L.lib().lnx_plan_destroy(st["handle"])  # synchronises the (process-wide) side streams and destroys the plan's events
         finally:
             st["handle"] = None
             st["ws"] = None       # the workspace goes back to the caching allocator
