@@ -639,8 +639,9 @@ typedef struct lnx_mformer_cfg {
                                   config 5's "fp8 MFMA path".  Weights are re-quantised from the fp32 masters every forward,
                                   activations as they are produced; everything saved for the backward, and the backward, stay
                                   bf16 (environment LNX_FP8_DGRAD=1: the proj / fc2 / fc1 data-gradient products in MXFP8 as
-                                  well, gradients quantised per 32-element block -- measured: +0.5 % speed at xl for a quarter
-                                  more gradient error, so off by default).  Needs RoPE dims and MLP widths that are multiples
+                                  well, gradients quantised per 32-element block, dY as the MXFP8 copy the LayerNorm backward
+                                  writes beside its bf16 output -- measured: +1 % speed at xl for a quarter more gradient
+                                  error, so off by default).  Needs RoPE dims and MLP widths that are multiples
                                   of 128. */
 } lnx_mformer_cfg;
 
