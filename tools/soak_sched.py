@@ -42,22 +42,26 @@ print(json.dumps(losses))
 steps = sys.argv[1] if len(sys.argv) > 1 else "150"
 what = sys.argv[2] if len(sys.argv) > 2 else "sched"
 batch = sys.argv[3] if len(sys.argv) > 3 else "256"
-names = ("static", "atomic") if what == "sched" else ("serial", "stream")
+names = ("static", "atomic", "static2") if what == "sched" else ("serial", "stream", "serial2")
 out = {}
 for sched in names:
-    env = dict(os.environ, LNX_TILE_SCHED=sched) if what == "sched" else dict(os.environ, LNX_WGRAD_STREAM="0" if sched == "serial" else "1")
-    r = subprocess.run([sys.executable, "-c", CHILD, steps, batch], env=env, capture_output=True, text=True, timeout=600)
+    base = sched.rstrip("2")
+    env = dict(os.environ, LNX_TILE_SCHED=base) if what == "sched" else dict(os.environ, LNX_WGRAD_STREAM="0" if base == "serial" else "1")
+    r = subprocess.run([sys.executable, "-c", CHILD, steps, batch], env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         print(r.stderr[-2000:])
         sys.exit(1)
     out[sched] = json.loads(r.stdout.strip().splitlines()[-1])
-a, b = out[names[0]], out[names[1]]
-rel = [abs(p - q) / max(abs(p), 1e-9) for p, q in zip(a, b)]
-print(f"{names[0]:7s}:", " ".join(f"{v:.4f}" for v in a))
-print(f"{names[1]:7s}:", " ".join(f"{v:.4f}" for v in b))
-print(f"max relative difference of the sampled losses: {max(rel):.3e} (first step {rel[0]:.3e}); all finite: {all(v == v and abs(v) < 1e6 for v in a + b)}")
-# (two runs of ONE schedule decorrelate as well once the loss is small -- DESIGN 8b': atomics + Adam; 200 steps at batch 128 gave 12 % at
-# one sample with 0.4412 / 0.4430 at the end -- so the bound on the later samples is loose; the first steps are the sharp check)
+a, b, c = out[names[0]], out[names[1]], out[names[2]]
+def spread(p_, q_):
+    return [abs(u - v) / max(abs(u), 1e-9) for u, v in zip(p_, q_)]
+rel, ctl = spread(a, b), spread(a, c)
+for nm in names:
+    print(f"{nm:8s}:", " ".join(f"{v:.4f}" for v in out[nm]))
+print(f"max relative difference of the sampled losses: {names[1]} against {names[0]} {max(rel):.3e} (first step {rel[0]:.3e}); "
+      f"CONTROL, {names[0]} against a second run of itself: {max(ctl):.3e} (first step {ctl[0]:.3e}); all finite: {all(v == v and abs(v) < 1e6 for v in a + b + c)}")
+# Two runs of ONE schedule decorrelate once the loss is small (DESIGN 8b': atomics + Adam on a batch that is being memorised), so the later
+# samples are judged against that control; the first steps are the sharp check (a schedule that computes something else differs at once).
 early = max(rel[:3])
-ok = all(v == v for v in a + b) and early < 1e-4 and max(rel) < 0.3 and b[-1] < 0.2 * b[0] and a[-1] < 0.2 * a[0]
+ok = all(v == v for v in a + b + c) and early < 1e-4 and max(rel) < max(0.15, 3.0 * max(ctl)) and b[-1] < 0.2 * b[0] and a[-1] < 0.2 * a[0]
 sys.exit(0 if ok else 2)
