@@ -95,13 +95,14 @@ typedef struct lnx_gemm_args {
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 
-/* Which kernel family lnx_gemm_nt's dispatcher chose (host-side bookkeeping, no device work): the parity tests use it to prove
+/* Which kernel family the NT dispatchers (lnx_gemm_nt, lnx_gemm_nt_fp8, lnx_gemm_nt_mxfp8) chose (host-side bookkeeping, no device work): the parity tests use it to prove
  * that a shape really ran on the kernel it is meant to cover (e.g. the persistent gemm_nt_v7 at the benchmark's M = 50 944).
  * lnx_last_nt_kernel(): family of the most recent NT launch of this process (any stream), 0 before the first.
  * lnx_nt_kernel_launches(kind): launches of that family since the library was loaded. */
 enum { LNX_NT_KERNEL_NONE = 0, LNX_NT_KERNEL_V1 = 1 /* 128x128 register-staged, both storage types */, LNX_NT_KERNEL_V2 = 2 /* 256x128 LDS-DMA ring */,
        LNX_NT_KERNEL_SKINNY = 3 /* M <= 256, one wave per tile */, LNX_NT_KERNEL_V4 = 4 /* 256x256 tile */,
-       LNX_NT_KERNEL_V7 = 7 /* persistent 256x128, deferred stores */, LNX_NT_KERNEL_V9 = 9 /* persistent 256x256 (round 4) */,
+       LNX_NT_KERNEL_FP8 = 6 /* lnx_gemm_nt_fp8 / _mxfp8 on the 128x128 tile */, LNX_NT_KERNEL_V7 = 7 /* persistent 256x128, deferred stores */,
+       LNX_NT_KERNEL_MX8 = 8 /* lnx_gemm_nt_mxfp8 on the 256x256 tile (gemm_nt_mx8_kernel) */, LNX_NT_KERNEL_V9 = 9 /* persistent 256x256 (round 4) */,
        LNX_NT_KERNEL_EXPERIMENT = 15 /* a kernel of tools/experiments/ (never in the shipped library) */, LNX_NT_KERNEL_KINDS = 16 };
 int lnx_last_nt_kernel(void);
 int64_t lnx_nt_kernel_launches(int kind);
@@ -159,8 +160,13 @@ typedef struct lnx_wgrad_args {
 #define LNX_TN_WS_FLOATS (256 * (256 * 128 + 256))
 
 int lnx_gemm_tn(const lnx_wgrad_args* args, void* stream);
-/* sums the partial tiles of the products postponed with `defer` into their dW / db (no-op when nothing is pending) */
+/* sums the partial tiles of the products postponed with `defer` into their dW / db (no-op when nothing is pending).  `stream` must be the
+ * stream those products were launched on (or NULL = that stream): another stream is an error (the reduces would be ordered behind the wrong work). */
 int lnx_gemm_tn_flush(void* stream);
+/* forgets this host thread's postponed products WITHOUT summing them (returns how many): for a caller whose step failed between a
+ * postponed product and its flush -- the descriptors hold raw ws / dW / db pointers that must not outlive those buffers.
+ * lnx_plan_backward does this itself on entry and on every error path, lnx_plan_destroy on teardown. */
+int lnx_gemm_tn_discard(void);
 
 
 /* ------------------------------------------------------------------------------------

@@ -116,12 +116,12 @@ def check(rc: int, what: str) -> None:
 AUG_CLAMP, AUG_POSTERIZE, AUG_SOLARIZE, AUG_SOLARIZE_ADD, AUG_INVERT, AUG_BRIGHTNESS, AUG_CONTRAST = range(7)
 
 # lnx_last_nt_kernel / lnx_nt_kernel_launches kinds (include/lnx.h)
-NT_KERNEL_NONE, NT_KERNEL_V1, NT_KERNEL_V2, NT_KERNEL_SKINNY, NT_KERNEL_V4, NT_KERNEL_V7, NT_KERNEL_V9, NT_KERNEL_EXPERIMENT = 0, 1, 2, 3, 4, 7, 9, 15
+NT_KERNEL_NONE, NT_KERNEL_V1, NT_KERNEL_V2, NT_KERNEL_SKINNY, NT_KERNEL_V4, NT_KERNEL_FP8, NT_KERNEL_V7, NT_KERNEL_MX8, NT_KERNEL_V9, NT_KERNEL_EXPERIMENT = 0, 1, 2, 3, 4, 6, 7, 8, 9, 15
 
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus", "lnx_set_cu_margin",
-    "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
+    "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_gemm_tn_discard", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",

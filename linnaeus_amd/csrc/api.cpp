@@ -48,8 +48,8 @@ bool tile_sched_static() {
     return e && strcmp(e, "static") == 0;
 }
 int tile_slot_of(hipStream_t st) {
-    // stream handle -> slot, first come first served; more than 64 streams in one process share by hash (their kernels would have
-    // to overlap in time AND be persistent kernels of the same family to disturb each other)
+    // stream handle -> slot, first come first served; a 65th stream gets -1 = the static stride (no counters: a shared slot would let two
+    // overlapping persistent launches skip or repeat each other's tiles)
     static std::mutex mu;
     static hipStream_t known[64];
     static int n = 0;
@@ -60,7 +60,7 @@ int tile_slot_of(hipStream_t st) {
         known[n] = st;
         return n++;
     }
-    return (int)((reinterpret_cast<uintptr_t>(st) >> 6) % 64u);
+    return -1;
 }
 int device_cus() {
     static std::atomic<int> cached{0};  // (one device per process: one process per GPU)

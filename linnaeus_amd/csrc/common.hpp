@@ -98,7 +98,7 @@ __device__ __forceinline__ TileShare tile_share(int n) {
 int persistent_cus(int cus);   // CUs a persistent launch may occupy: cus - margin
 void set_cu_margin(int m);
 bool tile_sched_static();      // LNX_TILE_SCHED=static, read per launch
-int tile_slot_of(hipStream_t st);  // the counter set launches on this stream draw from (one per stream: a stream's kernels run one after the other)
+int tile_slot_of(hipStream_t st);  // the counter set launches on this stream draw from (one per stream: a stream's kernels run one after the other); -1 once 64 streams hold one (static stride)
 int device_cus();              // cached multiProcessorCount of the current device (0 on failure)
 
 // ---------------------------------------------------------------------------------

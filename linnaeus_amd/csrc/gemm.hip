@@ -479,7 +479,9 @@ extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
 }
 
 extern "C" int lnx_gemm_tn_flush(void* stream) {
-    tn_flush((hipStream_t)stream);
+    LNX_CHECK(tn_flush((hipStream_t)stream) == 0, "lnx_gemm_tn_flush: the postponed products of this thread were launched on another stream (flush on that stream, or lnx_gemm_tn_discard)");
     LNX_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int lnx_gemm_tn_discard(void) { return tn_discard(); }

@@ -759,13 +759,25 @@ static thread_local TnReduceBatch g_tn_pending = {};
 static thread_local int g_tn_pending_blocks = 0;
 static thread_local hipStream_t g_tn_pending_stream = nullptr;
 
+// The postponed second stages run on the stream their products were launched on; `st` must be that stream (a flush asked for on another
+// stream would order the reduces behind the wrong work) -- nullptr stands for "whichever it was" (the discard / cleanup paths).
 int tn_flush(hipStream_t st) {
-    (void)st;
     if (g_tn_pending.n == 0) return 0;
+    if (st != nullptr && st != g_tn_pending_stream) return 1;
     hipLaunchKernelGGL(gemm_tn_reduce_batch_kernel, dim3((unsigned)g_tn_pending_blocks), dim3(256), 0, g_tn_pending_stream, g_tn_pending);
     g_tn_pending.n = 0;
     g_tn_pending_blocks = 0;
     return 0;
+}
+
+// Forget the postponed second stages of this host thread without running them (error paths, plan teardown: their descriptors hold raw
+// workspace / gradient pointers that may not outlive the call that failed).  Returns how many were dropped.
+int tn_discard() {
+    const int n = g_tn_pending.n;
+    g_tn_pending.n = 0;
+    g_tn_pending_blocks = 0;
+    g_tn_pending_stream = nullptr;
+    return n;
 }
 
 bool tn_v2_ok(const WgradP& p, int dtype) {
@@ -824,7 +836,7 @@ int launch_tn_v2(const WgradP& p0, int splits_hint, hipStream_t st, bool defer) 
         const int64_t work = (int64_t)tiles * (RW * CW / 4) + (p.db ? p.N : 0);  // one thread per float4 slot of a partial tile, then one per bias entry
         const int blocks = (int)cdiv(work, 256);
         if (defer) {
-            if (g_tn_pending.n > 0 && (g_tn_pending_stream != st || g_tn_pending.n == TN_BATCH)) tn_flush(g_tn_pending_stream);
+            if (g_tn_pending.n > 0 && (g_tn_pending_stream != st || g_tn_pending.n == TN_BATCH)) (void)tn_flush(nullptr);
             TnReduceDesc& d = g_tn_pending.d[g_tn_pending.n++];
             d.p = p;
             d.RW = RW;

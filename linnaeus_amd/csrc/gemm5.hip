@@ -35,7 +35,8 @@ constexpr int PIECES9 = STAGE9 / 1024 / 8;   // 1-KiB LDS-DMA instructions per w
 __device__ __forceinline__ int key9(int row) { return (row & 16) ? 3 : 0; }
 
 // 16-byte stores one lane issues in the epilogue of a FULL tile (two 64x64 sub-tiles): what the first two iterations of the next
-// tile let stay in flight.  Checked against the compiled code by tools/audit_v9_stores.py (a smaller number is always safe).
+// tile let stay in flight.  Checked against the compiled code by tools/audit_counted_waits.py
+// (run by __graft_entry__.build() and tests/test_host_logic.py: a mismatch fails the build; a smaller number is always safe).
 template <bool OUT_F32, int F> struct EpiStores {
     static constexpr int value = 2 * (OUT_F32 ? 16 : 8) + ((F & F_C2) ? 16 : 0);
 };

@@ -476,7 +476,8 @@ int launch_nt_skinny(const GemmP& p, bool out_f32, hipStream_t st);
 int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);
 bool nt_v2_ok(const GemmP& p, int dtype);
 int launch_tn_v2(const WgradP& p, int splits_hint, hipStream_t st, bool defer);
-int tn_flush(hipStream_t st);  // launches the deferred second stages of this thread, if any
+int tn_flush(hipStream_t st);  // launches the deferred second stages of this thread, if any (st: their stream, or nullptr); 1 = they belong to another stream
+int tn_discard();               // forgets them without launching (error paths / teardown); returns how many
 bool tn_v2_ok(const WgradP& p, int dtype);
 
 }  // namespace lnxg

@@ -683,6 +683,7 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
             else done = false;
 #undef X8_LAUNCH
             if (done) {
+                note_nt_kernel(LNX_NT_KERNEL_MX8);
                 LNX_LAUNCH_CHECK();
                 return 0;
             }
@@ -718,6 +719,7 @@ static int launch_fp8(const lnx_gemm_args* a, const float* a_scale, const float*
     else LNX_CHECK(false, "%s: unsupported epilogue feature set %d", who, f);
 #undef F8_LAUNCH
 #undef F8_LAUNCH_
+    note_nt_kernel(LNX_NT_KERNEL_FP8);
     LNX_LAUNCH_CHECK();
     return 0;
 }

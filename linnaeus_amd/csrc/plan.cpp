@@ -776,6 +776,7 @@ static hipStream_t shared_stream(int which) {
 
 extern "C" void lnx_plan_destroy(lnx_plan* p) {
     if (!p) return;
+    (void)lnx_gemm_tn_discard();  // no postponed reduce of this thread may outlive the workspace / gradient arena it points into
     if (p->side) {
         (void)hipStreamSynchronize(p->side);  // (shared_stream: not destroyed)
         (void)hipEventDestroy(p->ev_fork);
@@ -1530,6 +1531,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
     void* sC = c.at<void>(p->o_sC);
     void* sD = c.at<void>(p->o_sD);
     Timed span(c, 9, 4.0 * M * C * (8.0 * C + 49.0));
+    bool forked = false, joined = false;  // (only a block that forked work onto the weight-gradient stream waits for it)
     if (k.fused) {
         void* sB = c.at<void>(p->o_sB);
         lnx_convmlp_bwd_args f;
@@ -1551,6 +1553,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         }
         const Ctx cw = wg_ctx(c);
         RUN(wg_fork(c, 0));  // the two pointwise weight gradients (and the LayerScale step behind them) beside the depthwise backward
+        forked = true;
         if (k.keep_z) {
             RUN(wgrad(cw, M, C, 4 * C, sC, C, sB, 4 * C, k.w2.param, k.b2, 4 * C, 0, 0));
             RUN(wgrad(cw, M, 4 * C, C, sA, 4 * C, c.at<void>(k.ln), C, k.w1.param, k.b1, C, 0, 1));
@@ -1567,7 +1570,10 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             RUN(lnx_layerscale_apply_wgrad(S, T, 4 * C, p->P[k.w2.param], p->P[k.b2], 4 * C, p->P[k.gamma], p->G[k.w2.param], p->G[k.b2], 4 * C, p->G[k.gamma], C, 4 * C, cw.st));
         }
         RUN(wg_done(c, 0));
-        if (!k.fused_ln) RUN(wg_join(c, 0));  // the LayerNorm backward below overwrites sC
+        if (!k.fused_ln) {  // the LayerNorm backward below overwrites sC
+            RUN(wg_join(c, 0));
+            joined = true;
+        }
     } else {
         RUN(lnx_layerscale_bwd(g, c.at<void>(k.z), c.dt, p->P[k.gamma], p->drop_ptr(p->drop_conv[s][i]), H * W, sC, p->G[k.gamma], M, C, c.st));
         RUN(wgrad(c, M, C, 4 * C, sC, C, c.at<void>(k.act), 4 * C, k.w2.param, k.b2, 4 * C));
@@ -1601,7 +1607,7 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
         Timed t(c, 4, (double)M * C * (8 + p->esz));  // bytes: read T dy + fp32 g, write fp32 g
         RUN(lnx_dwconv7_fwd(&d, c.st));
     }
-    RUN(wg_join(c, 0));  // the next block's kernels overwrite sA / sB / sC, and this block's gradients count as written from here on
+    if (forked && !joined) RUN(wg_join(c, 0));  // the next block's kernels overwrite sA / sB / sC, and this block's gradients count as written from here on
     return 0;
 }
 
@@ -1707,6 +1713,13 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     if (!p || !p->bound || !p->has_grads) FAIL("lnx_plan_backward: plan is not bound with gradient buffers");
     if (!p->fwd_done) FAIL("lnx_plan_backward: no forward to differentiate");
     if (segment < -1 || segment > 3) FAIL("lnx_plan_backward: bad segment %d", segment);
+    // Postponed split-K second stages (lnx_wgrad_args.defer) are raw workspace / gradient pointers held per host thread: whatever an earlier
+    // call that failed midway left behind is dropped here, and whatever THIS call leaves behind on an error path is dropped when it
+    // returns (every block flushes its own products, so a call that succeeds leaves nothing).
+    (void)lnx_gemm_tn_discard();
+    struct TnGuard {
+        ~TnGuard() { (void)lnx_gemm_tn_discard(); }
+    } tn_guard;
     const lnx_mformer_cfg& cf = p->c;
     if (segment <= 0) p->dy8_ready = false;
     Ctx c{p, stream, cf.dtype};

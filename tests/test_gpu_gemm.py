@@ -450,6 +450,50 @@ def test_nt_v9_forced_every_form(form, M, N, K, monkeypatch):
     assert kind == L.NT_KERNEL_V9, kind
 
 
+# ----------------------------------------------------------------------------------------------------
+# Round 5: the (N, K) pairs of mFormerV1_xl @224 at B = 128 (M = 128 x 199 = 25 472, C = 1024) and of
+# mFormerV1_lg @384 at B = 64 (M = 64 x 580 = 37 120, C = 768) -- the shapes `bench.py --arch xl --batch 128` and `--arch lg --img 384
+# --batch 64` time -- under the default dispatch and with gemm_nt_v9 forced, every epilogue form, against fp64.
+# ----------------------------------------------------------------------------------------------------
+M_XL, M_LG = 128 * 199, 64 * 580
+XL_LG_NK = [(M_XL, 1024, 1024), (M_XL, 3072, 1024), (M_XL, 4096, 1024), (M_XL, 1024, 4096), (M_XL, 1024, 3072),
+            (M_LG, 768, 768), (M_LG, 2304, 768), (M_LG, 3072, 768), (M_LG, 768, 3072), (M_LG, 768, 2304)]
+
+
+@pytest.mark.parametrize("M,N,K", XL_LG_NK)
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1", "fc1d", "bias_gelu"])
+def test_nt_default_dispatch_at_xl_lg_rows(form, M, N, K, monkeypatch):
+    """Default dispatch: every N here is a multiple of 256 on 400+ tiles, so the persistent kernels take all of them -- gemm_nt_v9 except
+    the GELU'-multiply data gradients, which gemm2.hip's nt_v7_preferred gives to gemm_nt_v7 (the dispatcher's own record)."""
+    monkeypatch.delenv("LNX_NT_V7", raising=False)
+    monkeypatch.delenv("LNX_NT_V9", raising=False)
+    kind = _check_form(form, M, N, K, rows_per_sample=199 if M == M_XL else 580)
+    assert kind == (L.NT_KERNEL_V7 if form == "mul_aux" else L.NT_KERNEL_V9), (form, M, N, K, kind)
+
+
+@pytest.mark.parametrize("M,N,K", XL_LG_NK)
+@pytest.mark.parametrize("form", ["plain", "bias", "res_f32", "mul_aux", "gelu_bwd", "fc1", "fc1d", "bias_gelu"])
+def test_nt_v9_forced_at_xl_lg_rows(form, M, N, K, monkeypatch):
+    monkeypatch.setenv("LNX_NT_V9", "1")
+    monkeypatch.setenv("LNX_NT_V7", "0")
+    kind = _check_form(form, M, N, K, rows_per_sample=199 if M == M_XL else 580)
+    assert kind == L.NT_KERNEL_V9, kind
+
+
+@pytest.mark.parametrize("M,N,K", XL_LG_NK)
+def test_tn_at_xl_lg_rows(M, N, K):
+    """The weight-gradient products of the same layers (dW[N, K] = dY^T A over M rows; gemm_tn_v2 + the workspace reduce, as the plan calls
+    it) against fp64: accumulates onto what dW / db hold, fixed summation order (bit-reproducible)."""
+    dY = _gpu_randn((M, N), 11 + N).bfloat16()
+    A = _gpu_randn((M, K), 12 + K).bfloat16()
+    dW, db = run_tn(dY, A, L.BF16, ws=True, init=0.25)
+    ref = dY.double().T @ A.double()
+    torch.testing.assert_close(dW.double(), ref + 0.25, rtol=1e-4, atol=2e-5 * M**0.5)
+    torch.testing.assert_close(db.double(), dY.double().sum(0) + 0.25, rtol=1e-4, atol=2e-5 * M**0.5)
+    dW2, db2 = run_tn(dY, A, L.BF16, ws=True, init=0.25)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("margin", [0, 5, 248])
 def test_persistent_kernels_cover_every_tile_once_for_any_grid(margin, monkeypatch):
     """The drawn-tile schedulers (common.hpp: per-XCD shares and counters) under odd tile counts and odd grids: lnx_set_cu_margin(5) gives a grid
@@ -571,3 +615,35 @@ def test_tn_deferred_reduces_in_one_launch():
     L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")
     torch.cuda.synchronize()
     assert all(torch.equal(dW, many[0][0]) for dW, _ in many)
+
+
+def test_tn_deferred_reduces_belong_to_their_stream_and_can_be_discarded():
+    """a flush asked for on another stream than the postponed products' is refused (it would order the reduces behind the wrong
+    work) and leaves them pending; lnx_gemm_tn_discard() forgets them without touching dW -- what lnx_plan_backward does on entry and
+    on its error paths, so that no descriptor with raw workspace / gradient pointers outlives a step that failed."""
+    M, N, K = 8192, 384, 384
+    g = torch.Generator(device="cuda").manual_seed(9)
+    dY = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    dW = torch.zeros(N, K, device="cuda")
+    w = torch.empty(L.TN_WS_FLOATS, device="cuda")
+    a = L.WgradArgs()
+    a.dtype, a.M, a.N, a.K = L.BF16, M, N, K
+    a.dY, a.lddy, a.A, a.lda, a.dW, a.lddw = _ptr(dY), N, _ptr(A), K, _ptr(dW), K
+    a.ws, a.ws_floats, a.defer = _ptr(w), w.numel(), 1
+    other = torch.cuda.Stream()
+    L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+    with pytest.raises(L.LnxError, match="another stream"):
+        L.check(L.lib().lnx_gemm_tn_flush(C.c_void_p(other.cuda_stream)), "lnx_gemm_tn_flush")
+    torch.cuda.synchronize()
+    assert float(dW.abs().sum()) == 0.0
+    assert L.lib().lnx_gemm_tn_discard() == 1
+    L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")  # nothing left: a no-op
+    torch.cuda.synchronize()
+    assert float(dW.abs().sum()) == 0.0
+    assert L.lib().lnx_gemm_tn_discard() == 0
+    # and the ordinary path still works afterwards
+    L.check(L.lib().lnx_gemm_tn(C.byref(a), _stream()), "lnx_gemm_tn")
+    L.check(L.lib().lnx_gemm_tn_flush(_stream()), "lnx_gemm_tn_flush")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dW.double(), dY.double().T @ A.double(), rtol=1e-4, atol=2e-5 * M**0.5)

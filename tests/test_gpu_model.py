@@ -639,6 +639,165 @@ def test_config4_lg384_hierarchical_heads_taxonomy_loss():
         assert glob <= gtol, (dtype, glob, wk)
 
 
+# ----------------------------------------------------------------------------------------------------
+# Round 5: configs 4 and 5 at the dispatch their bench lines time -- batch invariance, as
+# test_sm_b256_batch_invariance does for config 2.  Reference math of the kernels this reaches: rope_2d_mhsa.py:422-505,
+# blocks/mlp.py:46-66, blocks/convnext.py:73-87 (every sample independent: mFormerV1.py:407-541 has no batch statistics).
+# ----------------------------------------------------------------------------------------------------
+def _nt_counts():
+    from linnaeus_amd import _lib as L
+
+    return {k: L.lib().lnx_nt_kernel_launches(getattr(L, "NT_KERNEL_" + k)) for k in ("V1", "V2", "V4", "V7", "V9", "FP8", "MX8")}
+
+
+def _rel(ga, gb):
+    e2 = sum((ga[k].double() - gb[k].double()).pow(2).sum().item() for k in gb)
+    r2 = sum(gb[k].double().pow(2).sum().item() for k in gb)
+    return (e2 / r2) ** 0.5
+
+
+def _batch_invariance_case(model, osd, oout, x0, meta0, drops0, xf, metaf, dropsf, heads, loss_of, dtype, ftol, gtol, ftol_self, gtol_self, tag):
+    """Rows 0..B0-1 of the big batch are the oracle-checked small-batch inputs (same DropPath multipliers), the rest seeded filler.
+    (a) logits of those rows against the oracle and against the GPU's own small-batch run; (b) with the loss restricted to those rows
+    every parameter gradient against the oracle's and the small-batch run's.  Returns the NT dispatcher's launch counts of the big step."""
+    B0 = x0.shape[0]
+    model.set_compute_dtype(dtype)
+    model.zero_grad(set_to_none=True)
+    out_s = run(model, x0, meta0, drops0, train=True)
+    loss_of(out_s, "cuda").backward()
+    log_s = {t: v.detach().float().clone() for t, v in out_s.items()}
+    g_s = _grads(model)
+    model.zero_grad(set_to_none=True)
+    x, meta = torch.cat([x0, xf]), torch.cat([meta0, metaf])
+    drops = [None if a is None else torch.cat([a, b]) for a, b in zip(drops0, dropsf)]
+    before = _nt_counts()
+    out = run(model, x, meta, drops, train=True)
+    loss_of({t: v[:B0] for t, v in out.items()}, "cuda").backward()
+    torch.cuda.synchronize()
+    after = _nt_counts()
+    worst = worst_s = 0.0
+    for t, _ in heads:
+        ref = oout[t].detach()
+        got = out[t][:B0].detach().float().cpu()
+        scale = max(1.0, ref.abs().max().item())
+        err = (got - ref).abs().max().item() / scale
+        err_s = (out[t][:B0].detach().float() - log_s[t]).abs().max().item() / scale
+        worst, worst_s = max(worst, err), max(worst_s, err_s)
+        assert torch.isfinite(out[t]).all(), t
+        assert err <= ftol, (tag, dtype, t, err)
+        assert err_s <= ftol_self, (tag, dtype, t, err_s)
+    glob, wk = _grad_errors(model, osd)
+    glob_s = _rel(_grads(model), g_s)
+    print(f"[{tag} rows 0-{B0 - 1} of {x.shape[0]} / {dtype}] logits vs oracle {worst:.5f}, vs the small-batch run {worst_s:.5f} (of scale); gradient vs oracle "
+          f"{glob:.2e} (worst {wk[0]} {wk[1]:.2e}), vs the small-batch run {glob_s:.2e}")
+    assert glob <= gtol, (tag, dtype, glob, wk)
+    assert glob_s <= gtol_self, (tag, dtype, glob_s)
+    model.zero_grad(set_to_none=True)
+    return {k: after[k] - before[k] for k in after}
+
+
+def test_xl_b128_batch_invariance():
+    """BASELINE config 5 at the batch its bench lines time (`bench.py --arch xl --batch 128`, bf16 and --dtype fp8): mFormerV1_xl @224,
+    B = 128, DropPath 0.2.  M = 128 x 199 = 25 472 rows in stage 3: the persistent 256x256 kernel gemm_nt_v9 on 400-tile grids at
+    (N, K) in {(1024,1024), (3072,1024), (4096,1024), (1024,4096), (1024,3072)}, gemm_tn_v2 at those widths, the unfused C = 256 / 512 conv
+    path with the GELU' / multiply epilogues, and in fp8 mode gemm_nt_mx8_kernel inside the plan (its counter proves it).  Rows 0-1 are the
+    inputs of an oracle run; tolerances are test_xlarge_224_matches_oracle_and_autobatch's (bf16 0.04 / 0.05, fp8 0.10 / 0.12: stated there)."""
+    spec = O.Spec(conv_dims=(256, 512, 1024, 2048), rope_depths=(22, 2), rope_heads=(16, 32), heads=(("taxa_L10", 40), ("taxa_L20", 9)), drop_path_rate=0.2)
+    B0, B = 2, 128
+    sd = O.seeded_state_dict(O.param_shapes(spec), 4321)
+    x0, meta0 = O.seeded_inputs(spec, B0, 224, 77)
+    drops0 = _drop_scales(spec, B0, 78)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x0, meta0, drops0)
+    O.probe_loss(oout).backward()
+    xf, metaf = O.seeded_inputs(spec, B - B0, 224, 79)
+    dropsf = _drop_scales(spec, B - B0, 80)
+    model = build_model(make_config(spec, 224), num_classes={t: c for t, c in spec.heads})
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    loss_of = lambda out, dev: O.probe_loss(out)  # noqa: E731
+    n_rope3 = 22
+    for dtype, ftol, gtol, ftol_self, gtol_self in (("bf16", 0.04, 0.05, 0.02, 0.03), ("fp8", 0.10, 0.12, 0.03, 0.04)):
+        d = _batch_invariance_case(model, osd, oout, x0, meta0, drops0, xf, metaf, dropsf, spec.heads, loss_of, dtype, ftol, gtol, ftol_self, gtol_self, "xl@224")
+        print(f"[xl@224 B=128 / {dtype}] NT launches in the step: {d}")
+        if dtype == "bf16":
+            # stage 3, per block: qkv, proj, fc1, fc2 and the proj / fc1 / qkv data gradients on the persistent 256x256 kernel (N % 256 == 0, 400+
+            # tiles); the fc2 data gradient (multiply-by-GELU' epilogue) on the persistent 256x128 kernel (gemm2.hip: nt_v7_preferred)
+            assert d["V9"] >= 7 * n_rope3 and d["V7"] + d["V9"] >= 8 * n_rope3, d
+            assert d["MX8"] == 0 and d["FP8"] == 0, d
+        else:
+            # the MXFP8 forward products (qkv, fc1, fc2) of the 22 stage-3 blocks on the 256x256 MX kernel; proj and the data gradients stay bf16
+            assert d["MX8"] >= 3 * n_rope3, d
+            assert d["V9"] >= 4 * n_rope3, d
+
+
+def _config4_case(B):
+    """BASELINE config 4's pieces: mFormerV1_lg @384 with three metadata components (N = 24 x 24 + 4 = 580 tokens), ConditionalClassifier heads
+    on a 3-level taxonomy and TaxonomyAwareLabelSmoothingCE per task (soft-label matrices, ignore_index 0, class weights)."""
+    from linnaeus_amd.loss import TaxonomyAwareLabelSmoothingCE
+
+    heads = (("taxa_L10", 48), ("taxa_L20", 12), ("taxa_L30", 4))
+    g = torch.Generator().manual_seed(5)
+    soft, cw, tg, tw = {}, {}, {}, {"taxa_L10": 1.0, "taxa_L20": 0.5, "taxa_L30": 0.25}
+    for t, c in heads:
+        m = torch.rand(c, c, generator=g) * 0.1 + 0.9 * torch.eye(c)
+        soft[t] = m / m.sum(1, keepdim=True)
+        cw[t] = 0.5 + torch.rand(c, generator=g)
+        tg[t] = torch.randint(0, c, (B,), generator=g)  # index 0 = null, ignored
+    tg["taxa_L30"][0] = 0
+    crits = {}
+
+    def total(out, dev):
+        tot = 0.0
+        for t, _ in heads:
+            if dev == "cpu":
+                per = O.soft_label_ce(out[t], tg[t], soft[t], cw[t], 0)
+            else:
+                if t not in crits:
+                    crits[t] = TaxonomyAwareLabelSmoothingCE(soft[t], weight=cw[t], apply_class_weights=True, ignore_index=0).cuda()
+                per = crits[t](out[t], tg[t].cuda())
+            tot = tot + tw[t] * per.mean()
+        return tot
+
+    tree = TinyTree({"taxa_L10": {i: i // 4 for i in range(48)}, "taxa_L20": {i: i // 3 for i in range(12)}}, [t for t, _ in heads], dict(heads))
+    return heads, total, tree
+
+
+def test_lg384_b64_batch_invariance():
+    """BASELINE config 4 at the batch its bench line times (`bench.py --arch lg --img 384 --batch 64`): mFormerV1_lg @384, B = 64, DropPath 0.2,
+    ConditionalClassifier heads + taxonomy-aware label-smoothing loss.  M = 64 x 580 = 37 120 rows in stage 3: gemm_nt_v9 at (N, K) in
+    {(768,768), (2304,768), (3072,768), (768,3072), (768,2304)}, the multi-tile attention path at N = 580, the C = 192 fused and C = 384 unfused
+    conv blocks at 96 x 96 / 48 x 48.  Rows 0-1 are the inputs of an oracle run (loss value included); bounds as test_config4_lg384_... / test_large_384_..."""
+    B0, B = 2, 64
+    heads, total, tree = _config4_case(B0)
+    spec = O.Spec(conv_dims=(192, 384, 768, 1536), rope_depths=(10, 2), rope_heads=(12, 24), meta=(("TEMPORAL", 2), ("SPATIAL", 3), ("ELEVATION", 10)),
+                  heads=heads, drop_path_rate=0.2)
+    sd = O.seeded_state_dict(O.param_shapes(spec), 4321)
+    x0, meta0 = O.seeded_inputs(spec, B0, 384, 98)
+    drops0 = _drop_scales(spec, B0, 97)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout = O.forward(osd, spec, x0, meta0, drops0)
+    oloss = total(oout, "cpu")
+    oloss.backward()
+    xf, metaf = O.seeded_inputs(spec, B - B0, 384, 96)
+    dropsf = _drop_scales(spec, B - B0, 95)
+    model = build_model(make_config(spec, 384, "ConditionalClassifier"), num_classes=dict(heads), taxonomy_tree=tree)
+    model.load_state_dict(model_state_dict_from_oracle(model, sd), strict=True)
+    model = model.cuda()
+    seen = {}
+
+    def loss_of(out, dev):
+        l_ = total(out, dev)
+        seen["loss"] = float(l_.detach())
+        return l_
+
+    d = _batch_invariance_case(model, osd, oout, x0, meta0, drops0, xf, metaf, dropsf, heads, loss_of, "bf16", 0.03, 0.05, 0.02, 0.03, "lg@384")
+    print(f"[lg@384 B=64 / bf16] loss on rows 0-1 {seen['loss']:.5f} vs oracle {oloss.item():.5f}; NT launches in the step: {d}")
+    assert abs(seen["loss"] - oloss.item()) <= 3e-2 * max(1.0, abs(oloss.item())), (seen["loss"], oloss.item())
+    # stage 3 (10 blocks): every product has N % 256 == 0 and 145 x 3 = 435 tiles or more; the fc2 data gradient takes gemm_nt_v7
+    assert d["V9"] >= 7 * 10 and d["V7"] + d["V9"] >= 8 * 10, d
+
+
 def test_plan_cache_is_bounded_and_released():
     """every distinct batch size used to pin another workspace forever.  The plan cache is an LRU of
     `max_cached_plans`; evicted plans are destroyed and their workspaces freed; no_grad forwards use an inference plan

@@ -677,6 +677,49 @@ def test_mxfp8_quantize_and_gemm(M, N, K, xd):
     assert rel < 0.05
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 199, 1024, 1024), (128 * 199, 3072, 1024), (128 * 199, 4096, 1024), (128 * 199, 1024, 4096)])
+def test_mxfp8_256x256_kernel_at_xl_rows(M, N, K):
+    """Round 5: gemm_nt_mx8_kernel (the 256x256-tile MXFP8 kernel) at the shapes `bench.py --arch xl --batch 128 --dtype fp8` gives it
+    (M = 25 472; qkv, fc1, fc2 and -- with the opt-in MXFP8 data gradients -- proj), every epilogue it carries, against the fp64 product of
+    the DEQUANTISED operands (on the GPU); the dispatcher's own record says which kernel ran."""
+    gen = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device="cuda", generator=gen) * torch.exp2(torch.randint(-3, 4, (M, K // 32, 1), device="cuda", generator=gen).float()).expand(M, K // 32, 32).reshape(M, K)).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=gen) / K ** 0.5).bfloat16()
+    a8, sa = ops.quantize_mxfp8(a)
+    w8, sw = ops.quantize_mxfp8(w)
+    ref = ops.dequantize_mxfp8(a8, sa).double() @ ops.dequantize_mxfp8(w8, sw).double().t()
+    tol = 8e-3 * max(1.0, ref.abs().max().item())
+    bias = torch.randn(N, device="cuda", generator=gen)
+    h = ref + bias.double()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out)
+    assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_MX8
+    torch.testing.assert_close(out.double(), ref, rtol=8e-3, atol=tol)
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out, bias=bias)
+    torch.testing.assert_close(out.double(), h, rtol=8e-3, atol=tol)
+    pre = torch.empty_like(out)
+    c8 = torch.zeros(M, N, device="cuda", dtype=torch.uint8)
+    c8s = torch.zeros(N // 128, M, 4, device="cuda", dtype=torch.uint8)
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out, bias=bias, act=L.ACT_GELU, c2=pre, c8=c8, c8_scales=c8s)   # fc1: GELU + pre-activation + MXFP8 copy
+    assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_MX8
+    torch.testing.assert_close(pre.double(), h, rtol=8e-3, atol=tol)
+    torch.testing.assert_close(out.double(), torch.nn.functional.gelu(h), rtol=8e-3, atol=tol)
+    r8, rsc = ops.quantize_mxfp8(out)
+    assert torch.equal(c8s, rsc) and torch.equal(c8, r8.view(torch.uint8))
+    aux = torch.randn(M, N, device="cuda", generator=gen).bfloat16()
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, out, act=L.ACT_GELU_BWD, aux=aux)                                   # fc2 data gradient: x GELU'(aux)
+    assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_MX8
+    xa = aux.double().requires_grad_(True)
+    torch.nn.functional.gelu(xa).sum().backward()
+    torch.testing.assert_close(out.double(), ref * xa.grad, rtol=1e-2, atol=1.25 * tol)
+    res = torch.randn(M, N, device="cuda", generator=gen)
+    rs = ((torch.rand(128, device="cuda", generator=gen) > 0.2).float() / 0.8)
+    o32 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt_mxfp8(a8, sa, w8, sw, o32, bias=bias, res=res, rowscale=rs, rows_per_sample=199)          # proj / fc2: fp32 residual + DropPath scale
+    assert L.lib().lnx_last_nt_kernel() == L.NT_KERNEL_MX8
+    torch.testing.assert_close(o32.double(), res.double() + rs.double().repeat_interleave(199)[:, None] * h, rtol=1e-4, atol=1e-4 * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("M,C", [(1000, 384), (777, 768), (300, 1024), (513, 2048), (64, 128), (200, 256), (130, 1536), (99, 1280)])
 def test_layernorm_fused_mxfp8_output(M, C):
     """LayerNorm forward with the MXFP8 second output (the producer side of the model's fp8 mode): the bf16 output is what

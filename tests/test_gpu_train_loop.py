@@ -115,3 +115,31 @@ def test_training_loop_pieces_compose_and_learn(augment):
     # a recompute training plan and an inference plan, nothing else, are alive
     kinds = sorted((k[-2], k[-1]) for k in model._plans)
     assert kinds == [(False, False), (True, True)], kinds
+
+
+def test_bench_line_loss_is_pinned_and_checked_against_the_oracle():
+    """`bench.py` used to print a `loss` that nothing checked.  The driver's own command (`--gpus 1 --steps 20 --warmup 5`,
+    seeded inputs, seeded DropPath draws, 5 warm-up + 11 calibration + 20 timed AdamW steps on one fixed batch) must reproduce the pinned
+    loss of tests/golden/bench_loss.json to 1e-3 -- and the same process must have compared the timed model's loss with the CPU oracle's
+    at the oracle's weights (`cpu_baseline.loss_check`; bench.py raises when they differ by more than its stated tolerance).  The line also
+    carries config 3's per-GPU shape on one GPU (`config3_n1`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(repo, "tests", "golden", "bench_loss.json")) as fh:
+        pin = json.load(fh)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-batch", "8", "--profile-steps", "0"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"[bench line] loss {line['loss']} (pinned {pin['loss']}), loss_check {line['cpu_baseline']['loss_check']}, config3_n1 {line['config3_n1']['ms_per_step']} ms")
+    assert abs(line["loss"] - pin["loss"]) <= pin["rel_tol"] * pin["loss"], (line["loss"], pin)
+    chk = line["cpu_baseline"]["loss_check"]
+    assert chk is not None and chk["abs_diff"] <= chk["tolerance"], chk
+    n1 = line["config3_n1"]
+    assert n1["per_gpu_batch"] == 128 and n1["ms_per_step"] > 0 and n1["images_per_sec"] > 0
+    assert line["config"]["per_gpu_batch"] == 256 and line["roofline"] is None  # (--profile-steps 0)

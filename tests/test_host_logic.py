@@ -253,7 +253,7 @@ def test_bench_gpus_n_launches_its_own_ranks():
 
 
 def test_bench_legs():
-    """What `bench.py --gpus N` times: N = 1 is BASELINE config 2 (256 images); N > 1 times config 3's 128 images per GPU (global
+    """What `bench.py --gpus N` times: N = 1 is BASELINE config 2 (256 images; plus, untimed for `value`, config 3's 128 images on the one GPU); N > 1 times config 3's 128 images per GPU (global
     1024 at 8: the line's `value`) AND the 256-per-GPU weak leg in the same run; --batch overrides both."""
     import importlib.util
 
@@ -261,8 +261,25 @@ def test_bench_legs():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(repo, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.legs_for(1, None) == [("config2", 256)]
+    assert bench.legs_for(1, None) == [("config2", 256), ("config3_n1", 128)]  # round 5: the N = 1 line carries config 3's per-GPU shape too
     for n in (2, 4, 8):
         legs = bench.legs_for(n, None)
         assert legs[0] == ("config3", 128) and legs[0][1] * 8 == 1024 and ("weak256", 256) in legs
     assert bench.legs_for(8, 64) == [("batch", 64)]
+
+
+@pytest.mark.skipif(not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")), reason="needs hipcc (cross-compiles without a GPU)")
+def test_counted_waits_match_the_compiled_store_counts():
+    """gemm_nt_v9 / gemm_nt_v7 keep epilogue stores in flight by COUNT (`s_waitcnt vmcnt(pieces + stores)`); if the
+    compiler ever emitted fewer store instructions than the source counts, a K slice would be read from LDS before it has landed.
+    tools/audit_counted_waits.py compiles gemm5.hip / gemm3.hip for gfx950 and compares, per kernel instantiation, the 16-byte stores in
+    the assembly with EpiStores / 2 x NSTORE (also run by __graft_entry__.build(): a mismatch fails the build)."""
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("audit_counted_waits", os.path.join(repo, "tools", "audit_counted_waits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok, lines = mod.audit(arch="gfx950")
+    assert ok, "\n".join(lines)
+    assert sum("gemm_nt_v9" in ln for ln in lines) >= 6 and sum("gemm_nt_v7" in ln for ln in lines) >= 10, lines
