@@ -568,9 +568,23 @@ def main():
             t_off = few()
             keep_on = t_on <= 1.01 * t_off
             model.set_wgrad_stream(keep_on)
-            step()
             sched = {"weight_gradient_stream": "on" if keep_on else "off", "calibration_ms_on": round(t_on * 1e3, 3), "calibration_ms_off": round(t_off * 1e3, 3),
                      "what": "4 untimed steps each during warm-up, max over ranks; 'on' (the library default) unless 'off' is > 1 % faster"}
+            # ... and the stream the metadata-head chains run on (round 5): their own side stream (single-GPU default), the weight-gradient stream
+            # (DataParallel's default: one stream fewer beside the collective's) or the launch stream; the default is kept unless another
+            # placement is more than 1 % faster
+            if os.environ.get("LNX_NO_SIDE_STREAM") is None and os.environ.get("LNX_META_STREAM") is None:
+                default_mode = 2 if dist else 1
+                t_meta = {}
+                for mode in ([2, 0] if dist else [1, 2, 0]):
+                    model.set_meta_stream(mode)
+                    t_meta[mode] = few(3)
+                best = min(t_meta, key=t_meta.get)
+                keep = default_mode if t_meta[default_mode] <= 1.01 * t_meta[best] else best
+                model.set_meta_stream(keep)
+                sched["metadata_stream"] = {"kept": {0: "launch stream", 1: "own side stream", 2: "weight-gradient stream"}[keep],
+                                            "calibration_ms": {{0: "launch", 1: "side", 2: "weight_gradient"}[k_]: round(v_ * 1e3, 3) for k_, v_ in t_meta.items()}}
+            step()
         torch.cuda.synchronize()
         if dist:
             dist.barrier(device_ids=[local])
@@ -631,6 +645,21 @@ def main():
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                 "nccl_env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith(("NCCL_", "RCCL_"))}}
 
+    # ---- data parallel: stream budget and per-bucket issue -> done times (3 untimed steps with the reducer's telemetry on, all ranks) ----
+    dp_diag = None
+    if dist and hasattr(net, "bucket_report"):
+        net.telemetry = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier(device_ids=[local])
+        net.telemetry = False
+        dp_diag = {"buckets": net.bucket_report(), "stream_budget": net.stream_budget(),
+                   "what": "buckets: bytes all-reduced per backward segment and the time from issue (the segment's kernels enqueued) to done (the collective's end "
+                           "event), mean over 3 untimed steps, this rank; stream_budget: every HIP stream a step issues work on"}
+        step()
+        torch.cuda.synchronize()
+
     # ---- live per-kernel-class timing (untimed extra steps, rank 0 only) ----
     roofline, kernels, rope = None, {}, None
     if head["backward_schedule"]:  # (a later leg's calibration may have left the other schedule set)
@@ -690,6 +719,8 @@ def main():
     dp_keys = ("ms_per_step_no_sync", "exposed_allreduce_ms", "n1_equiv_images_per_sec", "scaling_efficiency")
     if rccl:
         line["rccl_ranks"] = rccl["world_size"]
+        if dp_diag:
+            rccl.update(dp_diag)
         line["rccl"] = rccl
     if "scaling_efficiency" in head:
         # value / (n_gpus * n1_equiv), both measured in THIS run at THIS leg's per-GPU batch: not value / (N * the N = 1 line's

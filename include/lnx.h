@@ -394,6 +394,64 @@ int lnx_agg2_bwd(const float* dout, const float* a, const float* b, const float*
 /* meta [B, width] fp32 -> T [B, 16] holding columns [off, off+dim) zero padded */
 int lnx_pack_meta(const float* meta, int width, int off, int dim, void* out, int dtype, int B, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Metadata-head chains, one launch per direction (round 5).  Replaces, per metadata component and RoPE stage, the chain
+ *     Linear(d, C) -> ReLU -> LayerNorm(C) -> ResNormLayer:  x + LN2(ReLU(W2 . LN1(ReLU(W1 . x))))
+ * of /root/reference/linnaeus/models/mFormerV1.py:282-311 and normalization/res_norm_layer.py:23-30 (eps 1e-5 everywhere),
+ * and its autograd backward -- until round 4 seven GEMM / LayerNorm launches per head forward and thirteen backward.
+ * fp32 storage and fp32 matrix-core arithmetic whatever the plan's dtype (M = batch rows: the cost is launches, not FLOPs).
+ * One workgroup takes 16 batch rows through the whole chain; every head passed in one call shares one launch (four per launch).
+ * All buffers are the caller's (no allocation, no host synchronisation); rows are 16-byte aligned.
+ * ------------------------------------------------------------------------------------ */
+typedef struct lnx_meta_head_args {
+    int B, C;                 /* batch rows; width of the RoPE stage this head feeds (a multiple of 64, <= 2048) */
+    int dim, off;             /* this component's input width (1..16) and its first column in `meta` */
+    const float* meta;        /* [B, meta_width] */
+    int meta_width;
+    float eps;                /* LayerNorm eps (the reference: 1e-5) */
+    const float* w0;          /* [C, ldw0], columns >= dim zero (the operand arena's copy of `.0.weight`); ldw0 >= 16 */
+    int ldw0;
+    const float *b0, *ln0_w, *ln0_b;   /* `.0.bias`, `.2.weight`, `.2.bias` */
+    const float* w1;          /* [C, ldw1]  `.3.w1.weight` */
+    int ldw1;
+    const float *b1, *ln1_w, *ln1_b;   /* `.3.w1.bias`, `.3.norm_fn1.*` */
+    const float* w2;          /* [C, ldw2]  `.3.w2.weight` */
+    int ldw2;
+    const float *b2, *ln2_w, *ln2_b;   /* `.3.w2.bias`, `.3.norm_fn2.*` */
+    /* activations kept for the backward (also the chain's own scratch: always required) */
+    float* t0;                /* [B, 16]  the metadata slice, zero padded */
+    float *h0, *x, *h1, *n1, *h2;      /* [B, C] each: ReLU outputs h0 / h1 / h2, LayerNorm outputs x / n1 */
+    float *m0, *r0, *m1, *r1, *m2, *r2; /* [B] each: mean / rstd of the three LayerNorms */
+    /* output: row b goes to tok[b * tok_row_stride + tok_row_offset .. + C) (the token matrix of the stage: stride N C, offset (1 + m) C) */
+    float* tok;
+    int64_t tok_row_stride, tok_row_offset;
+} lnx_meta_head_args;
+int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, void* stream);
+
+typedef struct lnx_meta_head_bwd_args {
+    int B, C, dim;
+    const float* g;           /* token-matrix gradient: row b at g[b * g_row_stride + g_row_offset .. + C) */
+    int64_t g_row_stride, g_row_offset;
+    const float* w1t;         /* transposed copies [C_in, ld]: w1t[i][o] = w1[o][i] */
+    int ldw1t;
+    const float* w2t;
+    int ldw2t;
+    const float *ln0_w, *ln1_w, *ln2_w;
+    const float *t0, *h0, *x, *h1, *n1, *h2, *m0, *r0, *m1, *r1, *m2, *r2;   /* what the forward left */
+    float *dp2, *dp1, *dp0;   /* [B, C] scratch each: gradients wrt the three Linear outputs (before the ReLU) */
+    float* part;              /* scratch, lnx_meta_heads_bwd_part_floats(B, C) floats: per-row-group column sums of the LayerNorm gradients */
+    /* gradients, ACCUMULATED (+=) in a fixed order (no atomics): */
+    float* d_w0;              /* [C, dim] (torch layout of `.0.weight`) */
+    float *d_b0, *d_ln0_w, *d_ln0_b;
+    float* d_w1;              /* [C, C] */
+    float *d_b1, *d_ln1_w, *d_ln1_b;
+    float* d_w2;              /* [C, C] */
+    float *d_b2, *d_ln2_w, *d_ln2_b;
+} lnx_meta_head_bwd_args;
+int64_t lnx_meta_heads_bwd_part_floats(int B, int C);
+/* two launches per (up to four) heads: the data-gradient chain, then every weight / bias / LayerNorm gradient of those heads */
+int lnx_meta_heads_bwd(const lnx_meta_head_bwd_args* heads, int n_heads, void* stream);
+
 /* Per-step parameter preparation: cast fp32 master parameters into the T-typed operand
  * arena the GEMMs read (plus transposed copies for the data-gradient GEMMs and the
  * tap-major depthwise weights).  `descs` is a DEVICE array built by the caller. */
@@ -715,6 +773,12 @@ int lnx_plan_profile_end_ex(lnx_plan* p, double* ms, double* work, double* bytes
  * lnx_plan_set_wgrad_stream(p, 0) puts everything back on the launch stream (what bench.py's per-kernel timing pass does, so that a
  * kernel's duration is its own); returns the previous setting (0 / 1), negative on error.  LNX_WGRAD_STREAM=0 never creates the stream. */
 int lnx_plan_set_wgrad_stream(lnx_plan* p, int on);
+/* Round 5: which stream the metadata heads (forward chain, backward chain + weight gradients) run on beside the launch stream:
+ * 0 = the launch stream itself, 1 = a side stream of their own (default; LNX_NO_SIDE_STREAM never creates it), 2 = the weight-gradient
+ * stream (one HIP stream fewer: a data-parallel step then uses launch + weight-gradient streams + the collective library's own --
+ * within the four hardware queues of the device; only with the one-launch chain, otherwise as 1).  Forks and joins are events either
+ * way: same values, same summation orders.  Returns the previous mode, negative on error.  LNX_META_STREAM=0/1/2 sets the default. */
+int lnx_plan_set_meta_stream(lnx_plan* p, int mode);
 /* indices of the parameters whose gradient is final after `segment`; returns their count.  The metadata heads' backward
  * runs on the plan's side stream and is joined one segment after the one that forks it, so the stage-4 heads report
  * segment 1 and the stage-3 heads segment 2 (a caller that stops early must run the following segment, or -1, to join). */

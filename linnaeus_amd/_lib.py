@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         _lib.lnx_last_error.restype = C.c_char_p
         _lib.lnx_nt_kernel_launches.restype = C.c_int64
         _lib.lnx_convmlp_bwd_ws_floats.restype = C.c_int64
+        _lib.lnx_meta_heads_bwd_part_floats.restype = C.c_int64
         for name in EXPORTS:
             if not hasattr(_lib, name):
                 raise LnxError(f"{LIB_PATH} does not export {name}; rebuild it")
@@ -126,14 +127,42 @@ EXPORTS = [
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_layerscale_apply_wgrad", "lnx_fill_rows", "lnx_colsum_rows",
-    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_meta_heads_fwd", "lnx_meta_heads_bwd", "lnx_meta_heads_bwd_part_floats", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
     "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_bwd_ws_floats",
     "lnx_plan_create", "lnx_plan_destroy", "lnx_plan_workspace_bytes", "lnx_plan_num_params", "lnx_plan_param_name",
     "lnx_plan_param_numel", "lnx_plan_num_drop_calls", "lnx_plan_logits_numel", "lnx_plan_logits_offset", "lnx_plan_logits_ld",
-    "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end", "lnx_plan_profile_begin_spans", "lnx_plan_profile_end_ex", "lnx_plan_set_wgrad_stream",
+    "lnx_plan_bind", "lnx_plan_forward", "lnx_plan_backward", "lnx_plan_segment_params", "lnx_plan_profile_begin", "lnx_plan_profile_end", "lnx_plan_profile_begin_spans", "lnx_plan_profile_end_ex", "lnx_plan_set_wgrad_stream", "lnx_plan_set_meta_stream",
 ]
+
+
+class MetaHeadArgs(C.Structure):  # == lnx_meta_head_args
+    _fields_ = [
+        ("B", C.c_int), ("C", C.c_int), ("dim", C.c_int), ("off", C.c_int),
+        ("meta", C.c_void_p), ("meta_width", C.c_int), ("eps", C.c_float),
+        ("w0", C.c_void_p), ("ldw0", C.c_int), ("b0", C.c_void_p), ("ln0_w", C.c_void_p), ("ln0_b", C.c_void_p),
+        ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p),
+        ("w2", C.c_void_p), ("ldw2", C.c_int), ("b2", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
+        ("t0", C.c_void_p), ("h0", C.c_void_p), ("x", C.c_void_p), ("h1", C.c_void_p), ("n1", C.c_void_p), ("h2", C.c_void_p),
+        ("m0", C.c_void_p), ("r0", C.c_void_p), ("m1", C.c_void_p), ("r1", C.c_void_p), ("m2", C.c_void_p), ("r2", C.c_void_p),
+        ("tok", C.c_void_p), ("tok_row_stride", C.c_int64), ("tok_row_offset", C.c_int64),
+    ]
+
+
+class MetaHeadBwdArgs(C.Structure):  # == lnx_meta_head_bwd_args
+    _fields_ = [
+        ("B", C.c_int), ("C", C.c_int), ("dim", C.c_int),
+        ("g", C.c_void_p), ("g_row_stride", C.c_int64), ("g_row_offset", C.c_int64),
+        ("w1t", C.c_void_p), ("ldw1t", C.c_int), ("w2t", C.c_void_p), ("ldw2t", C.c_int),
+        ("ln0_w", C.c_void_p), ("ln1_w", C.c_void_p), ("ln2_w", C.c_void_p),
+        ("t0", C.c_void_p), ("h0", C.c_void_p), ("x", C.c_void_p), ("h1", C.c_void_p), ("n1", C.c_void_p), ("h2", C.c_void_p),
+        ("m0", C.c_void_p), ("r0", C.c_void_p), ("m1", C.c_void_p), ("r1", C.c_void_p), ("m2", C.c_void_p), ("r2", C.c_void_p),
+        ("dp2", C.c_void_p), ("dp1", C.c_void_p), ("dp0", C.c_void_p), ("part", C.c_void_p),
+        ("d_w0", C.c_void_p), ("d_b0", C.c_void_p), ("d_ln0_w", C.c_void_p), ("d_ln0_b", C.c_void_p),
+        ("d_w1", C.c_void_p), ("d_b1", C.c_void_p), ("d_ln1_w", C.c_void_p), ("d_ln1_b", C.c_void_p),
+        ("d_w2", C.c_void_p), ("d_b2", C.c_void_p), ("d_ln2_w", C.c_void_p), ("d_ln2_b", C.c_void_p),
+    ]
 
 
 class LnArgs(C.Structure):

@@ -1,0 +1,485 @@
+// Metadata-head chains in one launch per direction (round 5; include/lnx.h: lnx_meta_heads_fwd / lnx_meta_heads_bwd).
+//
+// What it replaces (reference mFormerV1.py:282-311, normalization/res_norm_layer.py:23-30; per metadata component and RoPE stage):
+//     h0 = ReLU(Linear(d, C)(meta[:, off:off+d]));  x = LN0(h0);  tok = x + LN2(ReLU(W2 . LN1(ReLU(W1 . x))))
+// -- until round 4 a chain of 20 fp32 GEMM launches on 128x128 tiles (M = batch rows: two to six tiles each, 46-62 us, matrix pipe 2 %
+// busy), 15 LayerNorm and 12 weight-gradient launches per step, ~2.6 ms of side-stream kernel time for ~0.3 GFLOP.  Here ONE workgroup
+// takes 16 batch rows through the whole chain (the weights, at most 16 MB per matrix, are read from L2 by every workgroup), every head of
+// the model in the same launch; the backward is one launch for the data-gradient chain and one for the weight gradients.
+//
+// Arithmetic: fp32 storage, v_mfma_f32_16x16x4_f32 (an exact fp32 FMA chain), as the chain always ran.  A product tile is computed
+// transposed (first operand = 16 weight rows, second = the 16 activation rows), so lane (c = lane & 15, q = lane >> 4) ends with
+// out[row c][16 tile + 4 q .. 4 q + 3]: float4 loads / stores along the row, LayerNorm row sums = two lane shuffles + one LDS exchange
+// between the eight waves, column sums (LayerNorm weight / bias gradients) = four lane shuffles.  K is walked 16 at a time with a
+// permuted order (MFMA j of a chunk takes k = k0 + 4 q + j from both operands), so each operand chunk is ONE float4 per lane.
+// Nothing is atomic: per-row-group partial column sums go to scratch and are added in a fixed order by the weight-gradient launch,
+// which also owns every `+=` into the gradient arena -- bit-reproducible run to run.
+#include "common.hpp"
+#include "../../include/lnx.h"
+
+namespace {
+
+constexpr int MH_WAVES = 8, MH_THREADS = 512, MH_ROWS = 16;
+constexpr int MH_MAX_HEADS = 4;   // per launch (kernel arguments: 4 x ~300 bytes)
+
+struct FwdBatch {
+    lnx_meta_head_args h[MH_MAX_HEADS];
+};
+struct BwdBatch {
+    lnx_meta_head_bwd_args h[MH_MAX_HEADS];
+    int block_start[MH_MAX_HEADS + 1];  // weight-gradient launch: first block of each head's tasks
+};
+
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(f32x4_t v) { return float4{v[0], v[1], v[2], v[3]}; }
+
+// sum over the lanes that share a row (c = lane & 15), then over the eight waves: every lane returns the full-row sums of its row
+template <int NV>
+__device__ __forceinline__ void row_allreduce(float (&v)[NV], float* red /* [NV][MH_WAVES][16] */, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] += __shfl_xor(v[i], 16);
+        v[i] += __shfl_xor(v[i], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[(i * MH_WAVES + wave) * 16 + lane] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < MH_WAVES; ++w) s += red[(i * MH_WAVES + w) * 16 + (lane & 15)];
+        v[i] = s;
+    }
+    __syncthreads();
+}
+
+// sum over the 16 rows of the workgroup (lanes with equal q): lane c == 0 of each q group ends with the sums
+__device__ __forceinline__ float4 col_reduce(float4 v) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        v.x += __shfl_xor(v.x, m);
+        v.y += __shfl_xor(v.y, m);
+        v.z += __shfl_xor(v.z, m);
+        v.w += __shfl_xor(v.w, m);
+    }
+    return v;
+}
+
+// acc[t] (+)= A[16 rows][K] . W[rows 16 (wave + 8 t) .. +15][K]^T for this wave's ntw tiles.  A rows beyond the batch are clamped by the
+// caller (arow), K % 16 == 0.  One chunk of prefetch: the loads of chunk k+1 are in flight under the MFMAs of chunk k.
+template <int TPW>
+__device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[TPW], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
+                                             int ntw, int wave, int lane) {
+    constexpr int G = TPW < 8 ? TPW : 8;  // tiles whose weight chunks are held (and prefetched) at once: 16 tiles per wave (C = 2048) go in two passes over K
+    const int c = lane & 15, q = lane >> 4;
+    const float* ap = A + (int64_t)arow * lda + 4 * q;
+    const float* wbase = W + (int64_t)(wave * 16 + c) * ldw + 4 * q;
+    const int64_t tstride = (int64_t)MH_WAVES * 16 * ldw;
+#pragma unroll
+    for (int tb = 0; tb < TPW; tb += G) {
+        if (tb >= ntw) break;
+        float4 a_cur = ldf4(ap), w_cur[G];
+#pragma unroll
+        for (int t = 0; t < G; ++t)
+            if (tb + t < ntw) w_cur[t] = ldf4(wbase + (tb + t) * tstride);
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float4 a_nxt = a_cur, w_nxt[G];
+            const bool more = k0 + 16 < K;
+            if (more) a_nxt = ldf4(ap + k0 + 16);
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+                if (tb + t < ntw && more) w_nxt[t] = ldf4(wbase + (tb + t) * tstride + k0 + 16);
+            const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+                if (tb + t < ntw) {
+                    const float wv[4] = {w_cur[t].x, w_cur[t].y, w_cur[t].z, w_cur[t].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[tb + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[tb + t], 0, 0, 0);
+                }
+            a_cur = a_nxt;
+#pragma unroll
+            for (int t = 0; t < G; ++t)
+                if (tb + t < ntw && more) w_cur[t] = w_nxt[t];
+        }
+    }
+}
+
+// One Linear -> ReLU -> LayerNorm step of the chain on registers: acc holds the product; writes h = ReLU(acc + b) (saved for the backward)
+// and y = LN(h) (+ skip) and the row statistics.  Two-pass variance (mean first), as lnx_layernorm_fwd.
+template <int TPW>
+__device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[TPW], int ntw, int wave, int lane, int C, int row, bool valid, const float* __restrict__ bias,
+                                              const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, float* __restrict__ H, float* __restrict__ Y,
+                                              int64_t y_stride, float* __restrict__ mean_out, float* __restrict__ rstd_out, const float* __restrict__ skip, float* red) {
+    const int c = lane & 15, q = lane >> 4;
+    float s[1] = {0.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) {
+            const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
+            const float4 b = ldf4(bias + col);
+            acc[t][0] = fmaxf(acc[t][0] + b.x, 0.f);
+            acc[t][1] = fmaxf(acc[t][1] + b.y, 0.f);
+            acc[t][2] = fmaxf(acc[t][2] + b.z, 0.f);
+            acc[t][3] = fmaxf(acc[t][3] + b.w, 0.f);
+            if (valid && H) stf4(H + (int64_t)row * C + col, f4(acc[t]));
+            s[0] += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+        }
+    row_allreduce<1>(s, red, wave, lane);
+    const float mean = s[0] / (float)C;
+    float v[1] = {0.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[t][r] - mean;
+                v[0] = fmaf(d, d, v[0]);
+            }
+        }
+    row_allreduce<1>(v, red, wave, lane);
+    const float rstd = rsqrtf(v[0] / (float)C + eps);
+    if (valid && wave == 0 && q == 0 && mean_out) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) {
+            const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
+            const float4 g = ldf4(lnw + col), b = ldf4(lnb + col);
+            float4 y;
+            y.x = fmaf((acc[t][0] - mean) * rstd, g.x, b.x);
+            y.y = fmaf((acc[t][1] - mean) * rstd, g.y, b.y);
+            y.z = fmaf((acc[t][2] - mean) * rstd, g.z, b.z);
+            y.w = fmaf((acc[t][3] - mean) * rstd, g.w, b.w);
+            if (skip && valid) {
+                const float4 x = ldf4(skip + (int64_t)row * C + col);
+                y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
+            }
+            if (valid) stf4(Y + (int64_t)row * y_stride + col, y);
+        }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBatch bt) {
+    const lnx_meta_head_args& a = bt.h[blockIdx.y];
+    const int row0 = blockIdx.x * MH_ROWS;
+    if (row0 >= a.B) return;
+    __shared__ float red[2 * MH_WAVES * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15;
+    const int C = a.C;
+    const int ntiles = C / 16;
+    const int ntw = wave < ntiles ? (ntiles - wave + MH_WAVES - 1) / MH_WAVES : 0;
+    const int row = row0 + c;
+    const bool valid = row < a.B;
+    const int arow = valid ? row : a.B - 1;
+    // t0: this component's metadata columns, zero-padded to 16 (lnx_pack_meta's layout; the weight-gradient launch reads it too)
+    if (tid < MH_ROWS * 16) {
+        const int r = tid >> 4, d = tid & 15;
+        if (row0 + r < a.B) a.t0[(int64_t)(row0 + r) * 16 + d] = d < a.dim ? a.meta[(int64_t)(row0 + r) * a.meta_width + a.off + d] : 0.f;
+    }
+    __syncthreads();
+    f32x4_t acc[TPW];
+    auto zero = [&]() {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+    // h0 = ReLU(t0 W0^T + b0), x = LN0(h0)
+    zero();
+    chain_matmul<TPW>(acc, a.t0, 16, arow, a.w0, a.ldw0, 16, ntw, wave, lane);
+    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b0, a.ln0_w, a.ln0_b, a.eps, a.h0, a.x, C, a.m0, a.r0, nullptr, red);
+    __syncthreads();  // x is read back (every wave needs whole rows of it) through this CU's cache
+    // h1 = ReLU(x W1^T + b1), n1 = LN1(h1)
+    zero();
+    chain_matmul<TPW>(acc, a.x, C, arow, a.w1, a.ldw1, C, ntw, wave, lane);
+    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b1, a.ln1_w, a.ln1_b, a.eps, a.h1, a.n1, C, a.m1, a.r1, nullptr, red);
+    __syncthreads();
+    // h2 = ReLU(n1 W2^T + b2), tok = x + LN2(h2) -> the token row of this sample
+    zero();
+    chain_matmul<TPW>(acc, a.n1, C, arow, a.w2, a.ldw2, C, ntw, wave, lane);
+    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b2, a.ln2_w, a.ln2_b, a.eps, a.h2, a.tok + a.tok_row_offset, a.tok_row_stride, a.m2, a.r2, a.x, red);
+}
+
+// LayerNorm backward on registers, followed by the ReLU mask of the Linear in front of the LayerNorm: dy[t] (gradient wrt the LayerNorm
+// output; zero in rows beyond the batch) -> dp = [h > 0] rstd (dy g - mean(dy g) - xhat mean(dy g xhat)), stored to DP; the workgroup's
+// column sums of dy xhat / dy go to part_g / part_b (row group `rg` of [row_groups][C]).
+template <int TPW>
+__device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[TPW], int ntw, int wave, int lane, int C, int row, bool valid, const float* __restrict__ H,
+                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ lnw, float* __restrict__ DP,
+                                            float* __restrict__ part_g, float* __restrict__ part_b, int rg, float* red) {
+    const int c = lane & 15, q = lane >> 4;
+    const float mean = mean_in[row], rstd = rstd_in[row];  // (row is clamped by the caller)
+    float4 xh[TPW];
+    unsigned long long pos = 0ull;  // bit 4 t + r: h > 0 (the ReLU in front of this LayerNorm let the element through)
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) {
+            const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
+            const float4 h = ldf4(H + (int64_t)row * C + col);
+            const float4 g = ldf4(lnw + col);
+            xh[t] = float4{(h.x - mean) * rstd, (h.y - mean) * rstd, (h.z - mean) * rstd, (h.w - mean) * rstd};
+            pos |= (unsigned long long)((h.x > 0.f ? 1u : 0u) | (h.y > 0.f ? 2u : 0u) | (h.z > 0.f ? 4u : 0u) | (h.w > 0.f ? 8u : 0u)) << (4 * t);
+            // column partials first (they take dy itself), then dy <- dy g
+            float4 pg = float4{dy[t][0] * xh[t].x, dy[t][1] * xh[t].y, dy[t][2] * xh[t].z, dy[t][3] * xh[t].w};
+            float4 pb = f4(dy[t]);
+            pg = col_reduce(pg);
+            pb = col_reduce(pb);
+            if (c == 0) {
+                stf4(part_g + (int64_t)rg * C + col, pg);
+                stf4(part_b + (int64_t)rg * C + col, pb);
+            }
+            dy[t][0] *= g.x; dy[t][1] *= g.y; dy[t][2] *= g.z; dy[t][3] *= g.w;
+            s[0] += (dy[t][0] + dy[t][1]) + (dy[t][2] + dy[t][3]);
+            s[1] += (dy[t][0] * xh[t].x + dy[t][1] * xh[t].y) + (dy[t][2] * xh[t].z + dy[t][3] * xh[t].w);
+        }
+    row_allreduce<2>(s, red, wave, lane);
+    const float m1 = s[0] / (float)C, m2 = s[1] / (float)C;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) {
+            const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
+            const unsigned mk = (unsigned)(pos >> (4 * t)) & 15u;
+            float4 o;
+            o.x = (mk & 1u) ? rstd * (dy[t][0] - m1 - xh[t].x * m2) : 0.f;
+            o.y = (mk & 2u) ? rstd * (dy[t][1] - m1 - xh[t].y * m2) : 0.f;
+            o.z = (mk & 4u) ? rstd * (dy[t][2] - m1 - xh[t].z * m2) : 0.f;
+            o.w = (mk & 8u) ? rstd * (dy[t][3] - m1 - xh[t].w * m2) : 0.f;
+            if (valid) stf4(DP + (int64_t)row * C + col, o);
+        }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBatch bt) {
+    const lnx_meta_head_bwd_args& a = bt.h[blockIdx.y];
+    const int row0 = blockIdx.x * MH_ROWS;
+    if (row0 >= a.B) return;
+    __shared__ float red[2 * MH_WAVES * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int C = a.C;
+    const int ntiles = C / 16;
+    const int ntw = wave < ntiles ? (ntiles - wave + MH_WAVES - 1) / MH_WAVES : 0;
+    const int row = row0 + c;
+    const bool valid = row < a.B;
+    const int arow = valid ? row : a.B - 1;
+    const int rg = blockIdx.x, nrg = (a.B + MH_ROWS - 1) / MH_ROWS;
+    float* const part = a.part;  // [6][nrg][C]: dln2_w, dln2_b, dln1_w, dln1_b, dln0_w, dln0_b
+    const int64_t ps = (int64_t)nrg * C;
+    f32x4_t acc[TPW];
+    // tok = x + LN2(h2): the token-row gradient reaches LN2's output and, through the skip, x
+    auto load_dtok = [&](int t) -> f32x4_t {
+        const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
+        if (!valid) return f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const float4 v = ldf4(a.g + (int64_t)row * a.g_row_stride + a.g_row_offset + col);
+        return f32x4_t{v.x, v.y, v.z, v.w};
+    };
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) acc[t] = load_dtok(t);
+    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h2, a.m2, a.r2, a.ln2_w, a.dp2, part + 0 * ps, part + 1 * ps, rg, red);
+    __syncthreads();  // dp2 is read back whole-row by every wave
+    // d n1 = dp2 . W2 (the transposed copy: w2t[i][o]), then LN1 / ReLU backward
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    chain_matmul<TPW>(acc, a.dp2, C, arow, a.w2t, a.ldw2t, C, ntw, wave, lane);
+    if (!valid) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // clamped duplicate rows must not reach the column sums
+    }
+    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h1, a.m1, a.r1, a.ln1_w, a.dp1, part + 2 * ps, part + 3 * ps, rg, red);
+    __syncthreads();
+    // d x = dp1 . W1 + d tok (skip connection of the ResNormLayer), then LN0 / ReLU backward
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+        if (t < ntw) acc[t] = load_dtok(t);
+        else acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    chain_matmul<TPW>(acc, a.dp1, C, arow, a.w1t, a.ldw1t, C, ntw, wave, lane);
+    if (!valid) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h0, a.m0, a.r0, a.ln0_w, a.dp0, part + 4 * ps, part + 5 * ps, rg, red);
+}
+
+// ---- weight gradients: dW[o][i] += sum_m dP[m][o] X[m][i] for the three Linears of each head, their bias gradients (column sums of
+// dP) and the fixed-order sum of the LayerNorm column partials.  One wave = one 64 x 64 block of a dW over all batch rows: per four
+// rows ONE float4 of dP and ONE of X per lane feed 16 MFMAs (tile (tt, uu) pairs component tt of the dP vector with component uu of
+// the X vector: output row o0 + 4 M + tt, column i0 + 4 N + uu).
+__device__ __forceinline__ void wgrad_block(const float* __restrict__ DP, int64_t lddp, int o0, const float* __restrict__ X, int64_t ldx, int i0, int xcols, int B,
+                                            float* __restrict__ dW, int64_t lddw, int store_cols, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool xin = i0 + 4 * c < xcols;  // (the K = 16 first Linear: only lanes c < 4 hold X columns)
+    const float* dp = DP + o0 + 4 * c;
+    const float* xp = X + i0 + 4 * c;
+    auto fetch = [&](int m, float4& d, float4& x) {
+        const bool ok = m < B;
+        d = ok ? ldf4(dp + (int64_t)m * lddp) : float4{0.f, 0.f, 0.f, 0.f};
+        x = (ok && xin) ? ldf4(xp + (int64_t)m * ldx) : float4{0.f, 0.f, 0.f, 0.f};
+    };
+    float4 d_cur, x_cur;
+    fetch(q, d_cur, x_cur);
+    for (int m0 = 0; m0 < B; m0 += 4) {
+        float4 d_nxt, x_nxt;
+        fetch(m0 + 4 + q, d_nxt, x_nxt);
+        const float dv[4] = {d_cur.x, d_cur.y, d_cur.z, d_cur.w}, xv[4] = {x_cur.x, x_cur.y, x_cur.z, x_cur.w};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[tt], xv[uu], acc[tt][uu], 0, 0, 0);
+        d_cur = d_nxt;
+        x_cur = x_nxt;
+    }
+    // lane holds D[M = 4 q + r][N = c] of tile (tt, uu): dW[o0 + 4 (4 q + r) + tt][i0 + 4 c + uu]
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = o0 + 4 * (4 * q + r) + tt;
+            float* dst = dW + (int64_t)o * lddw + i0 + 4 * c;
+            if (store_cols < 0) {
+                float4 v = ldf4(dst);
+                v.x += acc[tt][0][r]; v.y += acc[tt][1][r]; v.z += acc[tt][2][r]; v.w += acc[tt][3][r];
+                stf4(dst, v);
+            } else {
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu)
+                    if (i0 + 4 * c + uu < store_cols) dst[uu] += acc[tt][uu][r];
+            }
+        }
+}
+
+// tasks of one head, in blocks of 256 threads (4 waves): [w2: (C/64)^2 wave tasks][w1: (C/64)^2][w0: C/64] then column tasks (one thread
+// per column: three bias sums and six LayerNorm partial sums)
+__host__ __device__ inline int mh_wave_tasks(int C) { return 2 * (C / 64) * (C / 64) + C / 64; }
+__host__ __device__ inline int mh_wgrad_blocks(int C) { return (mh_wave_tasks(C) + 3) / 4 + (C + 255) / 256; }
+
+__global__ __launch_bounds__(256) void meta_chain_wgrad_kernel(const BwdBatch bt) {
+    int hd = 0;
+#pragma unroll
+    for (int i = 1; i < MH_MAX_HEADS; ++i)
+        if ((int)blockIdx.x >= bt.block_start[i]) hd = i;
+    const lnx_meta_head_bwd_args& a = bt.h[hd];
+    const int blk = (int)blockIdx.x - bt.block_start[hd];
+    const int C = a.C, B = a.B, nb = C / 64;
+    const int wave_blocks = (mh_wave_tasks(C) + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blk < wave_blocks) {
+        int task = blk * 4 + wave;
+        if (task >= mh_wave_tasks(C)) return;
+        if (task < nb * nb) {
+            wgrad_block(a.dp2, C, (task / nb) * 64, a.n1, C, (task % nb) * 64, C, B, a.d_w2, C, -1, lane);
+        } else if (task < 2 * nb * nb) {
+            task -= nb * nb;
+            wgrad_block(a.dp1, C, (task / nb) * 64, a.x, C, (task % nb) * 64, C, B, a.d_w1, C, -1, lane);
+        } else {
+            task -= 2 * nb * nb;
+            wgrad_block(a.dp0, C, task * 64, a.t0, 16, 0, 16, B, a.d_w0, a.dim, a.dim, lane);
+        }
+        return;
+    }
+    const int col = (blk - wave_blocks) * 256 + tid;
+    if (col >= C) return;
+    float s2 = 0.f, s1 = 0.f, s0 = 0.f;
+    for (int m = 0; m < B; ++m) {
+        s2 += a.dp2[(int64_t)m * C + col];
+        s1 += a.dp1[(int64_t)m * C + col];
+        s0 += a.dp0[(int64_t)m * C + col];
+    }
+    a.d_b2[col] += s2;
+    a.d_b1[col] += s1;
+    a.d_b0[col] += s0;
+    const int nrg = (B + MH_ROWS - 1) / MH_ROWS;
+    float* const outs[6] = {a.d_ln2_w, a.d_ln2_b, a.d_ln1_w, a.d_ln1_b, a.d_ln0_w, a.d_ln0_b};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float s = 0.f;
+        for (int g = 0; g < nrg; ++g) s += a.part[((int64_t)k * nrg + g) * C + col];
+        outs[k][col] += s;
+    }
+}
+
+int tpw_of(int C) { return C <= 512 ? 4 : (C <= 1024 ? 8 : 16); }
+
+}  // namespace
+
+extern "C" int64_t lnx_meta_heads_bwd_part_floats(int B, int C) { return 6 * (int64_t)((B + MH_ROWS - 1) / MH_ROWS) * C; }
+
+static int check_head_dims(int B, int C, int dim, const char* who) {
+    LNX_CHECK(B > 0 && C >= 64 && C % 64 == 0 && C <= 2048 && dim >= 1 && dim <= 16, "%s: B=%d C=%d dim=%d (C a multiple of 64 up to 2048, dim 1..16)", who, B, C, dim);
+    return 0;
+}
+
+extern "C" int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, void* stream) {
+    LNX_CHECK(heads != nullptr && n_heads > 0, "lnx_meta_heads_fwd: no heads");
+    for (int i0 = 0; i0 < n_heads; i0 += MH_MAX_HEADS) {
+        const int n = n_heads - i0 < MH_MAX_HEADS ? n_heads - i0 : MH_MAX_HEADS;
+        FwdBatch bt;
+        int maxB = 0, tpw = 4;
+        for (int i = 0; i < n; ++i) {
+            const lnx_meta_head_args& a = heads[i0 + i];
+            if (check_head_dims(a.B, a.C, a.dim, "lnx_meta_heads_fwd")) return 1;
+            LNX_CHECK(a.meta && a.w0 && a.w1 && a.w2 && a.b0 && a.b1 && a.b2 && a.ln0_w && a.ln0_b && a.ln1_w && a.ln1_b && a.ln2_w && a.ln2_b && a.tok,
+                      "lnx_meta_heads_fwd: null operand (head %d)", i0 + i);
+            LNX_CHECK(a.t0 && a.h0 && a.x && a.h1 && a.n1 && a.h2 && a.m0 && a.r0 && a.m1 && a.r1 && a.m2 && a.r2, "lnx_meta_heads_fwd: null activation buffer (head %d)", i0 + i);
+            LNX_CHECK(a.ldw0 >= 16 && a.ldw0 % 4 == 0 && a.ldw1 >= a.C && a.ldw1 % 4 == 0 && a.ldw2 >= a.C && a.ldw2 % 4 == 0 && a.off >= 0 && a.off + a.dim <= a.meta_width,
+                      "lnx_meta_heads_fwd: bad leading dimension / metadata slice (head %d)", i0 + i);
+            LNX_CHECK(a.tok_row_stride % 4 == 0 && a.tok_row_offset % 4 == 0 && ((((uintptr_t)a.tok) | ((uintptr_t)a.w0) | ((uintptr_t)a.w1) | ((uintptr_t)a.w2)) & 15) == 0,
+                      "lnx_meta_heads_fwd: 16-byte alignment (head %d)", i0 + i);
+            bt.h[i] = a;
+            if (a.B > maxB) maxB = a.B;
+            if (tpw_of(a.C) > tpw) tpw = tpw_of(a.C);
+        }
+        const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
+        if (tpw == 4) hipLaunchKernelGGL(meta_chain_fwd_kernel<4>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        else if (tpw == 8) hipLaunchKernelGGL(meta_chain_fwd_kernel<8>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        else hipLaunchKernelGGL(meta_chain_fwd_kernel<16>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        LNX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int lnx_meta_heads_bwd(const lnx_meta_head_bwd_args* heads, int n_heads, void* stream) {
+    LNX_CHECK(heads != nullptr && n_heads > 0, "lnx_meta_heads_bwd: no heads");
+    for (int i0 = 0; i0 < n_heads; i0 += MH_MAX_HEADS) {
+        const int n = n_heads - i0 < MH_MAX_HEADS ? n_heads - i0 : MH_MAX_HEADS;
+        BwdBatch bt;
+        int maxB = 0, tpw = 4, blocks = 0;
+        for (int i = 0; i < MH_MAX_HEADS + 1; ++i) bt.block_start[i] = 0x7fffffff;
+        for (int i = 0; i < n; ++i) {
+            const lnx_meta_head_bwd_args& a = heads[i0 + i];
+            if (check_head_dims(a.B, a.C, a.dim, "lnx_meta_heads_bwd")) return 1;
+            LNX_CHECK(a.g && a.w1t && a.w2t && a.ln0_w && a.ln1_w && a.ln2_w && a.t0 && a.h0 && a.x && a.h1 && a.n1 && a.h2 && a.m0 && a.r0 && a.m1 && a.r1 && a.m2 && a.r2,
+                      "lnx_meta_heads_bwd: null operand (head %d)", i0 + i);
+            LNX_CHECK(a.dp2 && a.dp1 && a.dp0 && a.part && a.d_w0 && a.d_b0 && a.d_ln0_w && a.d_ln0_b && a.d_w1 && a.d_b1 && a.d_ln1_w && a.d_ln1_b && a.d_w2 && a.d_b2 && a.d_ln2_w && a.d_ln2_b,
+                      "lnx_meta_heads_bwd: null scratch / gradient buffer (head %d)", i0 + i);
+            LNX_CHECK(a.ldw1t >= a.C && a.ldw1t % 4 == 0 && a.ldw2t >= a.C && a.ldw2t % 4 == 0 && a.g_row_stride % 4 == 0 && a.g_row_offset % 4 == 0 &&
+                          ((((uintptr_t)a.g) | ((uintptr_t)a.w1t) | ((uintptr_t)a.w2t) | ((uintptr_t)a.d_w1) | ((uintptr_t)a.d_w2)) & 15) == 0,
+                      "lnx_meta_heads_bwd: leading dimensions / 16-byte alignment (head %d)", i0 + i);
+            bt.h[i] = a;
+            bt.block_start[i] = blocks;
+            blocks += mh_wgrad_blocks(a.C);
+            if (a.B > maxB) maxB = a.B;
+            if (tpw_of(a.C) > tpw) tpw = tpw_of(a.C);
+        }
+        const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
+        if (tpw == 4) hipLaunchKernelGGL(meta_chain_bwd_kernel<4>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        else if (tpw == 8) hipLaunchKernelGGL(meta_chain_bwd_kernel<8>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        else hipLaunchKernelGGL(meta_chain_bwd_kernel<16>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        LNX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(meta_chain_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+        LNX_LAUNCH_CHECK();
+    }
+    return 0;
+}

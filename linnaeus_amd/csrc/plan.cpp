@@ -76,6 +76,7 @@ struct MetaHead {
     OpW w0, w1, w2;
     int dim, off;
     int64_t t0, h0, x, m0, r0, h1, n1, m1, r1, h2, m2, r2;
+    int64_t dp2 = 0, dp1 = 0, dp0 = 0, part = 0;  // one-launch chain (metahead.hip): backward scratch of this head
 };
 struct Down {
     int lnw, lnb, cb;
@@ -160,6 +161,9 @@ struct lnx_plan {
     // The kernels do not share CUs (one workgroup per CU by LDS) -- what overlaps is one kernel's ramp and tail with the other's body.
     hipStream_t wgs = nullptr;
     bool wgs_on = true;
+    bool meta_forked[2] = {false, false};  // backward: stage s's metadata heads were forked off the launch stream and not joined yet
+    int meta_mode = 1;       // which stream the metadata heads run on: 0 launch stream, 1 their own side stream, 2 the weight-gradient stream (lnx_plan_set_meta_stream)
+    bool meta_chain = true;  // metadata heads as one launch per direction (metahead.hip); LNX_META_CHAIN=0: the round-1 chain of GEMM / LayerNorm launches (A/B)
     bool dy8_ready = false;  // backward, fp8 plans: o_a8 / o_a8s hold the MXFP8 copy of the dY in sC (written by the LayerNorm backward that wrote sC)
     hipEvent_t ev_wf[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wj[4] = {nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
@@ -337,6 +341,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     lnx_plan* p = new lnx_plan();
     p->c = c;
     p->esz = c.dtype == LNX_BF16 ? 2 : 4;
+    p->meta_chain = !(getenv("LNX_META_CHAIN") && atoi(getenv("LNX_META_CHAIN")) == 0);
     p->E = 1 + c.n_meta;
     p->H[0] = c.img_h / 4;
     p->W[0] = c.img_w / 4;
@@ -634,6 +639,12 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.h2 = cv.take((int64_t)B * C * 4);
             k.m2 = cv.take(B * 4);
             k.r2 = cv.take(B * 4);
+            if (!inf && p->meta_chain) {  // the heads of a stage run side by side in one launch: scratch per head
+                k.dp2 = cv.take((int64_t)B * C * 4);
+                k.dp1 = cv.take((int64_t)B * C * 4);
+                k.dp0 = cv.take((int64_t)B * C * 4);
+                k.part = cv.take(lnx_meta_heads_bwd_part_floats(B, (int)C) * 4);
+            }
         }
     }
     {
@@ -877,6 +888,8 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
             if (w->f32) push_w(w);
     p->n_descs_f = (int64_t)d.size() - p->n_descs_t;
     p->prep_blocks_f = blk;
+    if (getenv("LNX_NO_SIDE_STREAM") != nullptr) p->meta_mode = 0;
+    if (const char* e = getenv("LNX_META_STREAM")) p->meta_mode = atoi(e) < 0 || atoi(e) > 2 ? 1 : atoi(e);
     if (p->side == nullptr && p->c.n_meta > 0 && getenv("LNX_NO_SIDE_STREAM") == nullptr) {
         p->side = shared_stream(0);
         if (!p->side) FAIL("lnx_plan: no side stream");
@@ -906,6 +919,15 @@ extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* con
 // launch helpers
 // ------------------------------------------------------------------------------------
 namespace {
+
+// the stream the metadata heads run on beside the launch stream, nullptr = on the launch stream itself (lnx_plan_set_meta_stream)
+hipStream_t meta_stream(const lnx_plan* p) {
+    if (p->c.n_meta <= 0 || p->meta_mode == 0) return nullptr;
+    // the weight-gradient stream only carries the one-launch chain: the launch-by-launch chain shares scratch with the launch stream's kernels
+    // unless it runs on `side` (ln_bwd / wgrad_to below)
+    if (p->meta_mode == 2 && p->meta_chain && p->wgs != nullptr) return p->wgs;
+    return p->side;
+}
 
 struct Ctx {
     lnx_plan* p;
@@ -1187,6 +1209,51 @@ int meta_head_fwd(const Ctx& cc, int s, int m, const float* meta, int meta_width
     return 0;
 }
 
+// All metadata heads of the given stages in one launch (metahead.hip): the chain meta_head_fwd spells out launch by launch
+int meta_chain_fwd(const Ctx& c, int s_lo, int s_hi, const float* meta, int meta_width) {
+    lnx_plan* p = c.p;
+    lnx_meta_head_args a[2 * LNX_MAX_META];
+    int n = 0;
+    for (int s = s_lo; s < s_hi; ++s)
+        for (int m = 0; m < p->c.n_meta; ++m) {
+            MetaHead& k = p->meta[s][m];
+            const int C = p->c.dims[2 + s], N = s == 0 ? p->N2 : p->N3;
+            lnx_meta_head_args& h = a[n++];
+            memset(&h, 0, sizeof h);
+            h.B = p->c.batch; h.C = C; h.dim = k.dim; h.off = k.off; h.meta = meta; h.meta_width = meta_width; h.eps = 1e-5f;
+            h.w0 = (const float*)c.wptr(k.w0); h.ldw0 = k.w0.ld; h.b0 = p->P[k.b0]; h.ln0_w = p->P[k.lnw0]; h.ln0_b = p->P[k.lnb0];
+            h.w1 = (const float*)c.wptr(k.w1); h.ldw1 = k.w1.ld; h.b1 = p->P[k.b1]; h.ln1_w = p->P[k.nf1w]; h.ln1_b = p->P[k.nf1b];
+            h.w2 = (const float*)c.wptr(k.w2); h.ldw2 = k.w2.ld; h.b2 = p->P[k.b2]; h.ln2_w = p->P[k.nf2w]; h.ln2_b = p->P[k.nf2b];
+            h.t0 = c.at<float>(k.t0); h.h0 = c.at<float>(k.h0); h.x = c.at<float>(k.x); h.h1 = c.at<float>(k.h1); h.n1 = c.at<float>(k.n1); h.h2 = c.at<float>(k.h2);
+            h.m0 = c.at<float>(k.m0); h.r0 = c.at<float>(k.r0); h.m1 = c.at<float>(k.m1); h.r1 = c.at<float>(k.r1); h.m2 = c.at<float>(k.m2); h.r2 = c.at<float>(k.r2);
+            h.tok = c.at<float>(p->o_tok[s]); h.tok_row_stride = (int64_t)N * C; h.tok_row_offset = (int64_t)(1 + m) * C;
+        }
+    return n ? lnx_meta_heads_fwd(a, n, c.st) : 0;
+}
+
+// ... and their backward for one stage: g = gradient of the stage's token matrix [B N, C]
+int meta_chain_bwd(const Ctx& c, int s, const float* g) {
+    lnx_plan* p = c.p;
+    lnx_meta_head_bwd_args a[LNX_MAX_META];
+    const int C = p->c.dims[2 + s], N = s == 0 ? p->N2 : p->N3;
+    for (int m = 0; m < p->c.n_meta; ++m) {
+        MetaHead& k = p->meta[s][m];
+        lnx_meta_head_bwd_args& h = a[m];
+        memset(&h, 0, sizeof h);
+        h.B = p->c.batch; h.C = C; h.dim = k.dim;
+        h.g = g; h.g_row_stride = (int64_t)N * C; h.g_row_offset = (int64_t)(1 + m) * C;
+        h.w1t = (const float*)c.wtptr(k.w1); h.ldw1t = k.w1.ld_t; h.w2t = (const float*)c.wtptr(k.w2); h.ldw2t = k.w2.ld_t;
+        h.ln0_w = p->P[k.lnw0]; h.ln1_w = p->P[k.nf1w]; h.ln2_w = p->P[k.nf2w];
+        h.t0 = c.at<float>(k.t0); h.h0 = c.at<float>(k.h0); h.x = c.at<float>(k.x); h.h1 = c.at<float>(k.h1); h.n1 = c.at<float>(k.n1); h.h2 = c.at<float>(k.h2);
+        h.m0 = c.at<float>(k.m0); h.r0 = c.at<float>(k.r0); h.m1 = c.at<float>(k.m1); h.r1 = c.at<float>(k.r1); h.m2 = c.at<float>(k.m2); h.r2 = c.at<float>(k.r2);
+        h.dp2 = c.at<float>(k.dp2); h.dp1 = c.at<float>(k.dp1); h.dp0 = c.at<float>(k.dp0); h.part = c.at<float>(k.part);
+        h.d_w0 = p->G[k.w0.param]; h.d_b0 = p->G[k.b0]; h.d_ln0_w = p->G[k.lnw0]; h.d_ln0_b = p->G[k.lnb0];
+        h.d_w1 = p->G[k.w1.param]; h.d_b1 = p->G[k.b1]; h.d_ln1_w = p->G[k.nf1w]; h.d_ln1_b = p->G[k.nf1b];
+        h.d_w2 = p->G[k.w2.param]; h.d_b2 = p->G[k.b2]; h.d_ln2_w = p->G[k.nf2w]; h.d_ln2_b = p->G[k.nf2b];
+    }
+    return p->c.n_meta ? lnx_meta_heads_bwd(a, p->c.n_meta, c.st) : 0;
+}
+
 // forward FLOPs of one RoPE2DMHSABlock: qkv + proj + fc1 + fc2 products and the two attention products (SURVEY 8d's count)
 double rope_block_flops(int B, int N, int C, int hid, int heads) {
     const double M = (double)B * N;
@@ -1291,13 +1358,18 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
     // metadata heads of both RoPE stages: forked onto the side stream right after the weight refresh
     int mw_all = 0;
     for (int m = 0; m < cf.n_meta; ++m) mw_all += cf.meta_dims[m];
-    if (p->side && cf.n_meta > 0) {
+    hipStream_t const mst = meta_stream(p);
+    if (mst) {
         HIPRUN(hipEventRecord(p->ev_fork, (hipStream_t)stream));
-        HIPRUN(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-        Ctx cs{p, (void*)p->side, cf.dtype};
-        for (int s2 = 0; s2 < 2; ++s2)
-            for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(cs, s2, m, meta, mw_all, c.at<float>(p->o_tok[s2]), s2 == 0 ? p->N2 : p->N3));
-        HIPRUN(hipEventRecord(p->ev_meta, p->side));
+        HIPRUN(hipStreamWaitEvent(mst, p->ev_fork, 0));
+        Ctx cs{p, (void*)mst, cf.dtype};
+        if (p->meta_chain) {
+            RUN(meta_chain_fwd(cs, 0, 2, meta, mw_all));  // every head of both stages: one launch
+        } else {
+            for (int s2 = 0; s2 < 2; ++s2)
+                for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(cs, s2, m, meta, mw_all, c.at<float>(p->o_tok[s2]), s2 == 0 ? p->N2 : p->N3));
+        }
+        HIPRUN(hipEventRecord(p->ev_meta, mst));
     }
 
     // 1. stem: 4x4/4 patchify conv as im2col + GEMM, then channels-first LN (mFormerV1.py:145-148)
@@ -1347,8 +1419,10 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         float* tok = c.at<float>(p->o_tok[s]);
         const lnx_rowmap clsmap = {1, N - 1, 0};
         RUN(lnx_fill_rows(p->P[p->cls[s]], tok, C, clsmap, B, C, stream));
-        if (p->side && cf.n_meta > 0) {
+        if (mst) {
             if (s == 0) HIPRUN(hipStreamWaitEvent((hipStream_t)stream, p->ev_meta, 0));  // join: all meta tokens written
+        } else if (p->meta_chain) {
+            RUN(meta_chain_fwd(c, s, s + 1, meta, mw_all));
         } else {
             for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(c, s, m, meta, mw_all, tok, N));
         }
@@ -1668,13 +1742,19 @@ int tokens_bwd(const Ctx& c, int s, const float* g) {
     const int B = p->c.batch, C = p->c.dims[2 + s], N = s == 0 ? p->N2 : p->N3;
     const lnx_rowmap clsmap = {1, N - 1, 0};
     RUN(lnx_colsum_rows(g, C, clsmap, p->G[p->cls[s]], B, C, c.st));
-    if (p->side && p->c.n_meta > 0) {
+    hipStream_t const mst = meta_stream(p);
+    p->meta_forked[s] = mst != nullptr;
+    if (mst) {
         // fork: the metadata-head backward only reads g; joined at the end of the segment (join_side)
         HIPRUN(hipEventRecord(p->ev_bfork[s], (hipStream_t)c.st));
-        HIPRUN(hipStreamWaitEvent(p->side, p->ev_bfork[s], 0));
-        const Ctx cs{p, (void*)p->side, c.dt};
-        for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(cs, s, m, g, N));
-        HIPRUN(hipEventRecord(p->ev_bjoin[s], p->side));
+        HIPRUN(hipStreamWaitEvent(mst, p->ev_bfork[s], 0));
+        const Ctx cs{p, (void*)mst, c.dt};
+        if (p->meta_chain) RUN(meta_chain_bwd(cs, s, g));
+        else
+            for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(cs, s, m, g, N));
+        HIPRUN(hipEventRecord(p->ev_bjoin[s], mst));
+    } else if (p->meta_chain) {
+        RUN(meta_chain_bwd(c, s, g));
     } else {
         for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(c, s, m, g, N));
     }
@@ -1702,7 +1782,10 @@ int rope_block_restore(const Ctx& c, int s, int i) {
 
 int join_side(const Ctx& c, int s) {
     lnx_plan* p = c.p;
-    if (p->side && p->c.n_meta > 0) HIPRUN(hipStreamWaitEvent((hipStream_t)c.st, p->ev_bjoin[s], 0));
+    if (p->meta_forked[s]) {  // (what tokens_bwd(s) did, whatever the mode has been switched to since)
+        HIPRUN(hipStreamWaitEvent((hipStream_t)c.st, p->ev_bjoin[s], 0));
+        p->meta_forked[s] = false;
+    }
     return 0;
 }
 
@@ -1883,6 +1966,17 @@ extern "C" int lnx_plan_set_wgrad_stream(lnx_plan* p, int on) {
     const int was = wg_on(p) ? 1 : 0;
     if (p->wgs) (void)hipStreamSynchronize(p->wgs);  // (every block joins before it returns: nothing is pending unless a call failed half-way)
     p->wgs_on = on != 0;
+    return was;
+}
+
+extern "C" int lnx_plan_set_meta_stream(lnx_plan* p, int mode) {
+    if (!p || mode < 0 || mode > 2) {
+        lnx_set_error("lnx_plan_set_meta_stream: null plan / mode %d (0 launch stream, 1 side stream, 2 weight-gradient stream)", mode);
+        return -1;
+    }
+    const int was = p->meta_mode;
+    if (mode == 1 && p->side == nullptr) mode = 0;  // LNX_NO_SIDE_STREAM: the side stream was never created
+    p->meta_mode = mode;
     return was;
 }
 

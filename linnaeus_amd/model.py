@@ -346,6 +346,17 @@ class mFormerV1(nn.Module):
             if st.get("handle") is not None and L.lib().lnx_plan_set_wgrad_stream(st["handle"], int(self._wgrad_stream)) < 0:
                 L.check(1, "lnx_plan_set_wgrad_stream")
 
+    def set_meta_stream(self, mode: int) -> None:
+        """Which stream the metadata-head chains run on beside the launch stream (include/lnx.h lnx_plan_set_meta_stream): 0 the launch stream,
+        1 a side stream of their own (default), 2 the weight-gradient stream -- one stream fewer, for steps that share the device's
+        hardware queues with a collective library's stream (DataParallel asks for 2)."""
+        if mode not in (0, 1, 2):
+            raise ValueError(f"meta stream mode {mode!r}: 0 (launch stream), 1 (side stream) or 2 (weight-gradient stream)")
+        self._meta_stream = int(mode)
+        for st in self._plans.values():
+            if st.get("handle") is not None and L.lib().lnx_plan_set_meta_stream(st["handle"], self._meta_stream) < 0:
+                L.check(1, "lnx_plan_set_meta_stream")
+
     def _destroy_plan(self, st) -> None:
         if st.get("destroyed"):
             return
@@ -481,6 +492,8 @@ class mFormerV1(nn.Module):
             L.check(lib.lnx_plan_create(C.byref(cfg), C.byref(handle)), "lnx_plan_create")
             if not getattr(self, "_wgrad_stream", True) and lib.lnx_plan_set_wgrad_stream(handle, 0) < 0:
                 L.check(1, "lnx_plan_set_wgrad_stream")
+            if getattr(self, "_meta_stream", None) is not None and lib.lnx_plan_set_meta_stream(handle, self._meta_stream) < 0:
+                L.check(1, "lnx_plan_set_meta_stream")
             lib.lnx_plan_workspace_bytes.restype = C.c_int64
             lib.lnx_plan_param_name.restype = C.c_char_p
             lib.lnx_plan_param_numel.restype = C.c_int64

@@ -332,3 +332,63 @@ def convmlp_bwd(g, ln, z, w1, b1, w2t, w1t, gamma, act, dh, dz, dln, dgamma, *, 
     a.ws, a.ws_floats = _p(ws), (ws.numel() if ws is not None else 0)
     a.dz_plain = int(dz_plain)
     L.check(L.lib().lnx_convmlp_bwd(C.byref(a), _stream()), "lnx_convmlp_bwd")
+
+
+# ---- metadata-head chains in one launch per direction (metahead.hip; reference mFormerV1.py:282-311, res_norm_layer.py:23-30) ----
+def _meta_head_buffers(B, C_, dev):
+    f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
+    return {"t0": f(B, 16), "h0": f(B, C_), "x": f(B, C_), "h1": f(B, C_), "n1": f(B, C_), "h2": f(B, C_),
+            "m0": f(B), "r0": f(B), "m1": f(B), "r1": f(B), "m2": f(B), "r2": f(B)}
+
+
+def meta_heads_fwd(meta, heads, tok, eps=1e-5):
+    """heads: list of dicts with `off`, `dim`, `slot` (token row of a sample, 1 + m) and the parameters `w0` [C, dim], `b0`, `ln0_w`, `ln0_b`,
+    `w1`, `b1`, `ln1_w`, `ln1_b`, `w2`, `b2`, `ln2_w`, `ln2_b`.  tok: [B, N, C] fp32, row `slot` of every sample is written.
+    Returns the per-head activation dicts the backward needs."""
+    B = meta.shape[0]
+    arr = (L.MetaHeadArgs * len(heads))()
+    keep, saved = [], []
+    for i, h in enumerate(heads):
+        C_ = h["w1"].shape[0]
+        w0p = torch.zeros(C_, 16, device=meta.device)
+        w0p[:, :h["dim"]] = h["w0"]
+        bufs = _meta_head_buffers(B, C_, meta.device)
+        t = tok[i] if isinstance(tok, (list, tuple)) else tok
+        a = arr[i]
+        a.B, a.C, a.dim, a.off, a.meta, a.meta_width, a.eps = B, C_, h["dim"], h["off"], _p(meta), meta.shape[1], eps
+        a.w0, a.ldw0, a.b0, a.ln0_w, a.ln0_b = _p(w0p), 16, _p(h["b0"]), _p(h["ln0_w"]), _p(h["ln0_b"])
+        a.w1, a.ldw1, a.b1, a.ln1_w, a.ln1_b = _p(h["w1"]), C_, _p(h["b1"]), _p(h["ln1_w"]), _p(h["ln1_b"])
+        a.w2, a.ldw2, a.b2, a.ln2_w, a.ln2_b = _p(h["w2"]), C_, _p(h["b2"]), _p(h["ln2_w"]), _p(h["ln2_b"])
+        for k_, v in bufs.items():
+            setattr(a, k_, _p(v))
+        a.tok, a.tok_row_stride, a.tok_row_offset = _p(t), t.shape[1] * C_, h["slot"] * C_
+        keep.append(w0p)
+        saved.append(bufs)
+    L.check(L.lib().lnx_meta_heads_fwd(arr, len(heads), _stream()), "lnx_meta_heads_fwd")
+    return saved
+
+
+def meta_heads_bwd(g, heads, saved, grads):
+    """g: [B, N, C] gradient of the token matrix (or a list, one per head); grads: per head a dict of fp32 tensors (torch layouts) that are ADDED to."""
+    arr = (L.MetaHeadBwdArgs * len(heads))()
+    keep = []
+    for i, (h, sv, gr) in enumerate(zip(heads, saved, grads)):
+        C_ = h["w1"].shape[0]
+        gi = g[i] if isinstance(g, (list, tuple)) else g
+        B = gi.shape[0]
+        w1t, w2t = h["w1"].t().contiguous(), h["w2"].t().contiguous()
+        dp = [torch.empty(B, C_, device=gi.device) for _ in range(3)]
+        part = torch.empty(L.lib().lnx_meta_heads_bwd_part_floats(B, C_), device=gi.device)
+        a = arr[i]
+        a.B, a.C, a.dim = B, C_, h["dim"]
+        a.g, a.g_row_stride, a.g_row_offset = _p(gi), gi.shape[1] * C_, h["slot"] * C_
+        a.w1t, a.ldw1t, a.w2t, a.ldw2t = _p(w1t), C_, _p(w2t), C_
+        a.ln0_w, a.ln1_w, a.ln2_w = _p(h["ln0_w"]), _p(h["ln1_w"]), _p(h["ln2_w"])
+        for k_, v in sv.items():
+            setattr(a, k_, _p(v))
+        a.dp2, a.dp1, a.dp0, a.part = _p(dp[0]), _p(dp[1]), _p(dp[2]), _p(part)
+        for k_ in ("w0", "b0", "ln0_w", "ln0_b", "w1", "b1", "ln1_w", "ln1_b", "w2", "b2", "ln2_w", "ln2_b"):
+            setattr(a, "d_" + k_, _p(gr[k_]))
+        keep += [w1t, w2t, part] + dp
+    L.check(L.lib().lnx_meta_heads_bwd(arr, len(heads), _stream()), "lnx_meta_heads_bwd")
+    torch.cuda.current_stream().synchronize()  # (the scratch tensors above die with this frame)

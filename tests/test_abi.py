@@ -49,7 +49,7 @@ def test_ctypes_mirrors_have_the_sizes_the_c_compiler_gives(tmp_path):
         "lnx_dwconv_args": L.DwconvArgs, "lnx_dwconv_wgrad_args": L.DwconvWgradArgs, "lnx_attn_args": L.AttnArgs, "lnx_attn_bwd_args": L.AttnBwdArgs,
         "lnx_prep_desc": L.PrepDesc, "lnx_softce_args": L.SoftCEArgs, "lnx_mix_args": L.MixArgs, "lnx_adamw_desc": L.AdamWDesc,
         "lnx_adamw_hyper": L.AdamWHyper, "lnx_convmlp_args": L.ConvMlpArgs, "lnx_convmlp_bwd_args": L.ConvMlpBwdArgs,
-        "lnx_mformer_cfg": _Cfg,
+        "lnx_mformer_cfg": _Cfg, "lnx_meta_head_args": L.MetaHeadArgs, "lnx_meta_head_bwd_args": L.MetaHeadBwdArgs,
     }
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "lnx.h"\nint main(void) {\n' +

@@ -816,3 +816,69 @@ def test_fused_stem_matches_conv_and_layernorm(B, Cin, H, W, Cout):
     y2 = torch.empty_like(y)
     ops.stem_fwd(x, wq, bias, lw, lb, y2)  # inference form: nothing but y
     assert torch.equal(y, y2)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Round 5: metadata-head chains in one launch per direction (metahead.hip) against torch autograd on the reference's chain
+# (mFormerV1.py:282-311: Linear -> ReLU -> LayerNorm -> ResNormLayer; res_norm_layer.py:23-30)
+# ----------------------------------------------------------------------------------------------------
+def _meta_head_params(C, dim, gen, dev="cuda"):
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(dev)  # noqa: E731
+    return {"w0": r(C, dim, sc=0.7), "b0": r(C, sc=0.3), "ln0_w": 1 + r(C, sc=0.2), "ln0_b": r(C, sc=0.2),
+            "w1": r(C, C, sc=C ** -0.5), "b1": r(C, sc=0.3), "ln1_w": 1 + r(C, sc=0.2), "ln1_b": r(C, sc=0.2),
+            "w2": r(C, C, sc=C ** -0.5), "b2": r(C, sc=0.3), "ln2_w": 1 + r(C, sc=0.2), "ln2_b": r(C, sc=0.2)}
+
+
+def _meta_head_reference(meta, h):
+    F = torch.nn.functional
+    C = h["w1"].shape[0]
+    p = {k: v.double().requires_grad_(True) for k, v in h.items() if torch.is_tensor(v)}
+    t = meta.double()[:, h["off"]:h["off"] + h["dim"]]
+    x = F.layer_norm(F.relu(t @ p["w0"].t() + p["b0"]), (C,), p["ln0_w"], p["ln0_b"], 1e-5)
+    n1 = F.layer_norm(F.relu(x @ p["w1"].t() + p["b1"]), (C,), p["ln1_w"], p["ln1_b"], 1e-5)
+    y = x + F.layer_norm(F.relu(n1 @ p["w2"].t() + p["b2"]), (C,), p["ln2_w"], p["ln2_b"], 1e-5)
+    return y, p
+
+
+@pytest.mark.parametrize("B,cfg", [(256, [(384, 2, 0), (384, 3, 2), (768, 2, 0), (768, 3, 2)]), (24, [(768, 3, 2)]), (5, [(128, 10, 5), (256, 2, 0)]),
+                                   (130, [(1024, 3, 2), (2048, 2, 0)]), (33, [(1536, 10, 5), (128, 1, 4), (192 * 4, 16, 0), (64, 2, 0), (2048, 3, 2)])])
+def test_meta_head_chain_one_launch_matches_autograd(B, cfg):
+    """lnx_meta_heads_fwd / lnx_meta_heads_bwd: several heads of different widths in one call (sm's four heads at the benchmark's batch; lg / xl
+    widths incl. C = 2048 with 16 tiles per wave; more than four heads = two launches; partial last row group; dim up to 16) against fp64
+    autograd of the reference chain.  fp32 arithmetic: tokens to 2e-5, every gradient to 1e-4 of its scale; gradients ACCUMULATE onto what the
+    buffers held; rows of the token matrix that belong to other tokens are untouched; two runs are bit-identical (no atomics)."""
+    gen = g(B * 131 + len(cfg))
+    meta = torch.randn(B, 16, generator=gen).cuda()
+    N = 7
+    heads, toks = [], []
+    for i, (C, dim, off) in enumerate(cfg):
+        h = _meta_head_params(C, dim, gen)
+        h.update(dim=dim, off=off, slot=1 + i % (N - 1))
+        heads.append(h)
+        toks.append(torch.full((B, N, C), 7.0, device="cuda"))
+    saved = ops.meta_heads_fwd(meta, heads, toks)
+    torch.cuda.synchronize()
+    gouts, refs = [], []
+    for h, tok in zip(heads, toks):
+        y, p = _meta_head_reference(meta, h)
+        got = tok[:, h["slot"]]
+        torch.testing.assert_close(got.double(), y.detach(), rtol=2e-5, atol=2e-5 * max(1.0, y.abs().max().item()))
+        other = torch.ones(N, dtype=torch.bool)
+        other[h["slot"]] = False
+        assert (tok[:, other] == 7.0).all()
+        gout = torch.randn(B, N, h["w1"].shape[0], generator=gen).cuda()
+        (y * gout[:, h["slot"]].double()).sum().backward()
+        gouts.append(gout)
+        refs.append(p)
+    keys = ("w0", "b0", "ln0_w", "ln0_b", "w1", "b1", "ln1_w", "ln1_b", "w2", "b2", "ln2_w", "ln2_b")
+    runs = []
+    for _ in range(2):
+        grads = [{k: torch.full_like(h[k], 0.5) for k in keys} for h in heads]
+        ops.meta_heads_bwd(gouts, heads, saved, grads)
+        runs.append(grads)
+    for h, gr, gr2, p in zip(heads, runs[0], runs[1], refs):
+        for k in keys:
+            ref = p[k].grad
+            scale = max(1e-3, ref.abs().max().item())
+            torch.testing.assert_close((gr[k] - 0.5).double(), ref, rtol=1e-4, atol=1e-4 * scale, msg=lambda m, k=k, C=h["w1"].shape[0]: f"{k} (C={C}): {m}")
+            assert torch.equal(gr[k], gr2[k]), k
