@@ -106,6 +106,10 @@ enum { LNX_NT_KERNEL_NONE = 0, LNX_NT_KERNEL_V1 = 1 /* 128x128 register-staged, 
        LNX_NT_KERNEL_EXPERIMENT = 15 /* a kernel of tools/experiments/ (never in the shipped library) */, LNX_NT_KERNEL_KINDS = 16 };
 int lnx_last_nt_kernel(void);
 int64_t lnx_nt_kernel_launches(int kind);
+/* The family lnx_gemm_nt WOULD launch for these arguments (no launch, no device work, no GPU needed; negative on bad arguments): only
+ * M / N / K / dtype / out_f32 / act / a_mode / c_mode and WHICH optional operands are non-NULL are looked at, never the memory behind
+ * them.  DESIGN.md's dispatch table is checked against this by tests/test_host_logic.py. */
+int lnx_nt_dispatch(const lnx_gemm_args* args);
 
 /* fp8 operands (BASELINE config 5's "fp8 MFMA path"; the reference has no fp8 code: this is the MI355X form of its
  * bf16 Linear, mlp.py:46-66 / rope_2d_mhsa.py:432,500).  OCP e4m3fn storage, one dequantisation scale per tensor:
@@ -404,7 +408,7 @@ int lnx_pack_meta(const float* meta, int width, int off, int dim, void* out, int
  * All buffers are the caller's (no allocation, no host synchronisation); rows are 16-byte aligned.
  * ------------------------------------------------------------------------------------ */
 typedef struct lnx_meta_head_args {
-    int B, C;                 /* batch rows; width of the RoPE stage this head feeds (a multiple of 64, <= 2048) */
+    int B, C;                 /* batch rows; width of the RoPE stage this head feeds: lnx_meta_heads_supported(C), i.e. C / 128 in {1, 2, 3, 4, 6, 8} */
     int dim, off;             /* this component's input width (1..16) and its first column in `meta` */
     const float* meta;        /* [B, meta_width] */
     int meta_width;
@@ -426,6 +430,8 @@ typedef struct lnx_meta_head_args {
     float* tok;
     int64_t tok_row_stride, tok_row_offset;
 } lnx_meta_head_args;
+/* 1 when the one-launch chain carries this width (heads of one call may have different widths: a launch per run of equal ones) */
+int lnx_meta_heads_supported(int C);
 int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, void* stream);
 
 typedef struct lnx_meta_head_bwd_args {

@@ -122,12 +122,12 @@ NT_KERNEL_NONE, NT_KERNEL_V1, NT_KERNEL_V2, NT_KERNEL_SKINNY, NT_KERNEL_V4, NT_K
 # every symbol include/lnx.h declares (kept in sync by tests/test_abi.py)
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus", "lnx_set_cu_margin",
-    "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_gemm_tn_discard", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
+    "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_nt_dispatch", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_gemm_tn_discard", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_layerscale_apply_wgrad", "lnx_fill_rows", "lnx_colsum_rows",
-    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_meta_heads_fwd", "lnx_meta_heads_bwd", "lnx_meta_heads_bwd_part_floats", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
+    "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_meta_heads_supported", "lnx_meta_heads_fwd", "lnx_meta_heads_bwd", "lnx_meta_heads_bwd_part_floats", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
     "lnx_aug_pointwise", "lnx_aug_saturation", "lnx_aug_rowstat", "lnx_aug_rescale", "lnx_aug_affine", "lnx_aug_stencil", "lnx_erase_rects", "lnx_u8hwc_to_f32chw",
     "lnx_convmlp_supported", "lnx_convmlp_fwd", "lnx_convmlp_bwd", "lnx_convmlp_bwd_ws_floats",

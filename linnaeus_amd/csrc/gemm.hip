@@ -348,6 +348,46 @@ extern "C" int64_t lnx_nt_kernel_launches(int kind) {
     return (kind < 0 || kind >= LNX_NT_KERNEL_KINDS) ? -1 : (int64_t)g_nt_launches[kind].load(std::memory_order_relaxed);
 }
 
+static void fill_gemm_p(const lnx_gemm_args* a, GemmP& p) {
+    p.A = (const unsigned char*)a->A;
+    p.W = (const unsigned char*)a->W;
+    p.C = (unsigned char*)a->C;
+    p.C2 = (unsigned char*)a->c2;
+    p.aux = (const unsigned char*)a->aux;
+    p.bias = a->bias;
+    p.gamma = a->gamma;
+    p.rowscale = a->rowscale;
+    p.res = a->res;
+    p.lda = a->lda;
+    p.ldw = a->ldw;
+    p.ldc = a->ldc;
+    p.ldc2 = a->ldc2;
+    p.ldaux = a->ldaux;
+    p.ldres = a->ldres;
+    p.M = a->M;
+    p.N = a->N;
+    p.K = a->K;
+    p.a_mode = a->a_mode;
+    p.c_mode = a->c_mode;
+    p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
+    p.cmap = RowMap{a->c_map.group, a->c_map.pad, a->c_map.off};
+    p.act = a->act;
+    p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
+    p.tiles_m = cdiv(a->M, TILE);
+    p.tiles_n = cdiv(a->N, TILE);
+}
+
+// The dispatcher's decision without a launch (include/lnx.h): only M / N / K / dtype / out_f32 / act / addressing modes and WHICH of the
+// optional operands are present matter -- the pointers are never dereferenced, so a host-side caller may pass any non-null value.
+extern "C" int lnx_nt_dispatch(const lnx_gemm_args* a) {
+    if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->dtype != LNX_F32 && a->dtype != LNX_BF16)) return -1;
+    GemmP p;
+    fill_gemm_p(a, p);
+    if (nt_skinny_ok(p, a->dtype, a->out_f32 != 0) && !g_force_v1) return LNX_NT_KERNEL_SKINNY;
+    if (nt_v2_ok(p, a->dtype) && !g_force_v1) return nt_v2_family(p, a->out_f32 != 0, nullptr);
+    return LNX_NT_KERNEL_V1;
+}
+
 extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     LNX_CHECK(a != nullptr, "lnx_gemm_nt: null args");
     LNX_CHECK(a->dtype == LNX_F32 || a->dtype == LNX_BF16, "lnx_gemm_nt: bad dtype %d", a->dtype);
@@ -375,32 +415,7 @@ extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     if (a->rowscale) LNX_CHECK(a->rows_per_sample > 0, "lnx_gemm_nt: rowscale needs rows_per_sample");
 
     GemmP p;
-    p.A = (const unsigned char*)a->A;
-    p.W = (const unsigned char*)a->W;
-    p.C = (unsigned char*)a->C;
-    p.C2 = (unsigned char*)a->c2;
-    p.aux = (const unsigned char*)a->aux;
-    p.bias = a->bias;
-    p.gamma = a->gamma;
-    p.rowscale = a->rowscale;
-    p.res = a->res;
-    p.lda = a->lda;
-    p.ldw = a->ldw;
-    p.ldc = a->ldc;
-    p.ldc2 = a->ldc2;
-    p.ldaux = a->ldaux;
-    p.ldres = a->ldres;
-    p.M = a->M;
-    p.N = a->N;
-    p.K = a->K;
-    p.a_mode = a->a_mode;
-    p.c_mode = a->c_mode;
-    p.pg = PatchGeom{a->Hin, a->Win, a->Cin};
-    p.cmap = RowMap{a->c_map.group, a->c_map.pad, a->c_map.off};
-    p.act = a->act;
-    p.rows_per_sample = a->rows_per_sample > 0 ? a->rows_per_sample : 1;
-    p.tiles_m = cdiv(a->M, TILE);
-    p.tiles_n = cdiv(a->N, TILE);
+    fill_gemm_p(a, p);
     hipStream_t st = (hipStream_t)stream;
     if (nt_skinny_ok(p, a->dtype, a->out_f32 != 0) && !g_force_v1) {
         note_nt_kernel(LNX_NT_KERNEL_SKINNY);

@@ -344,6 +344,31 @@ bool nt_v2_ok(const GemmP& p, int dtype) {
     return true;
 }
 
+// Which pipelined family a product takes (no launch: lnx_nt_dispatch and launch_nt_v2 share this) -- the rules of DESIGN.md's dispatch table:
+//   LNX_NT_V7: 1 = every shape the persistent deferred-store kernel can run, 0 = never, unset = the measured choice (nt_v7_preferred)
+//   LNX_NT_V9: 1 = the persistent 256x256 kernel wherever it can run, 0 = never, unset = with at least 1.5 tiles per CU (below that a
+//              workgroup has no second tile to hide the first one's epilogue under) and where the big tile wins on rounds
+int nt_v2_family(const GemmP& p, bool out_f32, int* f_out) {
+    const bool patch = p.a_mode == LNX_ADDR_PATCH2;
+    static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
+    const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+    if (f_out) *f_out = f;
+    {
+        const char* e7 = getenv("LNX_NT_V7");
+        const int v7 = e7 ? atoi(e7) : -1;
+        if (v7 != 0 && nt_v7_ok(p, f, out_f32) && (v7 == 1 || nt_v7_preferred(p, f, out_f32))) return LNX_NT_KERNEL_V7;
+    }
+    const char* e9 = getenv("LNX_NT_V9");
+    const int v9 = e9 ? atoi(e9) : -1;
+    if (nt_v4_ok(p, f) && (v9 == 1 || big_tile_wins(p))) {
+        const int dc = device_cus();
+        const int64_t cus = dc > 0 ? dc : 256;
+        if (v9 != 0 && nt_v9_ok(p, f, out_f32) && (v9 == 1 || (int64_t)cdiv(p.M, BM4) * (p.N / BN4) * 2 >= 3 * cus)) return LNX_NT_KERNEL_V9;
+        return LNX_NT_KERNEL_V4;
+    }
+    return LNX_NT_KERNEL_V2;
+}
+
 int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     GemmP p = p0;
     p.tiles_m = cdiv(p.M, BM2);
@@ -351,29 +376,20 @@ int launch_nt_v2(const GemmP& p0, bool out_f32, hipStream_t st) {
     const int grid = p.tiles_m * p.tiles_n;
     const size_t lds = NSTAGE * STAGE_BYTES;
     const bool patch = p.a_mode == LNX_ADDR_PATCH2;
-    static const bool no_fast = getenv("LNX_NT_GENERIC_EPI") != nullptr;  // A/B switch for benchmarking
-    const int f = (patch || no_fast) ? (int)F_GENERIC : fast_epilogue_mask(p, out_f32);
+    int f = 0;
+    const int family = nt_v2_family(p, out_f32, &f);
     // measurement kernels kept outside the product (tools/experiments/: gemm_nt_v5, gemm_nt_v8) hook in here when their
     // library is the one loaded (LNX_LIB_PATH=tools/liblnx_experiments.so); the shipped library never sets the hook
     if (g_nt_experiment && g_nt_experiment(p, f, out_f32, st) == 0) return 0;
-    // LNX_NT_V7: 1 = every shape the persistent deferred-store kernel can run, 0 = never, unset = the measured choice
-    {
-        const char* e7 = getenv("LNX_NT_V7");
-        const int v7 = e7 ? atoi(e7) : -1;
-        if (v7 != 0 && nt_v7_ok(p, f, out_f32) && (v7 == 1 || nt_v7_preferred(p, f, out_f32))) {
-            note_nt_kernel(LNX_NT_KERNEL_V7);
-            return launch_nt_v7(p, f, out_f32, st);
-        }
+    if (family == LNX_NT_KERNEL_V7) {
+        note_nt_kernel(LNX_NT_KERNEL_V7);
+        return launch_nt_v7(p, f, out_f32, st);
     }
-    // LNX_NT_V9: 1 = the persistent 256x256 kernel wherever it can run, 0 = never, unset = with at least 1.5 tiles per CU (below
-    // that a workgroup has no second tile to hide the first one's epilogue under) and where the big tile wins on rounds
-    const char* e9 = getenv("LNX_NT_V9");
-    const int v9 = e9 ? atoi(e9) : -1;
-    if (nt_v4_ok(p, f) && (v9 == 1 || big_tile_wins(p))) {
-        if (v9 != 0 && nt_v9_ok(p, f, out_f32) && (v9 == 1 || (int64_t)cdiv(p.M, BM4) * (p.N / BN4) * 2 >= 3 * 256)) {
-            note_nt_kernel(LNX_NT_KERNEL_V9);
-            return launch_nt_v9(p, f, out_f32, st);
-        }
+    if (family == LNX_NT_KERNEL_V9) {
+        note_nt_kernel(LNX_NT_KERNEL_V9);
+        return launch_nt_v9(p, f, out_f32, st);
+    }
+    if (family == LNX_NT_KERNEL_V4) {
         note_nt_kernel(LNX_NT_KERNEL_V4);
         p.tiles_m = cdiv(p.M, BM4);
         p.tiles_n = p.N / BN4;

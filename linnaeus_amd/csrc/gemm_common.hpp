@@ -474,6 +474,7 @@ int launch_nt_skinny(const GemmP& p, bool out_f32, hipStream_t st);
 
 // gemm2.hip: 256x128 LDS-DMA pipelined kernels (bf16)
 int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);
+int nt_v2_family(const GemmP& p, bool out_f32, int* f_out);  // V7 / V9 / V4 / V2: the choice launch_nt_v2 makes, without launching
 bool nt_v2_ok(const GemmP& p, int dtype);
 int launch_tn_v2(const WgradP& p, int splits_hint, hipStream_t st, bool defer);
 int tn_flush(hipStream_t st);  // launches the deferred second stages of this thread, if any (st: their stream, or nullptr); 1 = they belong to another stream

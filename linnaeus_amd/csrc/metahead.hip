@@ -31,6 +31,19 @@ struct BwdBatch {
 };
 
 __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Raw buffer addressing for the operand streams of chain_matmul: a scalar 64-bit base in the descriptor, one 32-bit byte offset per lane
+// and a scalar offset for the k position -- instead of a 64-bit address per lane, tile and chunk in flight (which spilled the chunk buffers).
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_mh;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mh_rsrc(const void* base) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint64_t u = (uint64_t)hi << 32 | lo;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 mh_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff /* uniform */) {
+    const u32x4_mh v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return float4{__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), __builtin_bit_cast(float, v[2]), __builtin_bit_cast(float, v[3])};
+}
 __device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(f32x4_t v) { return float4{v[0], v[1], v[2], v[3]}; }
 
@@ -69,57 +82,62 @@ __device__ __forceinline__ float4 col_reduce(float4 v) {
     return v;
 }
 
-// acc[t] (+)= A[16 rows][K] . W[rows 16 (wave + 8 t) .. +15][K]^T for this wave's ntw tiles.  A rows beyond the batch are clamped by the
-// caller (arow), K % 16 == 0.  One chunk of prefetch: the loads of chunk k+1 are in flight under the MFMAs of chunk k.
-template <int TPW>
-__device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[TPW], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
-                                             int ntw, int wave, int lane) {
-    constexpr int G = TPW < 8 ? TPW : 8;  // tiles whose weight chunks are held (and prefetched) at once: 16 tiles per wave (C = 2048) go in two passes over K
+// acc[t] (+)= A[16 rows][K] . W[rows 16 (wave + 8 t) .. +15][K]^T for this wave's NT tiles (every wave has the same number: C % 128 == 0).
+// A rows beyond the batch are clamped by the caller (arow).  The weights come from HBM / the Infinity Cache behind ~2 us of latency (every
+// workgroup of a head streams the same 0.6-16 MB matrix, in step with the others), so D chunks of 16 k stay in flight per wave: with one
+// chunk of prefetch the C = 768 chain took 417 us for 70 us of matrix-core work (round 5).  K % (16 D) == 0; the loop body has no
+// condition (the last D chunks are peeled), so the compiler's waits are counted ones.
+template <int NT, int D>
+__device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
+                                             int wave, int lane) {
+    constexpr int G = NT;  // (NT <= 8: every tile's weight chunk is held at once)
     const int c = lane & 15, q = lane >> 4;
-    const float* ap = A + (int64_t)arow * lda + 4 * q;
-    const float* wbase = W + (int64_t)(wave * 16 + c) * ldw + 4 * q;
-    const int64_t tstride = (int64_t)MH_WAVES * 16 * ldw;
+    // (every operand of the chain is far below 2 GiB: C <= 2048 rows of at most 8 KiB, B rows of C floats)
+    const __amdgpu_buffer_rsrc_t ra = mh_rsrc(A), rw = mh_rsrc(W);
+    const uint32_t aoff = (uint32_t)(arow * lda + 4 * q) * 4u;
+    const uint32_t woff = (uint32_t)((wave * 16 + c) * ldw + 4 * q) * 4u;
+    const uint32_t tstride = (uint32_t)(MH_WAVES * 16 * ldw) * 4u;
 #pragma unroll
-    for (int tb = 0; tb < TPW; tb += G) {
-        if (tb >= ntw) break;
-        float4 a_cur = ldf4(ap), w_cur[G];
+    for (int tb = 0; tb < NT; tb += G) {
+        float4 a_buf[D], w_buf[D][G];
+        auto load = [&](int d, uint32_t kbytes) __attribute__((always_inline)) {
+            a_buf[d] = mh_ld(ra, aoff, kbytes);
 #pragma unroll
-        for (int t = 0; t < G; ++t)
-            if (tb + t < ntw) w_cur[t] = ldf4(wbase + (tb + t) * tstride);
-        for (int k0 = 0; k0 < K; k0 += 16) {
-            float4 a_nxt = a_cur, w_nxt[G];
-            const bool more = k0 + 16 < K;
-            if (more) a_nxt = ldf4(ap + k0 + 16);
+            for (int t = 0; t < G; ++t) w_buf[d][t] = mh_ld(rw, woff + (uint32_t)(tb + t) * tstride, kbytes);
+        };
+        auto use = [&](int d) __attribute__((always_inline)) {
+            const float av[4] = {a_buf[d].x, a_buf[d].y, a_buf[d].z, a_buf[d].w};
 #pragma unroll
-            for (int t = 0; t < G; ++t)
-                if (tb + t < ntw && more) w_nxt[t] = ldf4(wbase + (tb + t) * tstride + k0 + 16);
-            const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+            for (int t = 0; t < G; ++t) {
+                const float wv[4] = {w_buf[d][t].x, w_buf[d][t].y, w_buf[d][t].z, w_buf[d][t].w};
 #pragma unroll
-            for (int t = 0; t < G; ++t)
-                if (tb + t < ntw) {
-                    const float wv[4] = {w_cur[t].x, w_cur[t].y, w_cur[t].z, w_cur[t].w};
+                for (int j = 0; j < 4; ++j) acc[tb + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[tb + t], 0, 0, 0);
+            }
+        };
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[tb + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[tb + t], 0, 0, 0);
-                }
-            a_cur = a_nxt;
+        for (int d = 0; d < D; ++d) load(d, 64u * d);
+        for (int k0 = 16 * D; k0 < K; k0 += 16 * D) {
 #pragma unroll
-            for (int t = 0; t < G; ++t)
-                if (tb + t < ntw && more) w_cur[t] = w_nxt[t];
+            for (int d = 0; d < D; ++d) {
+                use(d);
+                load(d, 4u * (uint32_t)(k0 + 16 * d));
+            }
         }
+#pragma unroll
+        for (int d = 0; d < D; ++d) use(d);
     }
 }
 
 // One Linear -> ReLU -> LayerNorm step of the chain on registers: acc holds the product; writes h = ReLU(acc + b) (saved for the backward)
 // and y = LN(h) (+ skip) and the row statistics.  Two-pass variance (mean first), as lnx_layernorm_fwd.
-template <int TPW>
-__device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[TPW], int ntw, int wave, int lane, int C, int row, bool valid, const float* __restrict__ bias,
+template <int NT>
+__device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[NT], int wave, int lane, int C, int row, bool valid, const float* __restrict__ bias,
                                               const float* __restrict__ lnw, const float* __restrict__ lnb, float eps, float* __restrict__ H, float* __restrict__ Y,
                                               int64_t y_stride, float* __restrict__ mean_out, float* __restrict__ rstd_out, const float* __restrict__ skip, float* red) {
     const int c = lane & 15, q = lane >> 4;
     float s[1] = {0.f};
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) {
+    for (int t = 0; t < NT; ++t) {
             const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
             const float4 b = ldf4(bias + col);
             acc[t][0] = fmaxf(acc[t][0] + b.x, 0.f);
@@ -133,8 +151,7 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[TPW], int ntw, int 
     const float mean = s[0] / (float)C;
     float v[1] = {0.f};
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float d = acc[t][r] - mean;
@@ -148,8 +165,7 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[TPW], int ntw, int 
         rstd_out[row] = rstd;
     }
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) {
+    for (int t = 0; t < NT; ++t) {
             const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
             const float4 g = ldf4(lnw + col), b = ldf4(lnb + col);
             float4 y;
@@ -165,8 +181,9 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[TPW], int ntw, int 
         }
 }
 
-template <int TPW>
+template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBatch bt) {
+    constexpr int FD = NT <= 3 ? 8 : 4;  // weight chunks in flight per wave (chain_matmul); K / 16 = 8 NT is a multiple of it
     const lnx_meta_head_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;
@@ -174,8 +191,6 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBat
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15;
     const int C = a.C;
-    const int ntiles = C / 16;
-    const int ntw = wave < ntiles ? (ntiles - wave + MH_WAVES - 1) / MH_WAVES : 0;
     const int row = row0 + c;
     const bool valid = row < a.B;
     const int arow = valid ? row : a.B - 1;
@@ -185,49 +200,50 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBat
         if (row0 + r < a.B) a.t0[(int64_t)(row0 + r) * 16 + d] = d < a.dim ? a.meta[(int64_t)(row0 + r) * a.meta_width + a.off + d] : 0.f;
     }
     __syncthreads();
-    f32x4_t acc[TPW];
+    f32x4_t acc[NT];
     auto zero = [&]() {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     };
     // h0 = ReLU(t0 W0^T + b0), x = LN0(h0)
     zero();
-    chain_matmul<TPW>(acc, a.t0, 16, arow, a.w0, a.ldw0, 16, ntw, wave, lane);
-    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b0, a.ln0_w, a.ln0_b, a.eps, a.h0, a.x, C, a.m0, a.r0, nullptr, red);
+    chain_matmul<NT, 1>(acc, a.t0, 16, arow, a.w0, a.ldw0, 16, wave, lane);
+    relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b0, a.ln0_w, a.ln0_b, a.eps, a.h0, a.x, C, a.m0, a.r0, nullptr, red);
     __syncthreads();  // x is read back (every wave needs whole rows of it) through this CU's cache
     // h1 = ReLU(x W1^T + b1), n1 = LN1(h1)
     zero();
-    chain_matmul<TPW>(acc, a.x, C, arow, a.w1, a.ldw1, C, ntw, wave, lane);
-    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b1, a.ln1_w, a.ln1_b, a.eps, a.h1, a.n1, C, a.m1, a.r1, nullptr, red);
+    chain_matmul<NT, FD>(acc, a.x, C, arow, a.w1, a.ldw1, C, wave, lane);
+    relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b1, a.ln1_w, a.ln1_b, a.eps, a.h1, a.n1, C, a.m1, a.r1, nullptr, red);
     __syncthreads();
     // h2 = ReLU(n1 W2^T + b2), tok = x + LN2(h2) -> the token row of this sample
     zero();
-    chain_matmul<TPW>(acc, a.n1, C, arow, a.w2, a.ldw2, C, ntw, wave, lane);
-    relu_ln_store<TPW>(acc, ntw, wave, lane, C, row, valid, a.b2, a.ln2_w, a.ln2_b, a.eps, a.h2, a.tok + a.tok_row_offset, a.tok_row_stride, a.m2, a.r2, a.x, red);
+    chain_matmul<NT, FD>(acc, a.n1, C, arow, a.w2, a.ldw2, C, wave, lane);
+    relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b2, a.ln2_w, a.ln2_b, a.eps, a.h2, a.tok + a.tok_row_offset, a.tok_row_stride, a.m2, a.r2, a.x, red);
 }
 
 // LayerNorm backward on registers, followed by the ReLU mask of the Linear in front of the LayerNorm: dy[t] (gradient wrt the LayerNorm
 // output; zero in rows beyond the batch) -> dp = [h > 0] rstd (dy g - mean(dy g) - xhat mean(dy g xhat)), stored to DP; the workgroup's
 // column sums of dy xhat / dy go to part_g / part_b (row group `rg` of [row_groups][C]).
-template <int TPW>
-__device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[TPW], int ntw, int wave, int lane, int C, int row, bool valid, const float* __restrict__ H,
+template <int NT>
+__device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[NT], int wave, int lane, int C, int row, bool valid, const float* __restrict__ H,
                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in, const float* __restrict__ lnw, float* __restrict__ DP,
                                             float* __restrict__ part_g, float* __restrict__ part_b, int rg, float* red) {
     const int c = lane & 15, q = lane >> 4;
     const float mean = mean_in[row], rstd = rstd_in[row];  // (row is clamped by the caller)
-    float4 xh[TPW];
+    constexpr bool KEEP = true;
+    float4 xh[KEEP ? NT : 1];
     unsigned long long pos = 0ull;  // bit 4 t + r: h > 0 (the ReLU in front of this LayerNorm let the element through)
     float s[2] = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) {
+    for (int t = 0; t < NT; ++t) {
             const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
             const float4 h = ldf4(H + (int64_t)row * C + col);
             const float4 g = ldf4(lnw + col);
-            xh[t] = float4{(h.x - mean) * rstd, (h.y - mean) * rstd, (h.z - mean) * rstd, (h.w - mean) * rstd};
+            float4& xt = xh[KEEP ? t : 0];
+            xt = float4{(h.x - mean) * rstd, (h.y - mean) * rstd, (h.z - mean) * rstd, (h.w - mean) * rstd};
             pos |= (unsigned long long)((h.x > 0.f ? 1u : 0u) | (h.y > 0.f ? 2u : 0u) | (h.z > 0.f ? 4u : 0u) | (h.w > 0.f ? 8u : 0u)) << (4 * t);
             // column partials first (they take dy itself), then dy <- dy g
-            float4 pg = float4{dy[t][0] * xh[t].x, dy[t][1] * xh[t].y, dy[t][2] * xh[t].z, dy[t][3] * xh[t].w};
+            float4 pg = float4{dy[t][0] * xt.x, dy[t][1] * xt.y, dy[t][2] * xt.z, dy[t][3] * xt.w};
             float4 pb = f4(dy[t]);
             pg = col_reduce(pg);
             pb = col_reduce(pb);
@@ -237,26 +253,35 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[TPW], int ntw, int wav
             }
             dy[t][0] *= g.x; dy[t][1] *= g.y; dy[t][2] *= g.z; dy[t][3] *= g.w;
             s[0] += (dy[t][0] + dy[t][1]) + (dy[t][2] + dy[t][3]);
-            s[1] += (dy[t][0] * xh[t].x + dy[t][1] * xh[t].y) + (dy[t][2] * xh[t].z + dy[t][3] * xh[t].w);
+            s[1] += (dy[t][0] * xt.x + dy[t][1] * xt.y) + (dy[t][2] * xt.z + dy[t][3] * xt.w);
+            if (!KEEP && (t & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from interleaving all 16 tiles' loads and shuffle chains of a 2048-wide row: 250 registers spilled)
         }
     row_allreduce<2>(s, red, wave, lane);
     const float m1 = s[0] / (float)C, m2 = s[1] / (float)C;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) {
+    for (int t = 0; t < NT; ++t) {
             const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
             const unsigned mk = (unsigned)(pos >> (4 * t)) & 15u;
+            float4 xt;
+            if (KEEP) {
+                xt = xh[KEEP ? t : 0];
+            } else {
+                const float4 h = ldf4(H + (int64_t)row * C + col);
+                xt = float4{(h.x - mean) * rstd, (h.y - mean) * rstd, (h.z - mean) * rstd, (h.w - mean) * rstd};
+            }
             float4 o;
-            o.x = (mk & 1u) ? rstd * (dy[t][0] - m1 - xh[t].x * m2) : 0.f;
-            o.y = (mk & 2u) ? rstd * (dy[t][1] - m1 - xh[t].y * m2) : 0.f;
-            o.z = (mk & 4u) ? rstd * (dy[t][2] - m1 - xh[t].z * m2) : 0.f;
-            o.w = (mk & 8u) ? rstd * (dy[t][3] - m1 - xh[t].w * m2) : 0.f;
+            o.x = (mk & 1u) ? rstd * (dy[t][0] - m1 - xt.x * m2) : 0.f;
+            o.y = (mk & 2u) ? rstd * (dy[t][1] - m1 - xt.y * m2) : 0.f;
+            o.z = (mk & 4u) ? rstd * (dy[t][2] - m1 - xt.z * m2) : 0.f;
+            o.w = (mk & 8u) ? rstd * (dy[t][3] - m1 - xt.w * m2) : 0.f;
             if (valid) stf4(DP + (int64_t)row * C + col, o);
+            if (!KEEP && (t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
 }
 
-template <int TPW>
+template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBatch bt) {
+    constexpr int BD = NT <= 3 ? 8 : 4;
     const lnx_meta_head_bwd_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;
@@ -264,15 +289,13 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int C = a.C;
-    const int ntiles = C / 16;
-    const int ntw = wave < ntiles ? (ntiles - wave + MH_WAVES - 1) / MH_WAVES : 0;
     const int row = row0 + c;
     const bool valid = row < a.B;
     const int arow = valid ? row : a.B - 1;
     const int rg = blockIdx.x, nrg = (a.B + MH_ROWS - 1) / MH_ROWS;
     float* const part = a.part;  // [6][nrg][C]: dln2_w, dln2_b, dln1_w, dln1_b, dln0_w, dln0_b
     const int64_t ps = (int64_t)nrg * C;
-    f32x4_t acc[TPW];
+    f32x4_t acc[NT];
     // tok = x + LN2(h2): the token-row gradient reaches LN2's output and, through the skip, x
     auto load_dtok = [&](int t) -> f32x4_t {
         const int col = (wave + MH_WAVES * t) * 16 + 4 * q;
@@ -281,31 +304,28 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
         return f32x4_t{v.x, v.y, v.z, v.w};
     };
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) acc[t] = load_dtok(t);
-    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h2, a.m2, a.r2, a.ln2_w, a.dp2, part + 0 * ps, part + 1 * ps, rg, red);
+    for (int t = 0; t < NT; ++t) acc[t] = load_dtok(t);
+    ln_relu_bwd<NT>(acc, wave, lane, C, arow, valid, a.h2, a.m2, a.r2, a.ln2_w, a.dp2, part + 0 * ps, part + 1 * ps, rg, red);
     __syncthreads();  // dp2 is read back whole-row by every wave
     // d n1 = dp2 . W2 (the transposed copy: w2t[i][o]), then LN1 / ReLU backward
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    chain_matmul<TPW>(acc, a.dp2, C, arow, a.w2t, a.ldw2t, C, ntw, wave, lane);
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    chain_matmul<NT, BD>(acc, a.dp2, C, arow, a.w2t, a.ldw2t, C, wave, lane);
     if (!valid) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // clamped duplicate rows must not reach the column sums
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // clamped duplicate rows must not reach the column sums
     }
-    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h1, a.m1, a.r1, a.ln1_w, a.dp1, part + 2 * ps, part + 3 * ps, rg, red);
+    ln_relu_bwd<NT>(acc, wave, lane, C, arow, valid, a.h1, a.m1, a.r1, a.ln1_w, a.dp1, part + 2 * ps, part + 3 * ps, rg, red);
     __syncthreads();
     // d x = dp1 . W1 + d tok (skip connection of the ResNormLayer), then LN0 / ReLU backward
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
-        if (t < ntw) acc[t] = load_dtok(t);
-        else acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    chain_matmul<TPW>(acc, a.dp1, C, arow, a.w1t, a.ldw1t, C, ntw, wave, lane);
+    for (int t = 0; t < NT; ++t) acc[t] = load_dtok(t);
+    chain_matmul<NT, BD>(acc, a.dp1, C, arow, a.w1t, a.ldw1t, C, wave, lane);
     if (!valid) {
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-    ln_relu_bwd<TPW>(acc, ntw, wave, lane, C, arow, valid, a.h0, a.m0, a.r0, a.ln0_w, a.dp0, part + 4 * ps, part + 5 * ps, rg, red);
+    ln_relu_bwd<NT>(acc, wave, lane, C, arow, valid, a.h0, a.m0, a.r0, a.ln0_w, a.dp0, part + 4 * ps, part + 5 * ps, rg, red);
 }
 
 // ---- weight gradients: dW[o][i] += sum_m dP[m][o] X[m][i] for the three Linears of each head, their bias gradients (column sums of
@@ -328,18 +348,22 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ DP, int64_
         d = ok ? ldf4(dp + (int64_t)m * lddp) : float4{0.f, 0.f, 0.f, 0.f};
         x = (ok && xin) ? ldf4(xp + (int64_t)m * ldx) : float4{0.f, 0.f, 0.f, 0.f};
     };
-    float4 d_cur, x_cur;
-    fetch(q, d_cur, x_cur);
-    for (int m0 = 0; m0 < B; m0 += 4) {
-        float4 d_nxt, x_nxt;
-        fetch(m0 + 4 + q, d_nxt, x_nxt);
-        const float dv[4] = {d_cur.x, d_cur.y, d_cur.z, d_cur.w}, xv[4] = {x_cur.x, x_cur.y, x_cur.z, x_cur.w};
+    constexpr int D = 8;  // row groups of four in flight (the operands come from L2 / HBM: one group of prefetch left this loop latency-bound)
+    float4 d_buf[D], x_buf[D];
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+    for (int d = 0; d < D; ++d) fetch(4 * d + q, d_buf[d], x_buf[d]);
+    for (int m0 = 0; m0 < B; m0 += 4 * D) {
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[tt], xv[uu], acc[tt][uu], 0, 0, 0);
-        d_cur = d_nxt;
-        x_cur = x_nxt;
+        for (int d = 0; d < D; ++d) {
+            if (m0 + 4 * d < B) {  // (uniform)
+                const float dv[4] = {d_buf[d].x, d_buf[d].y, d_buf[d].z, d_buf[d].w}, xv[4] = {x_buf[d].x, x_buf[d].y, x_buf[d].z, x_buf[d].w};
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[tt], xv[uu], acc[tt][uu], 0, 0, 0);
+                fetch(m0 + 4 * (d + D) + q, d_buf[d], x_buf[d]);
+            }
+        }
     }
     // lane holds D[M = 4 q + r][N = c] of tile (tt, uu): dW[o0 + 4 (4 q + r) + tt][i0 + 4 c + uu]
 #pragma unroll
@@ -410,23 +434,50 @@ __global__ __launch_bounds__(256) void meta_chain_wgrad_kernel(const BwdBatch bt
     }
 }
 
-int tpw_of(int C) { return C <= 512 ? 4 : (C <= 1024 ? 8 : 16); }
+bool nt_supported(int C) {
+    // C = 128 NT with NT tiles per wave; wider rows (lg / xl stage 4: C = 1536 / 2048) do not fit the backward's registers (dy + normalised row +
+    // chunk buffers of 12-16 tiles spilled 250 registers) and stay on the launch-by-launch chain (plan.cpp: per stage)
+    if (C < 128 || C % 128 != 0 || C > 1024) return false;
+    const int nt = C / 128;
+    return nt <= 4 || nt == 6 || nt == 8;
+}
+
+template <typename Batch, typename Args>
+int group_end(const Args* heads, int n_heads, int i0) {  // heads [i0, end) share one width (one template instantiation per launch), at most four
+    int e = i0 + 1;
+    while (e < n_heads && e - i0 < MH_MAX_HEADS && heads[e].C == heads[i0].C) ++e;
+    return e;
+}
+
+#define MH_DISPATCH_NT(KERNEL, nt, grid, st, bt)                                                                   \
+    do {                                                                                                           \
+        switch (nt) {                                                                                              \
+            case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(MH_THREADS), 0, st, bt); break;                       \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(MH_THREADS), 0, st, bt); break;                       \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(MH_THREADS), 0, st, bt); break;                       \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(MH_THREADS), 0, st, bt); break;                       \
+            case 6: hipLaunchKernelGGL(KERNEL<6>, grid, dim3(MH_THREADS), 0, st, bt); break;                       \
+            default: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(MH_THREADS), 0, st, bt); break;                      \
+        }                                                                                                          \
+    } while (0)
 
 }  // namespace
 
 extern "C" int64_t lnx_meta_heads_bwd_part_floats(int B, int C) { return 6 * (int64_t)((B + MH_ROWS - 1) / MH_ROWS) * C; }
+extern "C" int lnx_meta_heads_supported(int C) { return nt_supported(C) ? 1 : 0; }
 
 static int check_head_dims(int B, int C, int dim, const char* who) {
-    LNX_CHECK(B > 0 && C >= 64 && C % 64 == 0 && C <= 2048 && dim >= 1 && dim <= 16, "%s: B=%d C=%d dim=%d (C a multiple of 64 up to 2048, dim 1..16)", who, B, C, dim);
+    LNX_CHECK(B > 0 && nt_supported(C) && dim >= 1 && dim <= 16,
+              "%s: B=%d C=%d dim=%d (C / 128 in {1, 2, 3, 4, 6, 8} -- lnx_meta_heads_supported -- and dim 1..16)", who, B, C, dim);
     return 0;
 }
 
 extern "C" int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, void* stream) {
     LNX_CHECK(heads != nullptr && n_heads > 0, "lnx_meta_heads_fwd: no heads");
-    for (int i0 = 0; i0 < n_heads; i0 += MH_MAX_HEADS) {
-        const int n = n_heads - i0 < MH_MAX_HEADS ? n_heads - i0 : MH_MAX_HEADS;
+    for (int i0 = 0; i0 < n_heads;) {
+        const int e = group_end<FwdBatch>(heads, n_heads, i0), n = e - i0;
         FwdBatch bt;
-        int maxB = 0, tpw = 4;
+        int maxB = 0;
         for (int i = 0; i < n; ++i) {
             const lnx_meta_head_args& a = heads[i0 + i];
             if (check_head_dims(a.B, a.C, a.dim, "lnx_meta_heads_fwd")) return 1;
@@ -439,23 +490,21 @@ extern "C" int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, 
                       "lnx_meta_heads_fwd: 16-byte alignment (head %d)", i0 + i);
             bt.h[i] = a;
             if (a.B > maxB) maxB = a.B;
-            if (tpw_of(a.C) > tpw) tpw = tpw_of(a.C);
         }
         const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
-        if (tpw == 4) hipLaunchKernelGGL(meta_chain_fwd_kernel<4>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
-        else if (tpw == 8) hipLaunchKernelGGL(meta_chain_fwd_kernel<8>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
-        else hipLaunchKernelGGL(meta_chain_fwd_kernel<16>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        MH_DISPATCH_NT(meta_chain_fwd_kernel, heads[i0].C / 128, grid, (hipStream_t)stream, bt);
         LNX_LAUNCH_CHECK();
+        i0 = e;
     }
     return 0;
 }
 
 extern "C" int lnx_meta_heads_bwd(const lnx_meta_head_bwd_args* heads, int n_heads, void* stream) {
     LNX_CHECK(heads != nullptr && n_heads > 0, "lnx_meta_heads_bwd: no heads");
-    for (int i0 = 0; i0 < n_heads; i0 += MH_MAX_HEADS) {
-        const int n = n_heads - i0 < MH_MAX_HEADS ? n_heads - i0 : MH_MAX_HEADS;
+    for (int i0 = 0; i0 < n_heads;) {
+        const int e = group_end<BwdBatch>(heads, n_heads, i0), n = e - i0;
         BwdBatch bt;
-        int maxB = 0, tpw = 4, blocks = 0;
+        int maxB = 0, blocks = 0;
         for (int i = 0; i < MH_MAX_HEADS + 1; ++i) bt.block_start[i] = 0x7fffffff;
         for (int i = 0; i < n; ++i) {
             const lnx_meta_head_bwd_args& a = heads[i0 + i];
@@ -471,15 +520,13 @@ extern "C" int lnx_meta_heads_bwd(const lnx_meta_head_bwd_args* heads, int n_hea
             bt.block_start[i] = blocks;
             blocks += mh_wgrad_blocks(a.C);
             if (a.B > maxB) maxB = a.B;
-            if (tpw_of(a.C) > tpw) tpw = tpw_of(a.C);
         }
         const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
-        if (tpw == 4) hipLaunchKernelGGL(meta_chain_bwd_kernel<4>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
-        else if (tpw == 8) hipLaunchKernelGGL(meta_chain_bwd_kernel<8>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
-        else hipLaunchKernelGGL(meta_chain_bwd_kernel<16>, grid, dim3(MH_THREADS), 0, (hipStream_t)stream, bt);
+        MH_DISPATCH_NT(meta_chain_bwd_kernel, heads[i0].C / 128, grid, (hipStream_t)stream, bt);
         LNX_LAUNCH_CHECK();
         hipLaunchKernelGGL(meta_chain_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
         LNX_LAUNCH_CHECK();
+        i0 = e;
     }
     return 0;
 }

@@ -164,6 +164,7 @@ struct lnx_plan {
     bool meta_forked[2] = {false, false};  // backward: stage s's metadata heads were forked off the launch stream and not joined yet
     int meta_mode = 1;       // which stream the metadata heads run on: 0 launch stream, 1 their own side stream, 2 the weight-gradient stream (lnx_plan_set_meta_stream)
     bool meta_chain = true;  // metadata heads as one launch per direction (metahead.hip); LNX_META_CHAIN=0: the round-1 chain of GEMM / LayerNorm launches (A/B)
+    bool chain_ok[2] = {false, false};  // ... per RoPE stage: the one-launch chain carries widths up to 1024 (lnx_meta_heads_supported)
     bool dy8_ready = false;  // backward, fp8 plans: o_a8 / o_a8s hold the MXFP8 copy of the dY in sC (written by the LayerNorm backward that wrote sC)
     hipEvent_t ev_wf[4] = {nullptr, nullptr, nullptr, nullptr}, ev_wj[4] = {nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing with HIP events (bench.py's live roofline measurement)
@@ -342,6 +343,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->c = c;
     p->esz = c.dtype == LNX_BF16 ? 2 : 4;
     p->meta_chain = !(getenv("LNX_META_CHAIN") && atoi(getenv("LNX_META_CHAIN")) == 0);
+    for (int s = 0; s < 2; ++s) p->chain_ok[s] = p->meta_chain && lnx_meta_heads_supported(c.dims[2 + s]) != 0;
     p->E = 1 + c.n_meta;
     p->H[0] = c.img_h / 4;
     p->W[0] = c.img_w / 4;
@@ -639,7 +641,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             k.h2 = cv.take((int64_t)B * C * 4);
             k.m2 = cv.take(B * 4);
             k.r2 = cv.take(B * 4);
-            if (!inf && p->meta_chain) {  // the heads of a stage run side by side in one launch: scratch per head
+            if (!inf && p->chain_ok[s]) {  // the heads of a stage run side by side in one launch: scratch per head
                 k.dp2 = cv.take((int64_t)B * C * 4);
                 k.dp1 = cv.take((int64_t)B * C * 4);
                 k.dp0 = cv.take((int64_t)B * C * 4);
@@ -925,7 +927,7 @@ hipStream_t meta_stream(const lnx_plan* p) {
     if (p->c.n_meta <= 0 || p->meta_mode == 0) return nullptr;
     // the weight-gradient stream only carries the one-launch chain: the launch-by-launch chain shares scratch with the launch stream's kernels
     // unless it runs on `side` (ln_bwd / wgrad_to below)
-    if (p->meta_mode == 2 && p->meta_chain && p->wgs != nullptr) return p->wgs;
+    if (p->meta_mode == 2 && p->chain_ok[0] && p->chain_ok[1] && p->wgs != nullptr) return p->wgs;
     return p->side;
 }
 
@@ -1363,11 +1365,16 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         HIPRUN(hipEventRecord(p->ev_fork, (hipStream_t)stream));
         HIPRUN(hipStreamWaitEvent(mst, p->ev_fork, 0));
         Ctx cs{p, (void*)mst, cf.dtype};
-        if (p->meta_chain) {
-            RUN(meta_chain_fwd(cs, 0, 2, meta, mw_all));  // every head of both stages: one launch
+        if (p->chain_ok[0] && p->chain_ok[1]) {
+            RUN(meta_chain_fwd(cs, 0, 2, meta, mw_all));  // every head of both stages: one call (a launch per width)
         } else {
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (p->chain_ok[s2]) {
+                    RUN(meta_chain_fwd(cs, s2, s2 + 1, meta, mw_all));
+                    continue;
+                }
                 for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(cs, s2, m, meta, mw_all, c.at<float>(p->o_tok[s2]), s2 == 0 ? p->N2 : p->N3));
+            }
         }
         HIPRUN(hipEventRecord(p->ev_meta, mst));
     }
@@ -1421,7 +1428,7 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         RUN(lnx_fill_rows(p->P[p->cls[s]], tok, C, clsmap, B, C, stream));
         if (mst) {
             if (s == 0) HIPRUN(hipStreamWaitEvent((hipStream_t)stream, p->ev_meta, 0));  // join: all meta tokens written
-        } else if (p->meta_chain) {
+        } else if (p->chain_ok[s]) {
             RUN(meta_chain_fwd(c, s, s + 1, meta, mw_all));
         } else {
             for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(c, s, m, meta, mw_all, tok, N));
@@ -1749,11 +1756,11 @@ int tokens_bwd(const Ctx& c, int s, const float* g) {
         HIPRUN(hipEventRecord(p->ev_bfork[s], (hipStream_t)c.st));
         HIPRUN(hipStreamWaitEvent(mst, p->ev_bfork[s], 0));
         const Ctx cs{p, (void*)mst, c.dt};
-        if (p->meta_chain) RUN(meta_chain_bwd(cs, s, g));
+        if (p->chain_ok[s]) RUN(meta_chain_bwd(cs, s, g));
         else
             for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(cs, s, m, g, N));
         HIPRUN(hipEventRecord(p->ev_bjoin[s], mst));
-    } else if (p->meta_chain) {
+    } else if (p->chain_ok[s]) {
         RUN(meta_chain_bwd(c, s, g));
     } else {
         for (int m = 0; m < p->c.n_meta; ++m) RUN(meta_head_bwd(c, s, m, g, N));

@@ -841,10 +841,10 @@ def _meta_head_reference(meta, h):
 
 
 @pytest.mark.parametrize("B,cfg", [(256, [(384, 2, 0), (384, 3, 2), (768, 2, 0), (768, 3, 2)]), (24, [(768, 3, 2)]), (5, [(128, 10, 5), (256, 2, 0)]),
-                                   (130, [(1024, 3, 2), (2048, 2, 0)]), (33, [(1536, 10, 5), (128, 1, 4), (192 * 4, 16, 0), (64, 2, 0), (2048, 3, 2)])])
+                                   (130, [(1024, 3, 2), (1024, 2, 0), (512, 2, 0)]), (33, [(128, 1, 4), (128, 10, 5), (128, 2, 0), (128, 3, 2), (128, 16, 0), (768, 16, 0), (256, 2, 0)])])
 def test_meta_head_chain_one_launch_matches_autograd(B, cfg):
-    """lnx_meta_heads_fwd / lnx_meta_heads_bwd: several heads of different widths in one call (sm's four heads at the benchmark's batch; lg / xl
-    widths incl. C = 2048 with 16 tiles per wave; more than four heads = two launches; partial last row group; dim up to 16) against fp64
+    """lnx_meta_heads_fwd / lnx_meta_heads_bwd: several heads of different widths in one call (sm's four heads at the benchmark's batch; every
+    width the chain carries, C = 128 .. 1024; five heads of one width = two launches; partial last row group; dim up to 16) against fp64
     autograd of the reference chain.  fp32 arithmetic: tokens to 2e-5, every gradient to 1e-4 of its scale; gradients ACCUMULATE onto what the
     buffers held; rows of the token matrix that belong to other tokens are untouched; two runs are bit-identical (no atomics)."""
     gen = g(B * 131 + len(cfg))
@@ -882,3 +882,16 @@ def test_meta_head_chain_one_launch_matches_autograd(B, cfg):
             scale = max(1e-3, ref.abs().max().item())
             torch.testing.assert_close((gr[k] - 0.5).double(), ref, rtol=1e-4, atol=1e-4 * scale, msg=lambda m, k=k, C=h["w1"].shape[0]: f"{k} (C={C}): {m}")
             assert torch.equal(gr[k], gr2[k]), k
+
+
+def test_meta_head_chain_refuses_widths_it_does_not_carry():
+    """C / 128 must be in {1, 2, 3, 4, 6, 8}: the plan keeps the launch-by-launch chain for wider stages (lg / xl stage 4) and asks first."""
+    lib = L.lib()
+    assert [lib.lnx_meta_heads_supported(c) for c in (128, 256, 384, 512, 768, 1024)] == [1] * 6
+    assert [lib.lnx_meta_heads_supported(c) for c in (64, 192, 640, 896, 1536, 2048)] == [0] * 6
+    gen = g(1)
+    meta = torch.randn(4, 5, generator=gen).cuda()
+    h = _meta_head_params(1536, 2, gen)
+    h.update(dim=2, off=0, slot=1)
+    with pytest.raises(L.LnxError, match="lnx_meta_heads_supported"):
+        ops.meta_heads_fwd(meta, [h], torch.zeros(4, 3, 1536, device="cuda"))

@@ -118,11 +118,12 @@ def test_training_loop_pieces_compose_and_learn(augment):
 
 
 def test_bench_line_loss_is_pinned_and_checked_against_the_oracle():
-    """`bench.py` used to print a `loss` that nothing checked.  The driver's own command (`--gpus 1 --steps 20 --warmup 5`,
-    seeded inputs, seeded DropPath draws, 5 warm-up + 11 calibration + 20 timed AdamW steps on one fixed batch) must reproduce the pinned
-    loss of tests/golden/bench_loss.json to 1e-3 -- and the same process must have compared the timed model's loss with the CPU oracle's
-    at the oracle's weights (`cpu_baseline.loss_check`; bench.py raises when they differ by more than its stated tolerance).  The line also
-    carries config 3's per-GPU shape on one GPU (`config3_n1`)."""
+    """`bench.py` used to print a `loss` that nothing checked.  The driver's step counts (`--gpus 1 --steps 20 --warmup 5`;
+    seeded inputs, seeded DropPath draws, 25 AdamW steps on one fixed batch; `--no-sched-calibration`, so that the count of untimed steps does
+    not depend on how many schedules the warm-up compares) must reproduce the pinned loss of tests/golden/bench_loss.json within its stated
+    tolerance (3x the run-to-run spread the float atomics of a few weight-gradient kernels leave after 25 steps) -- and the same process must
+    have compared the timed model's loss with the CPU oracle's at the oracle's weights (`cpu_baseline.loss_check`; bench.py raises when
+    they differ by more than its stated tolerance).  The line also carries config 3's per-GPU shape on one GPU (`config3_n1`)."""
     import json
     import os
     import subprocess
@@ -132,7 +133,7 @@ def test_bench_line_loss_is_pinned_and_checked_against_the_oracle():
     with open(os.path.join(repo, "tests", "golden", "bench_loss.json")) as fh:
         pin = json.load(fh)
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-batch", "8", "--profile-steps", "0"],
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-batch", "8", "--profile-steps", "0", "--no-sched-calibration"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
