@@ -41,8 +41,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mh_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ float4 mh_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff /* uniform */) {
-    const u32x4_mh v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return float4{__builtin_bit_cast(float, v[0]), __builtin_bit_cast(float, v[1]), __builtin_bit_cast(float, v[2]), __builtin_bit_cast(float, v[3])};
+    // (the whole vector is cast at once: __builtin_bit_cast(float, v[i]) on an element of the ext-vector folded all four lanes onto element 0 and
+    // turned the load into a single dword -- hipcc of ROCm 7.2, caught by the op test)
+    const f32x4_t g = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return float4{g[0], g[1], g[2], g[3]};
 }
 __device__ __forceinline__ void stf4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(f32x4_t v) { return float4{v[0], v[1], v[2], v[3]}; }

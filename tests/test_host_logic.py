@@ -283,3 +283,24 @@ def test_counted_waits_match_the_compiled_store_counts():
     ok, lines = mod.audit(arch="gfx950")
     assert ok, "\n".join(lines)
     assert sum("gemm_nt_v9" in ln for ln in lines) >= 6 and sum("gemm_nt_v7" in ln for ln in lines) >= 10, lines
+
+
+def test_design_dispatch_table_is_what_the_library_decides():
+    """DESIGN.md's NT dispatch table (section 6) is generated from lnx_nt_dispatch -- the decision function
+    lnx_gemm_nt itself uses (gemm2.hip: nt_v2_family), callable without a GPU -- and this test regenerates it: a dispatch rule
+    that changes without the document fails here.  Spot checks pin the rules the parity tests rely on."""
+    import importlib.util
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_dispatch_table", os.path.join(repo, "tools", "gen_dispatch_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(repo, "DESIGN.md")) as fh:
+        in_doc = gen.parse(fh.read())
+    assert in_doc is not None, "DESIGN.md has no dispatch-table markers"
+    assert in_doc.strip() == gen.table().strip(), "DESIGN.md section 6 is stale: python tools/gen_dispatch_table.py --write"
+    from linnaeus_amd import _lib as L
+
+    assert gen.query(256 * 199, 1536, 384, "fc1d") == L.NT_KERNEL_V9 and gen.query(256 * 199, 384, 384, "res_f32") == L.NT_KERNEL_V7
+    assert gen.query(128 * 199, 1536, 384, "mul_aux") == L.NT_KERNEL_V7 and gen.query(128 * 199, 4096, 1024, "fc1d") == L.NT_KERNEL_V9
+    assert gen.query(200, 1000, 768, "bias") == L.NT_KERNEL_SKINNY and gen.query(800, 384, 384, "plain") == L.NT_KERNEL_V1

@@ -56,8 +56,8 @@ def table():
 
 
 def parse(text):
-    m = re.search(re.escape(BEGIN) + r"\n(.*?)\n" + re.escape(END), text, re.S)
-    return m.group(1) if m else None
+    m = re.search(re.escape(BEGIN) + r"\n(.*?)" + re.escape(END), text, re.S)
+    return m.group(1).strip() if m else None
 
 
 if __name__ == "__main__":
@@ -66,7 +66,7 @@ if __name__ == "__main__":
         p = os.path.join(REPO, "DESIGN.md")
         s = open(p).read()
         assert parse(s) is not None, "DESIGN.md has no dispatch-table markers"
-        s = re.sub(re.escape(BEGIN) + r"\n.*?\n" + re.escape(END), BEGIN + "\n" + t.replace("\\", "\\\\") + "\n" + END, s, flags=re.S)
+        s = re.sub(re.escape(BEGIN) + r"\n.*?" + re.escape(END), lambda m_: BEGIN + "\n" + t + "\n" + END, s, flags=re.S)
         open(p, "w").write(s)
     else:
         print(t)
