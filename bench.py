@@ -29,6 +29,7 @@ if REPO not in sys.path:
 TASKS = (("taxa_L10", 1000), ("taxa_L20", 300), ("taxa_L30", 80), ("taxa_L40", 20))
 FLOP_PER_IMG = 25.79e9          # fwd+bwd FLOPs per image, mFormerV1_sm @224
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0        # dense fp8 MFMA peak: what an `--dtype fp8` line's roofline is priced against
 PEAK_HBM_GBS = 8000.0
 MEASURED_HBM_COPY_GBS = 5000.0   # what a plain streaming copy gets from this HBM (read + written bytes; tools/ubench/hbm_rw.hip: 4.8-5.3 TB/s)
 
@@ -292,7 +293,9 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
     a_tf = work[0] / (ms[0] * 1e-3) / 1e12
     alg_b = byts[0] / cnt[0]                      # algorithmic bytes per launch
     intensity = work[0] / byts[0]                 # FLOP per algorithmic byte
-    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    # an fp8 line is priced against the fp8 peak: its RoPE-block forward products and their data gradients run on MXFP8 operands
+    peak_tf = PEAK_FP8_TFLOPS if args.dtype == "fp8" else PEAK_BF16_TFLOPS
+    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
     # HBM bytes per launch from the PMC counters: they cannot be read from inside this process, so the figure comes from the
     # committed rocprofv3 --pmc passes of this same command (profiles/*_gemm_nt_traffic.json); null for other workloads
     traffic = traffic_src = None
@@ -306,13 +309,13 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
            "frac_of_measured": round((traffic or alg_b) / launch_s / (MEASURED_HBM_COPY_GBS * 1e9), 4),
            "spec_gbs": PEAK_HBM_GBS, "measured_copy_gbs": MEASURED_HBM_COPY_GBS, "measured_copy_source": "tools/ubench/hbm_rw.hip, profiles/r03_hbm_rw.log",
            "mfma_frac_ceiling_at_spec_hbm": round(min(1.0, intensity / ridge), 3),
-           "mfma_frac_ceiling_at_measured_hbm": round(min(1.0, intensity * MEASURED_HBM_COPY_GBS * 1e9 / (PEAK_BF16_TFLOPS * 1e12)), 3)}
+           "mfma_frac_ceiling_at_measured_hbm": round(min(1.0, intensity * MEASURED_HBM_COPY_GBS * 1e9 / (peak_tf * 1e12)), 3)}
     roofline = {"bound": "hbm" if intensity < ridge else "mfma",
                 "kernel": f"gemm_nt class <{args.dtype}>: forward + data-gradient GEMMs with M >= 1024 (gemm_nt_v2 / v4 one-shot and gemm_nt_v7 / v9 persistent LDS-DMA kernels, fused epilogues)",
-                "achieved": round(a_tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(a_tf / PEAK_BF16_TFLOPS, 4),
+                "achieved": round(a_tf, 2), "peak": peak_tf, "unit": "TFLOP/s", "frac": round(a_tf / peak_tf, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": kernels["gemm_nt"]["avg_launch_us"],
                 "launches_per_step": kernels["gemm_nt"]["launches_per_step"], "flops_per_step": work[0] / n, "hbm": hbm,
-                "note": "frac = achieved / dense bf16 MFMA peak.  The class's FLOP per algorithmic byte is below the ridge, so by its own bytes it is HBM-bound: "
+                "note": f"frac = achieved / dense {'fp8' if args.dtype == 'fp8' else 'bf16'} MFMA peak.  The class's FLOP per algorithmic byte is below the ridge, so by its own bytes it is HBM-bound: "
                         "its MFMA fraction cannot exceed hbm.mfma_frac_ceiling_* at the stated bandwidths",
                 "measured_with": "HIP events around every launch of the class, extra untimed steps, weight-gradient stream OFF (each kernel alone on the chip: "
                                  "rocprofv3 --kernel-trace of `LNX_WGRAD_STREAM=0 python3 bench.py ...` agrees, profiles/*_kernel_stats.csv).  In the timed steps the "
@@ -324,7 +327,7 @@ def live_profile(args, model, state, loss_fn, ips_per_gpu):
         # north-star: ">= 60 % of MFMA peak on the attention + MLP blocks".  FLOPs = the plan's own count for the RoPE blocks
         # (forward + 2x backward; BASELINE.md section 2: 15.94 GFLOP/img for sm @224), time = the block spans of pass 2
         tf = swork[8] / (sms[8] * 1e-3) / 1e12
-        rope = {"frac": round(tf / PEAK_BF16_TFLOPS, 4), "achieved_tflops": round(tf, 2), "ms_per_step": round(sms[8] / n, 3),
+        rope = {"frac": round(tf / peak_tf, 4), "peak_tflops": peak_tf, "achieved_tflops": round(tf, 2), "ms_per_step": round(sms[8] / n, 3),
                 "gflop_per_image": round(swork[8] / n / state["x"].shape[0] / 1e9, 3), "blocks_timed_per_step": scnt[8] // n,
                 "what": "HIP-event spans around every whole RoPE2DMHSABlock forward and backward on the launch stream (LayerNorms, qkv, attention, proj, Mlp, "
                         "weight gradients, reduces; no events between the kernels), untimed extra steps"}

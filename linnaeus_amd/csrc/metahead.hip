@@ -86,47 +86,66 @@ __device__ __forceinline__ float4 col_reduce(float4 v) {
 
 // acc[t] (+)= A[16 rows][K] . W[rows 16 (wave + 8 t) .. +15][K]^T for this wave's NT tiles (every wave has the same number: C % 128 == 0).
 // A rows beyond the batch are clamped by the caller (arow).  The weights come from HBM / the Infinity Cache behind ~2 us of latency (every
-// workgroup of a head streams the same 0.6-16 MB matrix, in step with the others), so D chunks of 16 k stay in flight per wave: with one
-// chunk of prefetch the C = 768 chain took 417 us for 70 us of matrix-core work (round 5).  K % (16 D) == 0; the loop body has no
-// condition (the last D chunks are peeled), so the compiler's waits are counted ones.
+// workgroup of a head streams the same 0.6-4 MB matrix, in step with the others), so D chunks stay in flight per wave: with one chunk of
+// prefetch the C = 768 chain took 417 us for 70 us of matrix-core work (round 5).  A chunk is 32 k = TWO float4 per lane and operand, issued
+// back to back: lanes q = 0..3 of a row then ask for one whole 128-byte line (with 16-k chunks the second half of every line came a chunk
+// later, after the 32 KiB L1 had been flushed by the other waves' 114 KiB per chunk: every line crossed L2 -> CU twice, ~150 GB/s per CU
+// wanted of the ~130 it has).  K % (32 D) == 0; the loop body has no condition (the last D chunks are peeled): counted waits.
 template <int NT, int D>
 __device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
                                              int wave, int lane) {
-    constexpr int G = NT;  // (NT <= 8: every tile's weight chunk is held at once)
     const int c = lane & 15, q = lane >> 4;
-    // (every operand of the chain is far below 2 GiB: C <= 2048 rows of at most 8 KiB, B rows of C floats)
+    // (every operand of the chain is far below 2 GiB: C <= 1024 rows of at most 4 KiB, B rows of C floats)
     const __amdgpu_buffer_rsrc_t ra = mh_rsrc(A), rw = mh_rsrc(W);
     const uint32_t aoff = (uint32_t)(arow * lda + 4 * q) * 4u;
     const uint32_t woff = (uint32_t)((wave * 16 + c) * ldw + 4 * q) * 4u;
     const uint32_t tstride = (uint32_t)(MH_WAVES * 16 * ldw) * 4u;
+    float4 a_buf[D][2], w_buf[D][NT][2];
+    auto load = [&](int d, uint32_t kbytes) __attribute__((always_inline)) {
 #pragma unroll
-    for (int tb = 0; tb < NT; tb += G) {
-        float4 a_buf[D], w_buf[D][G];
-        auto load = [&](int d, uint32_t kbytes) __attribute__((always_inline)) {
-            a_buf[d] = mh_ld(ra, aoff, kbytes);
+        for (int h = 0; h < 2; ++h) a_buf[d][h] = mh_ld(ra, aoff + 64u * h, kbytes);
 #pragma unroll
-            for (int t = 0; t < G; ++t) w_buf[d][t] = mh_ld(rw, woff + (uint32_t)(tb + t) * tstride, kbytes);
-        };
-        auto use = [&](int d) __attribute__((always_inline)) {
-            const float av[4] = {a_buf[d].x, a_buf[d].y, a_buf[d].z, a_buf[d].w};
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < G; ++t) {
-                const float wv[4] = {w_buf[d][t].x, w_buf[d][t].y, w_buf[d][t].z, w_buf[d][t].w};
+            for (int h = 0; h < 2; ++h) w_buf[d][t][h] = mh_ld(rw, woff + (uint32_t)t * tstride + 64u * h, kbytes);
+    };
+    auto use = [&](int d) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[tb + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[tb + t], 0, 0, 0);
-            }
-        };
+        for (int h = 0; h < 2; ++h) {
+            const float av[4] = {a_buf[d][h].x, a_buf[d][h].y, a_buf[d][h].z, a_buf[d][h].w};
 #pragma unroll
-        for (int d = 0; d < D; ++d) load(d, 64u * d);
-        for (int k0 = 16 * D; k0 < K; k0 += 16 * D) {
+            for (int t = 0; t < NT; ++t) {
+                const float wv[4] = {w_buf[d][t][h].x, w_buf[d][t][h].y, w_buf[d][t][h].z, w_buf[d][t][h].w};
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                use(d);
-                load(d, 4u * (uint32_t)(k0 + 16 * d));
+                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[t], 0, 0, 0);
             }
         }
+    };
 #pragma unroll
-        for (int d = 0; d < D; ++d) use(d);
+    for (int d = 0; d < D; ++d) load(d, 128u * d);
+    for (int k0 = 32 * D; k0 < K; k0 += 32 * D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            use(d);
+            load(d, 4u * (uint32_t)(k0 + 32 * d));
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) use(d);
+}
+
+// the K = 16 product in front of the chain (the metadata slice, zero padded): one 16-k chunk
+template <int NT>
+__device__ __forceinline__ void chain_matmul16(f32x4_t (&acc)[NT], const float* __restrict__ A, int arow, const float* __restrict__ W, int64_t ldw, int wave, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    const float4 a = ldf4(A + (int64_t)arow * 16 + 4 * q);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 w = ldf4(W + (int64_t)((wave + MH_WAVES * t) * 16 + c) * ldw + 4 * q);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[t], 0, 0, 0);
     }
 }
 
@@ -185,7 +204,7 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[NT], int wave, int 
 
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBatch bt) {
-    constexpr int FD = NT <= 3 ? 8 : 4;  // weight chunks in flight per wave (chain_matmul); K / 16 = 8 NT is a multiple of it
+    constexpr int FD = NT <= 3 ? 4 : 2;  // 32-k weight chunks in flight per wave (chain_matmul); K / 32 = 4 NT is a multiple of it
     const lnx_meta_head_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBat
     };
     // h0 = ReLU(t0 W0^T + b0), x = LN0(h0)
     zero();
-    chain_matmul<NT, 1>(acc, a.t0, 16, arow, a.w0, a.ldw0, 16, wave, lane);
+    chain_matmul16<NT>(acc, a.t0, arow, a.w0, a.ldw0, wave, lane);
     relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b0, a.ln0_w, a.ln0_b, a.eps, a.h0, a.x, C, a.m0, a.r0, nullptr, red);
     __syncthreads();  // x is read back (every wave needs whole rows of it) through this CU's cache
     // h1 = ReLU(x W1^T + b1), n1 = LN1(h1)
@@ -283,7 +302,7 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[NT], int wave, int lan
 
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBatch bt) {
-    constexpr int BD = NT <= 3 ? 8 : 4;
+    constexpr int BD = NT <= 3 ? 4 : 2;
     const lnx_meta_head_bwd_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;
