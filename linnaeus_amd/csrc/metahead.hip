@@ -113,12 +113,14 @@ __device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float av[4] = {a_buf[d][h].x, a_buf[d][h].y, a_buf[d][h].z, a_buf[d][h].w};
+            // j outside t: consecutive MFMAs go to different accumulators (a dependent fp32 MFMA waits 40 cycles for 32 of issue)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float wv[4] = {w_buf[d][t][h].x, w_buf[d][t][h].y, w_buf[d][t][h].z, w_buf[d][t][h].w};
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[t], 0, 0, 0);
-            }
+                for (int t = 0; t < NT; ++t) {
+                    const float wv[4] = {w_buf[d][t][h].x, w_buf[d][t][h].y, w_buf[d][t][h].z, w_buf[d][t][h].w};
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], av[j], acc[t], 0, 0, 0);
+                }
         }
     };
 #pragma unroll
@@ -204,7 +206,7 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[NT], int wave, int 
 
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBatch bt) {
-    constexpr int FD = NT <= 3 ? 4 : 2;  // 32-k weight chunks in flight per wave (chain_matmul); K / 32 = 4 NT is a multiple of it
+    constexpr int FD = NT <= 4 ? 4 : (NT == 6 ? 3 : 2);  // 32-k weight chunks in flight per wave (chain_matmul); K / 32 = 4 NT is a multiple of it
     const lnx_meta_head_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;
@@ -302,7 +304,7 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[NT], int wave, int lan
 
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBatch bt) {
-    constexpr int BD = NT <= 3 ? 4 : 2;
+    constexpr int BD = NT <= 4 ? 4 : (NT == 6 ? 3 : 2);
     const lnx_meta_head_bwd_args& a = bt.h[blockIdx.y];
     const int row0 = blockIdx.x * MH_ROWS;
     if (row0 >= a.B) return;

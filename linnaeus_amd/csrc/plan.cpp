@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -823,6 +824,16 @@ extern "C" int lnx_plan_logits_ld(const lnx_plan* p, int t) { return (p && t >= 
 
 extern "C" int lnx_plan_bind(lnx_plan* p, const float* const* params, float* const* grads, void* workspace) {
     if (!p || !params || !workspace) FAIL("lnx_plan_bind: null argument");
+    {
+        // One device per process (one process per GPU): the cached CU count, the per-kernel dynamic-LDS attributes (set once per process) and the
+        // two shared side streams belong to the first device a plan is bound on -- a second device would launch with the wrong attributes.
+        static std::atomic<int> bound_dev{-1};
+        int dev = -1;
+        HIPRUN(hipGetDevice(&dev));
+        int expect = -1;
+        if (!bound_dev.compare_exchange_strong(expect, dev) && expect != dev)
+            FAIL("lnx_plan_bind: this process already runs plans on device %d, now device %d is current: the library is one-process-per-GPU", expect, dev);
+    }
     const int n = (int)p->names.size();
     p->P.assign(params, params + n);
     for (int i = 0; i < n; ++i)

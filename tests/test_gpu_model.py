@@ -702,9 +702,10 @@ def test_xl_b128_batch_invariance():
     path with the GELU' / multiply epilogues, and in fp8 mode gemm_nt_mx8_kernel inside the plan (its counter proves it).  Rows 0-1 are the
     inputs of an oracle run.  Stated tolerances (fractions of the logit scale / of the global gradient norm): bf16 0.04 / 0.05 against the oracle as in
     test_xlarge_224_matches_oracle_and_autobatch (measured here 0.008 / 0.012) and 0.02 / 0.03 against the GPU's own B = 2 run (measured 0.004 / 0.009);
-    fp8 0.16 / 0.13 against the oracle (measured 0.105 / 0.086 with these DropPath draws: 22 MXFP8 blocks deep on random-init weights) and 0.07 / 0.07
-    against the B = 2 fp8 run (measured 0.047 / 0.046: the two batches take different bf16 attention / GEMM tilings, and a bf16 rounding flip in a
-    LayerNorm output moves an e4m3 quantisation step of 6 % -- the mode amplifies the bf16 mode's 0.004 about tenfold, as it does the error itself)."""
+    fp8 (MXFP8 forward products AND data gradients, the mode's default since round 5) 0.16 / 0.14 against the oracle (measured 0.105 / 0.109 with
+    these DropPath draws: 22 MXFP8 blocks deep on random-init weights; 0.086 with bf16 data gradients) and 0.07 / 0.11 against the B = 2 fp8 run
+    (measured 0.048 / 0.079: the two batches take different bf16 attention / GEMM tilings, and a bf16 rounding flip in a LayerNorm output or a dY
+    moves an e4m3 quantisation step of 6 % -- the mode amplifies the bf16 mode's 0.004 / 0.009 about tenfold, as it does the error itself)."""
     spec = O.Spec(conv_dims=(256, 512, 1024, 2048), rope_depths=(22, 2), rope_heads=(16, 32), heads=(("taxa_L10", 40), ("taxa_L20", 9)), drop_path_rate=0.2)
     B0, B = 2, 128
     sd = O.seeded_state_dict(O.param_shapes(spec), 4321)
@@ -720,7 +721,7 @@ def test_xl_b128_batch_invariance():
     model = model.cuda()
     loss_of = lambda out, dev: O.probe_loss(out)  # noqa: E731
     n_rope3 = 22
-    for dtype, ftol, gtol, ftol_self, gtol_self in (("bf16", 0.04, 0.05, 0.02, 0.03), ("fp8", 0.16, 0.13, 0.07, 0.07)):
+    for dtype, ftol, gtol, ftol_self, gtol_self in (("bf16", 0.04, 0.05, 0.02, 0.03), ("fp8", 0.16, 0.14, 0.07, 0.11)):
         d = _batch_invariance_case(model, osd, oout, x0, meta0, drops0, xf, metaf, dropsf, spec.heads, loss_of, dtype, ftol, gtol, ftol_self, gtol_self, "xl@224")
         print(f"[xl@224 B=128 / {dtype}] NT launches in the step: {d}")
         if dtype == "bf16":

@@ -8,7 +8,9 @@ R=$GRAFT_REPO_ROOT
 bash $R/tools/profile_round.sh > $R/gpurun_out/${T}_profile_round.log 2>&1 || { echo "profile_round FAILED"; tail -5 $R/gpurun_out/${T}_profile_round.log; exit 1; }
 cd $R
 bash tools/bench_round.sh $T || exit 1
-bash tools/quick_trace.sh ${T}_b128 --batch 128 > gpurun_out/${T}_b128_trace.log 2>&1 || { echo "b128 trace FAILED"; exit 1; }
+python tools/bench_meta.py --batch 256 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_meta_chain.log; python tools/bench_meta.py --batch 128 2>&1 | grep -v amdgpu.ids >> gpurun_out/${T}_meta_chain.log
+python tools/bench_gemm_forms.py xl lg sm 2>&1 | grep -v amdgpu.ids > gpurun_out/${T}_bare_gemm.log
+LNX_WGRAD_STREAM=0 bash tools/quick_trace.sh ${T}_b128 --batch 128 --no-sched-calibration > gpurun_out/${T}_b128_trace.log 2>&1 || { echo "b128 trace FAILED"; exit 1; }
 H=gpurun_out/${T}_cu_hog.log
 : > $H
 for B in 128 256; do

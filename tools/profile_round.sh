@@ -6,7 +6,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_round
 mkdir -p $O
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0"
+# --batch 256: ONE leg (the default N = 1 run also times the 128-image leg config3_n1 since round 5, which would mix two batch sizes into the per-kernel averages);
+# --no-sched-calibration: exactly 13 steps traced
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 --batch 256 --no-sched-calibration"
 # the step as it is timed: weight-gradient products on their own stream beside the data-gradient chain (kernel durations overlap)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_overlap -o r -- python3 $R/bench.py $ARGS > $O/trace_overlap.log 2>&1 &&
 # every kernel alone on the chip (what bench.py's roofline object times; the PMC passes serialise the kernels anyway)
