@@ -24,9 +24,11 @@ constexpr int MH_MAX_HEADS = 4;   // per launch (kernel arguments: 4 x ~300 byte
 
 struct FwdBatch {
     lnx_meta_head_args h[MH_MAX_HEADS];
+    int n;
 };
 struct BwdBatch {
     lnx_meta_head_bwd_args h[MH_MAX_HEADS];
+    int n;
     int block_start[MH_MAX_HEADS + 1];  // weight-gradient launch: first block of each head's tasks
 };
 
@@ -207,8 +209,13 @@ __device__ __forceinline__ void relu_ln_store(f32x4_t (&acc)[NT], int wave, int 
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBatch bt) {
     constexpr int FD = NT <= 4 ? 4 : (NT == 6 ? 3 : 2);  // 32-k weight chunks in flight per wave (chain_matmul); K / 32 = 4 NT is a multiple of it
-    const lnx_meta_head_args& a = bt.h[blockIdx.y];
-    const int row0 = blockIdx.x * MH_ROWS;
+    // blockIdx.x = 8 * row group + head slot: blocks that are equal mod 8 share an XCD under the round-robin placement (speed only), so the 16
+    // row groups of a head stream its weight matrices through ONE L2 -- the first workgroup to touch a line pays the Infinity-Cache / HBM
+    // round trip, the others hit (a CU pulls ~30 GB/s from beyond L2, ~70 GB/s from it: MI355X_MICROARCH.md, indexed rows)
+    const int head = blockIdx.x & 7;
+    if (head >= bt.n) return;
+    const lnx_meta_head_args& a = bt.h[head];
+    const int row0 = (blockIdx.x >> 3) * MH_ROWS;
     if (row0 >= a.B) return;
     __shared__ float red[2 * MH_WAVES * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -305,8 +312,10 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4_t (&dy)[NT], int wave, int lan
 template <int NT>
 __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBatch bt) {
     constexpr int BD = NT <= 4 ? 4 : (NT == 6 ? 3 : 2);
-    const lnx_meta_head_bwd_args& a = bt.h[blockIdx.y];
-    const int row0 = blockIdx.x * MH_ROWS;
+    const int head = blockIdx.x & 7;  // (as meta_chain_fwd_kernel: the row groups of a head on one XCD)
+    if (head >= bt.n) return;
+    const lnx_meta_head_bwd_args& a = bt.h[head];
+    const int row0 = (blockIdx.x >> 3) * MH_ROWS;
     if (row0 >= a.B) return;
     __shared__ float red[2 * MH_WAVES * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
     const int row = row0 + c;
     const bool valid = row < a.B;
     const int arow = valid ? row : a.B - 1;
-    const int rg = blockIdx.x, nrg = (a.B + MH_ROWS - 1) / MH_ROWS;
+    const int rg = blockIdx.x >> 3, nrg = (a.B + MH_ROWS - 1) / MH_ROWS;
     float* const part = a.part;  // [6][nrg][C]: dln2_w, dln2_b, dln1_w, dln1_b, dln0_w, dln0_b
     const int64_t ps = (int64_t)nrg * C;
     f32x4_t acc[NT];
@@ -514,7 +523,8 @@ extern "C" int lnx_meta_heads_fwd(const lnx_meta_head_args* heads, int n_heads, 
             bt.h[i] = a;
             if (a.B > maxB) maxB = a.B;
         }
-        const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
+        bt.n = n;
+        const dim3 grid(8 * ((maxB + MH_ROWS - 1) / MH_ROWS));
         MH_DISPATCH_NT(meta_chain_fwd_kernel, heads[i0].C / 128, grid, (hipStream_t)stream, bt);
         LNX_LAUNCH_CHECK();
         i0 = e;
@@ -544,7 +554,8 @@ extern "C" int lnx_meta_heads_bwd(const lnx_meta_head_bwd_args* heads, int n_hea
             blocks += mh_wgrad_blocks(a.C);
             if (a.B > maxB) maxB = a.B;
         }
-        const dim3 grid((maxB + MH_ROWS - 1) / MH_ROWS, n);
+        bt.n = n;
+        const dim3 grid(8 * ((maxB + MH_ROWS - 1) / MH_ROWS));
         MH_DISPATCH_NT(meta_chain_bwd_kernel, heads[i0].C / 128, grid, (hipStream_t)stream, bt);
         LNX_LAUNCH_CHECK();
         hipLaunchKernelGGL(meta_chain_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);

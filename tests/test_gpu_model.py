@@ -730,9 +730,10 @@ def test_xl_b128_batch_invariance():
             assert d["V9"] >= 7 * n_rope3 and d["V7"] + d["V9"] >= 8 * n_rope3, d
             assert d["MX8"] == 0 and d["FP8"] == 0, d
         else:
-            # the MXFP8 forward products (qkv, fc1, fc2) of the 22 stage-3 blocks on the 256x256 MX kernel; proj and the data gradients stay bf16
-            assert d["MX8"] >= 3 * n_rope3, d
-            assert d["V9"] >= 4 * n_rope3, d
+            # the MXFP8 forward products (qkv, fc1, fc2) and data gradients (proj, fc1, fc2) of the 22 stage-3 blocks on the 256x256 MX kernel; the
+            # proj forward and the qkv data gradient stay bf16 (gemm_nt_v9)
+            assert d["MX8"] >= 6 * n_rope3, d
+            assert d["V9"] >= 2 * n_rope3, d
 
 
 def _config4_case(B):
