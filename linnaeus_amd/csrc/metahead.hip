@@ -93,9 +93,13 @@ __device__ __forceinline__ float4 col_reduce(float4 v) {
 // back to back: lanes q = 0..3 of a row then ask for one whole 128-byte line (with 16-k chunks the second half of every line came a chunk
 // later, after the 32 KiB L1 had been flushed by the other waves' 114 KiB per chunk: every line crossed L2 -> CU twice, ~150 GB/s per CU
 // wanted of the ~130 it has).  K % (32 D) == 0; the loop body has no condition (the last D chunks are peeled): counted waits.
+// chunk0: the k chunk this workgroup starts at (it wraps around).  The row groups of a head would otherwise ask for the same weight lines at
+// the same moment -- sixteen CUs waiting on one set of misses, i.e. ONE CU's worth of unique bytes in flight for the whole head (~30 GB/s:
+// 170 us for the C = 768 forward whatever the batch); staggered, they keep sixteen regions of the matrix in flight and find each other's
+// lines in L2.  (The fp32 sum order then depends on the row group: 1e-7-level differences between rows, none between runs.)
 template <int NT, int D>
 __device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
-                                             int wave, int lane) {
+                                             int wave, int lane, int chunk0) {
     const int c = lane & 15, q = lane >> 4;
     // (every operand of the chain is far below 2 GiB: C <= 1024 rows of at most 4 KiB, B rows of C floats)
     const __amdgpu_buffer_rsrc_t ra = mh_rsrc(A), rw = mh_rsrc(W);
@@ -125,13 +129,19 @@ __device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __
                 }
         }
     };
+    const int nchunks = K / 32;
+    auto kbytes_of = [&](int i) __attribute__((always_inline)) -> uint32_t {  // i-th chunk of this workgroup's walk (uniform)
+        int ch = chunk0 + i;
+        if (ch >= nchunks) ch -= nchunks;
+        return 128u * (uint32_t)ch;
+    };
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(d, 128u * d);
-    for (int k0 = 32 * D; k0 < K; k0 += 32 * D) {
+    for (int d = 0; d < D; ++d) load(d, kbytes_of(d));
+    for (int i0 = D; i0 < nchunks; i0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             use(d);
-            load(d, 4u * (uint32_t)(k0 + 32 * d));
+            load(d, kbytes_of(i0 + d));
         }
     }
 #pragma unroll
@@ -224,6 +234,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBat
     const int row = row0 + c;
     const bool valid = row < a.B;
     const int arow = valid ? row : a.B - 1;
+    const int chunk0 = (int)(((blockIdx.x >> 3) & 15) * (unsigned)(C / 32)) >> 4;  // row group r starts r / 16 of the way through K
     // t0: this component's metadata columns, zero-padded to 16 (lnx_pack_meta's layout; the weight-gradient launch reads it too)
     if (tid < MH_ROWS * 16) {
         const int r = tid >> 4, d = tid & 15;
@@ -242,12 +253,12 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_fwd_kernel(const FwdBat
     __syncthreads();  // x is read back (every wave needs whole rows of it) through this CU's cache
     // h1 = ReLU(x W1^T + b1), n1 = LN1(h1)
     zero();
-    chain_matmul<NT, FD>(acc, a.x, C, arow, a.w1, a.ldw1, C, wave, lane);
+    chain_matmul<NT, FD>(acc, a.x, C, arow, a.w1, a.ldw1, C, wave, lane, chunk0);
     relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b1, a.ln1_w, a.ln1_b, a.eps, a.h1, a.n1, C, a.m1, a.r1, nullptr, red);
     __syncthreads();
     // h2 = ReLU(n1 W2^T + b2), tok = x + LN2(h2) -> the token row of this sample
     zero();
-    chain_matmul<NT, FD>(acc, a.n1, C, arow, a.w2, a.ldw2, C, wave, lane);
+    chain_matmul<NT, FD>(acc, a.n1, C, arow, a.w2, a.ldw2, C, wave, lane, chunk0);
     relu_ln_store<NT>(acc, wave, lane, C, row, valid, a.b2, a.ln2_w, a.ln2_b, a.eps, a.h2, a.tok + a.tok_row_offset, a.tok_row_stride, a.m2, a.r2, a.x, red);
 }
 
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
     const bool valid = row < a.B;
     const int arow = valid ? row : a.B - 1;
     const int rg = blockIdx.x >> 3, nrg = (a.B + MH_ROWS - 1) / MH_ROWS;
+    const int chunk0 = (int)((rg & 15) * (unsigned)(C / 32)) >> 4;
     float* const part = a.part;  // [6][nrg][C]: dln2_w, dln2_b, dln1_w, dln1_b, dln0_w, dln0_b
     const int64_t ps = (int64_t)nrg * C;
     f32x4_t acc[NT];
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
     // d n1 = dp2 . W2 (the transposed copy: w2t[i][o]), then LN1 / ReLU backward
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    chain_matmul<NT, BD>(acc, a.dp2, C, arow, a.w2t, a.ldw2t, C, wave, lane);
+    chain_matmul<NT, BD>(acc, a.dp2, C, arow, a.w2t, a.ldw2t, C, wave, lane, chunk0);
     if (!valid) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};  // clamped duplicate rows must not reach the column sums
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
     // d x = dp1 . W1 + d tok (skip connection of the ResNormLayer), then LN0 / ReLU backward
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = load_dtok(t);
-    chain_matmul<NT, BD>(acc, a.dp1, C, arow, a.w1t, a.ldw1t, C, wave, lane);
+    chain_matmul<NT, BD>(acc, a.dp1, C, arow, a.w1t, a.ldw1t, C, wave, lane, chunk0);
     if (!valid) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(MH_THREADS) void meta_chain_bwd_kernel(const BwdBat
 // rows ONE float4 of dP and ONE of X per lane feed 16 MFMAs (tile (tt, uu) pairs component tt of the dP vector with component uu of
 // the X vector: output row o0 + 4 M + tt, column i0 + 4 N + uu).
 __device__ __forceinline__ void wgrad_block(const float* __restrict__ DP, int64_t lddp, int o0, const float* __restrict__ X, int64_t ldx, int i0, int xcols, int B,
-                                            float* __restrict__ dW, int64_t lddw, int store_cols, int lane) {
+                                            float* __restrict__ dW, int64_t lddw, int store_cols, int lane, int stagger) {
     const int c = lane & 15, q = lane >> 4;
     f32x4_t acc[4][4];
 #pragma unroll
@@ -381,19 +393,31 @@ __device__ __forceinline__ void wgrad_block(const float* __restrict__ DP, int64_
         x = (ok && xin) ? ldf4(xp + (int64_t)m * ldx) : float4{0.f, 0.f, 0.f, 0.f};
     };
     constexpr int D = 8;  // row groups of four in flight (the operands come from L2 / HBM: one group of prefetch left this loop latency-bound)
+    // the walk over the batch rows starts at a task-dependent group and wraps (`stagger`): tasks that share a dP or X column slab would
+    // otherwise ask for the same lines at the same moment (see chain_matmul)
+    const int ngroups = (B + 3) / 4;
+    const int g0 = (int)(((unsigned)stagger % 16u) * (unsigned)ngroups) >> 4;
+    auto group_of = [&](int i) __attribute__((always_inline)) -> int {
+        int gi = g0 + i;
+        if (gi >= ngroups) gi -= ngroups;
+        return gi;
+    };
     float4 d_buf[D], x_buf[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) fetch(4 * d + q, d_buf[d], x_buf[d]);
-    for (int m0 = 0; m0 < B; m0 += 4 * D) {
+    for (int d = 0; d < D; ++d) {
+        if (d < ngroups) fetch(4 * group_of(d) + q, d_buf[d], x_buf[d]);
+        else d_buf[d] = x_buf[d] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int i0 = 0; i0 < ngroups; i0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            if (m0 + 4 * d < B) {  // (uniform)
+            if (i0 + d < ngroups) {  // (uniform)
                 const float dv[4] = {d_buf[d].x, d_buf[d].y, d_buf[d].z, d_buf[d].w}, xv[4] = {x_buf[d].x, x_buf[d].y, x_buf[d].z, x_buf[d].w};
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                     for (int uu = 0; uu < 4; ++uu) acc[tt][uu] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[tt], xv[uu], acc[tt][uu], 0, 0, 0);
-                fetch(m0 + 4 * (d + D) + q, d_buf[d], x_buf[d]);
+                if (i0 + d + D < ngroups) fetch(4 * group_of(i0 + d + D) + q, d_buf[d], x_buf[d]);
             }
         }
     }
@@ -435,13 +459,13 @@ __global__ __launch_bounds__(256) void meta_chain_wgrad_kernel(const BwdBatch bt
         int task = blk * 4 + wave;
         if (task >= mh_wave_tasks(C)) return;
         if (task < nb * nb) {
-            wgrad_block(a.dp2, C, (task / nb) * 64, a.n1, C, (task % nb) * 64, C, B, a.d_w2, C, -1, lane);
+            wgrad_block(a.dp2, C, (task / nb) * 64, a.n1, C, (task % nb) * 64, C, B, a.d_w2, C, -1, lane, task / nb + 5 * (task % nb));
         } else if (task < 2 * nb * nb) {
             task -= nb * nb;
-            wgrad_block(a.dp1, C, (task / nb) * 64, a.x, C, (task % nb) * 64, C, B, a.d_w1, C, -1, lane);
+            wgrad_block(a.dp1, C, (task / nb) * 64, a.x, C, (task % nb) * 64, C, B, a.d_w1, C, -1, lane, task / nb + 5 * (task % nb) + 8);
         } else {
             task -= 2 * nb * nb;
-            wgrad_block(a.dp0, C, task * 64, a.t0, 16, 0, 16, B, a.d_w0, a.dim, a.dim, lane);
+            wgrad_block(a.dp0, C, task * 64, a.t0, 16, 0, 16, B, a.d_w0, a.dim, a.dim, lane, task);
         }
         return;
     }
