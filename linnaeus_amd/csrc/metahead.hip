@@ -93,10 +93,12 @@ __device__ __forceinline__ float4 col_reduce(float4 v) {
 // back to back: lanes q = 0..3 of a row then ask for one whole 128-byte line (with 16-k chunks the second half of every line came a chunk
 // later, after the 32 KiB L1 had been flushed by the other waves' 114 KiB per chunk: every line crossed L2 -> CU twice, ~150 GB/s per CU
 // wanted of the ~130 it has).  K % (32 D) == 0; the loop body has no condition (the last D chunks are peeled): counted waits.
-// chunk0: the k chunk this workgroup starts at (it wraps around).  The row groups of a head would otherwise ask for the same weight lines at
-// the same moment -- sixteen CUs waiting on one set of misses, i.e. ONE CU's worth of unique bytes in flight for the whole head (~30 GB/s:
-// 170 us for the C = 768 forward whatever the batch); staggered, they keep sixteen regions of the matrix in flight and find each other's
-// lines in L2.  (The fp32 sum order then depends on the row group: 1e-7-level differences between rows, none between runs.)
+// chunk0: the k chunk this workgroup starts at (it wraps around), so that the row groups of a head do not ask for the same weight lines at
+// the same moment.  (The fp32 sum order then depends on the row group: 1e-7-level differences between rows, none between runs.)
+// Measured (round 5, tools/bench_meta.py, the chip otherwise idle): none of the memory-side measures -- chunks in flight 2 -> 3 -> 4, whole
+// lines per request, the row groups of a head on one XCD, this stagger -- moved the C = 768 forward off 170 us (matrix-core work: 70 us);
+// the first two fixed the 417 us of the first form.  What is left looks like matrix time + streaming time (4.7 MB per workgroup at the
+// ~50-70 GB/s a CU pulls from L2) in sequence rather than overlapped; not resolved, and hidden in the step (side stream).
 template <int NT, int D>
 __device__ __forceinline__ void chain_matmul(f32x4_t (&acc)[NT], const float* __restrict__ A, int64_t lda, int arow, const float* __restrict__ W, int64_t ldw, int K,
                                              int wave, int lane, int chunk0) {
