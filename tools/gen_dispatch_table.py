@@ -42,8 +42,9 @@ def block_products(C_, hid):
             ("fc2 dgrad", hid, C_, "mul_aux"), ("fc1 dgrad", C_, hid, "plain"), ("proj dgrad", C_, C_, "plain"), ("qkv dgrad", C_, 3 * C_, "plain")]
 
 
-CONFIGS = [("sm @224, 256 img, stage 3", 256 * 199, 384, 1536, 199), ("sm @224, 256 img, stage 4", 256 * 52, 768, 3072, 52),
-           ("sm @224, 128 img, stage 3", 128 * 199, 384, 1536, 199), ("sm @224, 128 img, stage 4", 128 * 52, 768, 3072, 52),
+# (stage 4 of sm -- M = 13 312 / 6 656, C = 768: gemm_nt_v4 / v9 / v7 at 256 images, gemm_nt_v2 at 128 -- is left out of the document's table
+# for length; query() answers for any shape)
+CONFIGS = [("sm @224, 256 img, stage 3", 256 * 199, 384, 1536, 199), ("sm @224, 128 img, stage 3", 128 * 199, 384, 1536, 199),
            ("lg @384, 64 img, stage 3", 64 * 580, 768, 3072, 580), ("xl @224, 128 img, stage 3", 128 * 199, 1024, 4096, 199)]
 
 
