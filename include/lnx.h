@@ -242,8 +242,16 @@ typedef struct lnx_ln_bwd_args {
     void* dx2_8;
     void* dx2_8_scales;
     int64_t lddx2_8;
+    /* round 5.  != 0 (and ws given, dw / db wanted): the column partials stay in ws and their summation into dw / db is postponed to
+     * lnx_layernorm_bwd_flush(), which sums the partials of ALL postponed calls of this host thread in one launch (up to 16; a 17th, or
+     * one on another stream, flushes first).  Every pending call needs its own ws, untouched until the flush. */
+    int defer;
 } lnx_ln_bwd_args;
 int lnx_layernorm_bwd(const lnx_ln_bwd_args* args, void* stream);
+/* sums the postponed column partials into their dw / db (no-op when nothing is pending; `stream` = the postponed calls' stream or NULL) */
+int lnx_layernorm_bwd_flush(void* stream);
+/* forgets them without summing (error paths; lnx_plan_backward does it on entry and when it fails); returns how many */
+int lnx_layernorm_bwd_discard(void);
 
 /* ------------------------------------------------------------------------------------
  * Depthwise 7x7 convolution, padding 3, NHWC (nn.Conv2d(C, C, 7, padding=3, groups=C),
@@ -664,6 +672,8 @@ typedef struct lnx_convmlp_bwd_args {
     int dz_plain;          /* round 4.  != 0: the `dz` written to memory is rowscale * g, WITHOUT the LayerScale factor gamma (inside the
                               kernel the data gradient keeps it): the dY operand of a pwconv2 weight-gradient product whose result
                               lnx_layerscale_apply_wgrad multiplies by gamma afterwards (and reads the LayerScale gradient from) */
+    int ln_defer;          /* round 5.  != 0 (fused LayerNorm form): the fold of the workgroups' column sums into d_ln_w / d_ln_b is postponed to
+                              lnx_layernorm_bwd_flush() together with the postponed LayerNorm backward calls; `ws` must stay untouched until then */
 } lnx_convmlp_bwd_args;
 int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* args, void* stream);
 /* floats of `ws` the fused-LayerNorm backward needs for (C, M), from the same grid choice the launcher makes (0: unsupported C) */

@@ -123,7 +123,7 @@ NT_KERNEL_NONE, NT_KERNEL_V1, NT_KERNEL_V2, NT_KERNEL_SKINNY, NT_KERNEL_V4, NT_K
 EXPORTS = [
     "lnx_last_error", "lnx_version", "lnx_device_cus", "lnx_set_cu_margin",
     "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_nt_dispatch", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_gemm_tn_discard", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
-    "lnx_layernorm_fwd", "lnx_layernorm_bwd",
+    "lnx_layernorm_fwd", "lnx_layernorm_bwd", "lnx_layernorm_bwd_flush", "lnx_layernorm_bwd_discard",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
     "lnx_rope_cos_table", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_layerscale_apply_wgrad", "lnx_fill_rows", "lnx_colsum_rows",
@@ -189,6 +189,7 @@ class LnBwdArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("dx2", C.c_void_p), ("dx2_dtype", C.c_int), ("lddx2", C.c_int64), ("dx2_rowscale", C.c_void_p), ("dx2_rows_per_sample", C.c_int),
         ("dx2_8", C.c_void_p), ("dx2_8_scales", C.c_void_p), ("lddx2_8", C.c_int64),
+        ("defer", C.c_int),
     ]
 
 
@@ -256,7 +257,7 @@ class ConvMlpBwdArgs(C.Structure):
         ("act", C.c_void_p), ("dh", C.c_void_p), ("dz", C.c_void_p), ("dln", C.c_void_p), ("dgamma", C.c_void_p),
         ("y", C.c_void_p), ("ln_w", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("d_ln_w", C.c_void_p), ("d_ln_b", C.c_void_p),
         ("ws", C.c_void_p), ("ws_floats", C.c_int64),
-        ("dz_plain", C.c_int),
+        ("dz_plain", C.c_int), ("ln_defer", C.c_int),
     ]
 
 

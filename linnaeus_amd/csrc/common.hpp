@@ -100,6 +100,8 @@ void set_cu_margin(int m);
 bool tile_sched_static();      // LNX_TILE_SCHED=static, read per launch
 int tile_slot_of(hipStream_t st);  // the counter set launches on this stream draw from (one per stream: a stream's kernels run one after the other); -1 once 64 streams hold one (static stride)
 int device_cus();              // cached multiProcessorCount of the current device (0 on failure)
+// norm.hip: postpone the second stage of a LayerNorm-style column-sum reduction (part[nwg][2C] -> dw, db) to lnx_layernorm_bwd_flush()
+void ln_postpone_reduce(const float* part, int nwg, int C, float* dw, float* db, int slices, hipStream_t st);
 
 // ---------------------------------------------------------------------------------
 // scalar type traits.  T is the storage type of activations / GEMM operands:

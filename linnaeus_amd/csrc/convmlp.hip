@@ -57,6 +57,7 @@ struct CmP {
     float* rstd;
     float* part;                // bwd: per-workgroup partial sums of dw | db, [gridDim.x][2C]
     int64_t part_floats;
+    int ln_defer;               // LNB launches: postpone the column-sum fold to lnx_layernorm_bwd_flush (norm.hip)
     int tile_slot;              // resident-weight kernels: tile counter set of this launch (common.hpp), -1 = static stride
     int dz_plain;               // bwd: the dz written to memory is rowscale * g WITHOUT the LayerScale factor (the data gradient inside the
                                 // kernel keeps it): operand of a pwconv2 weight gradient that lnx_layerscale_apply_wgrad scales afterwards
@@ -1286,6 +1287,10 @@ int launch_fwd_res(const CmP& p, hipStream_t st) {
 }
 // LNB launches: the workgroups' column sums (p.part) are folded into the LayerNorm weight / bias gradient right behind the kernel
 inline int reduce_ln_partials(const CmP& p, int nwg, hipStream_t st) {
+    if (p.ln_defer) {
+        ln_postpone_reduce(p.part, nwg, p.C, p.dlnw, p.dlnb, nwg >= 64 ? 64 : 1, st);
+        return 0;
+    }
     hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * p.C, 256), nwg >= 64 ? 64 : 1), dim3(256), 0, st, p.part, nwg, p.C, p.dlnw, p.dlnb);
     return 0;
 }
@@ -1404,7 +1409,7 @@ extern "C" int lnx_convmlp_bwd(const lnx_convmlp_bwd_args* a, void* stream) {
     if (a->y) LNX_CHECK(a->ln_w && a->mean && a->rstd && a->d_ln_w && a->d_ln_b && a->ws, "lnx_convmlp_bwd: the fused LayerNorm form needs ln_w, mean, rstd, d_ln_w, d_ln_b and ws");
     CmP p{};
     p.y = (const unsigned char*)a->y; p.lnw = a->ln_w; p.mean = const_cast<float*>(a->mean); p.rstd = const_cast<float*>(a->rstd);
-    p.part = a->ws; p.part_floats = a->ws_floats; p.dlnw = a->d_ln_w; p.dlnb = a->d_ln_b;
+    p.part = a->ws; p.part_floats = a->ws_floats; p.dlnw = a->d_ln_w; p.dlnb = a->d_ln_b; p.ln_defer = a->ln_defer;
     p.g = a->g; p.ln = (const unsigned char*)a->ln; p.zin = (const unsigned char*)a->z; p.w1 = (const unsigned char*)a->w1;
     p.w2t = (const unsigned char*)a->w2t; p.w1t = (const unsigned char*)a->w1t; p.b1 = a->b1; p.gamma = a->gamma; p.rowscale = a->rowscale;
     p.act = (unsigned char*)a->act; p.dh = (unsigned char*)a->dh; p.dz = (unsigned char*)a->dz; p.dln = (unsigned char*)a->dln; p.dgamma = a->dgamma;

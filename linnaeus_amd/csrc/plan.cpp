@@ -40,6 +40,8 @@ void lnx_set_error(const char* fmt, ...);
 
 namespace {
 
+constexpr int LN_DEFER_SLOTS = 16;  // == norm.hip's LN_BATCH: postponed LayerNorm-backward reductions per flush
+
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct OpW {          // a GEMM weight in the T-typed operand arena
@@ -131,6 +133,10 @@ struct lnx_plan {
     int64_t o_g[4];           // fp32 gradient streams per stage
     int64_t o_sA, o_sB = 0, o_sC, o_sD; // T scratch: [M,4C] / [M,4C] (fused conv-MLP backward) / [M,C] / [M,C]
     int64_t o_lnws = 0, lnws_floats = 0, o_lnws_side = 0, lnws_side_floats = 0;
+    int64_t lnws_defer_floats = 0;
+    int64_t o_lnws_defer = 0;  // LN_DEFER_SLOTS partial-sum regions of lnws_defer_floats each: LayerNorm backward calls whose second stage waits for the segment's flush
+    int ln_pending = 0;        // ... how many of them are in use since the last flush
+    bool ln_defer = true;      // LNX_LN_DEFER=0: every LayerNorm backward reduces its column partials at once (A/B)
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_lsws = 0, lsws_floats = 0;  // S | T scratch of the z-free LayerScale gradient
     int64_t o_gcos /* freqs-gradient partials of lnx_attn_bwd */, o_delta, o_dt1, o_tail[6], o_mtmp[4], o_dlT;
@@ -344,6 +350,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->c = c;
     p->esz = c.dtype == LNX_BF16 ? 2 : 4;
     p->meta_chain = !(getenv("LNX_META_CHAIN") && atoi(getenv("LNX_META_CHAIN")) == 0);
+    p->ln_defer = !(getenv("LNX_LN_DEFER") && atoi(getenv("LNX_LN_DEFER")) == 0);
     for (int s = 0; s < 2; ++s) p->chain_ok[s] = p->meta_chain && lnx_meta_heads_supported(c.dims[2 + s]) != 0;
     p->E = 1 + c.n_meta;
     p->H[0] = c.img_h / 4;
@@ -697,6 +704,19 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->lnws_side_floats = (int64_t)256 * 2 * D[3];
     if (!inf) {
         p->o_lnws = cv.take(p->lnws_floats * 4);
+        {   // a postponed LayerNorm backward keeps its column partials until the segment's flush: LN_DEFER_SLOTS regions, each as large as the
+            // largest launch-stream LayerNorm of this plan wants (workgroups x 2C floats; the kernel caps its grid by the region it is given)
+            const int64_t rows[5] = {(int64_t)B * p->HW[0], (int64_t)B * p->HW[1], (int64_t)B * p->N2, (int64_t)B * p->N3, (int64_t)B};
+            const int64_t wide[5] = {D[0], D[1], D[2], D[3], D[3]};
+            int64_t need = 0;
+            for (int i = 0; i < 5; ++i) {
+                int64_t wgs = (rows[i] + 7) / 8;
+                if (wgs > 2048) wgs = 2048;
+                if (wgs * 2 * wide[i] > need) need = wgs * 2 * wide[i];
+            }
+            p->lnws_defer_floats = need;
+            p->o_lnws_defer = cv.take(need * 4 * LN_DEFER_SLOTS);
+        }
         p->o_lnws_side = cv.take(p->lnws_side_floats * 4);
         p->o_tnws = cv.take((int64_t)LNX_TN_WS_FLOATS * 4 * TN_WS_SLOTS);
         {   // pwconv2 weight / bias gradient of dY = rs g, before the LayerScale factor (lnx_layerscale_apply_wgrad): [C, 4C] + [C] fp32
@@ -792,6 +812,7 @@ static hipStream_t shared_stream(int which) {
 extern "C" void lnx_plan_destroy(lnx_plan* p) {
     if (!p) return;
     (void)lnx_gemm_tn_discard();  // no postponed reduce of this thread may outlive the workspace / gradient arena it points into
+    (void)lnx_layernorm_bwd_discard();
     if (p->side) {
         (void)hipStreamSynchronize(p->side);  // (shared_stream: not destroyed)
         (void)hipEventDestroy(p->ev_fork);
@@ -1056,6 +1077,19 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     const bool on_side = c.p->side != nullptr && c.st == (void*)c.p->side;
     a.ws = c.at<float>(on_side ? c.p->o_lnws_side : c.p->o_lnws);
     a.ws_floats = on_side ? c.p->lnws_side_floats : c.p->lnws_floats;
+    // Launch-stream calls postpone their column-sum reduce to the segment's flush (ln_flush below): each takes a partial-sum region of
+    // its own until then.  22 reduce launches of ~8 us per step become 4.
+    lnx_plan* p = c.p;
+    if (p->ln_defer && !on_side && c.st != (void*)p->wgs && p->o_lnws_defer != 0 && (a.dw || a.db)) {
+        if (p->ln_pending == LN_DEFER_SLOTS) {
+            RUN(lnx_layernorm_bwd_flush(c.st));
+            p->ln_pending = 0;
+        }
+        a.ws = c.at<float>(p->o_lnws_defer) + (int64_t)p->ln_pending * p->lnws_defer_floats;
+        a.ws_floats = p->lnws_defer_floats;
+        a.defer = 1;
+        ++p->ln_pending;
+    }
     return lnx_layernorm_bwd(&a, c.st);
 }
 
@@ -1639,6 +1673,16 @@ int conv_block_bwd(const Ctx& c, int s, int i, float* g) {
             f.y = c.at<void>(k.y); f.ln_w = p->P[k.lnw]; f.mean = c.at<float>(k.mean); f.rstd = c.at<float>(k.rstd);
             f.d_ln_w = p->G[k.lnw]; f.d_ln_b = p->G[k.lnb];
             f.ws = c.at<float>(p->o_lnws); f.ws_floats = p->lnws_floats;
+            if (p->ln_defer && p->o_lnws_defer != 0 && lnx_convmlp_bwd_ws_floats(C, M) <= p->lnws_defer_floats) {  // (as ln_bwd: folded at the segment's flush)
+                if (p->ln_pending == LN_DEFER_SLOTS) {
+                    RUN(lnx_layernorm_bwd_flush(c.st));
+                    p->ln_pending = 0;
+                }
+                f.ws = c.at<float>(p->o_lnws_defer) + (int64_t)p->ln_pending * p->lnws_defer_floats;
+                f.ws_floats = p->lnws_defer_floats;
+                f.ln_defer = 1;
+                ++p->ln_pending;
+            }
         }
         {
             Timed t(c, 7, 2.0 * M * C * 4 * C * 3);
@@ -1799,6 +1843,16 @@ int rope_block_restore(const Ctx& c, int s, int i) {
     return rope_block_fwd(c, s, i, xout);
 }
 
+// the postponed LayerNorm column-sum reductions of this segment -> their gradients (one launch)
+int ln_flush(const Ctx& c) {
+    lnx_plan* p = c.p;
+    if (p->ln_pending > 0) {
+        RUN(lnx_layernorm_bwd_flush(c.st));
+        p->ln_pending = 0;
+    }
+    return 0;
+}
+
 int join_side(const Ctx& c, int s) {
     lnx_plan* p = c.p;
     if (p->meta_forked[s]) {  // (what tokens_bwd(s) did, whatever the mode has been switched to since)
@@ -1819,9 +1873,15 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     // call that failed midway left behind is dropped here, and whatever THIS call leaves behind on an error path is dropped when it
     // returns (every block flushes its own products, so a call that succeeds leaves nothing).
     (void)lnx_gemm_tn_discard();
+    (void)lnx_layernorm_bwd_discard();
+    p->ln_pending = 0;
     struct TnGuard {
-        ~TnGuard() { (void)lnx_gemm_tn_discard(); }
-    } tn_guard;
+        lnx_plan* p;
+        ~TnGuard() {
+            (void)lnx_gemm_tn_discard();
+            if (lnx_layernorm_bwd_discard() > 0) p->ln_pending = 0;  // (a successful call has flushed everything: nothing to drop)
+        }
+    } tn_guard{p};
     const lnx_mformer_cfg& cf = p->c;
     if (segment <= 0) p->dy8_ready = false;
     Ctx c{p, stream, cf.dtype};
@@ -1909,6 +1969,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         // produces parameter gradients, and joining here exposed most of its ~0.7 ms behind the three downsample kernels.
         // That holds for segment-wise callers too (segments run 0..3 in order): the gradients of the stage-4 metadata heads
         // are reported as final after segment 1, those of the stage-3 heads after segment 2 (lnx_plan_segment_params).
+        RUN(ln_flush(c));
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);
@@ -1919,6 +1980,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         RUN(tokens_bwd(c, 0, g2));
         const lnx_rowmap gm = {p->HW[2], p->E, p->E};
         RUN(downsample_bwd(c, 1, g2, D[2], gm, c.at<float>(p->o_stage_out[1]), LNX_F32, D[1], IDM, c.at<float>(p->o_g[1]), LNX_F32, D[1]));
+        RUN(ln_flush(c));
         RUN(join_side(c, 1));
     }
     if (all || segment == 2) {
@@ -1928,6 +1990,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
             RUN(conv_block_bwd(c, 1, i, g1));
         }
         RUN(downsample_bwd(c, 0, g1, D[1], IDM, c.at<float>(p->o_stage_out[0]), LNX_F32, D[0], IDM, c.at<float>(p->o_g[0]), LNX_F32, D[0]));
+        RUN(ln_flush(c));
         RUN(join_side(c, 0));  // stage-3 metadata heads: hidden behind the whole ConvNeXt stage-2 backward
     }
     if (all || segment == 3) {
@@ -1942,6 +2005,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
                    c.at<float>(p->o_stem_rstd), nullptr, sC, cf.dtype, D[0], false));
         const int kst = cf.in_chans * 16;
         RUN(wgrad(c, M0, D[0], 64, sC, D[0], c.at<void>(p->o_patches), 64, p->stem_w.param, p->stem_b, kst, kst));
+        RUN(ln_flush(c));
     }
     return 0;
 }

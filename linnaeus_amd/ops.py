@@ -178,7 +178,7 @@ def layernorm_fwd(x, w, b, y, eps, *, M=None, C_=None, ldx=None, ldy=None, x_map
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=None, lddx=None, dy_map=None, x_map=None, gin=None,
-                  ldgin=None, dw=None, db=None, relu_mask=False, ws=None, dx2=None, dx2_rowscale=None, dx2_rows_per_sample=0, dx2_8=None, dx2_8_scales=None):
+                  ldgin=None, dw=None, db=None, relu_mask=False, ws=None, dx2=None, dx2_rowscale=None, dx2_rows_per_sample=0, dx2_8=None, dx2_8_scales=None, defer=False):
     a = L.LnBwdArgs()
     a.M = M if M is not None else dy.shape[0]
     a.C = C_ if C_ is not None else x.shape[-1]
@@ -189,6 +189,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=N
     a.dx, a.dx_dtype, a.lddx = _p(dx), code_of(dx), (lddx if lddx is not None else dx.stride(-2))
     a.dw, a.db, a.relu_mask = _p(dw), _p(db), int(relu_mask)
     a.ws, a.ws_floats = _p(ws), (ws.numel() if ws is not None else 0)
+    a.defer = int(defer)  # column-sum reduce postponed to layernorm_bwd_flush() (needs ws, one per pending call)
     if dx2 is not None:  # second output: rowscale[m // rows_per_sample] * dx in dx2's type (+ its MXFP8 copy)
         a.dx2, a.dx2_dtype, a.lddx2 = _p(dx2), code_of(dx2), dx2.stride(-2)
         a.dx2_rowscale, a.dx2_rows_per_sample = _p(dx2_rowscale), int(dx2_rows_per_sample)
@@ -196,6 +197,10 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, *, M=None, C_=None, lddy=None, ldx=N
             a.dx2_8, a.dx2_8_scales, a.lddx2_8 = _p(dx2_8), _p(dx2_8_scales), dx2_8.stride(-2)
     L.check(L.lib().lnx_layernorm_bwd(C.byref(a), _stream()), "lnx_layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_flush():
+    L.check(L.lib().lnx_layernorm_bwd_flush(_stream()), "lnx_layernorm_bwd_flush")
 
 
 def dwconv7(x, w49, bias, y, *, flip=False, res=None):

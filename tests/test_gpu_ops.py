@@ -895,3 +895,73 @@ def test_meta_head_chain_refuses_widths_it_does_not_carry():
     h.update(dim=2, off=0, slot=1)
     with pytest.raises(L.LnxError, match="lnx_meta_heads_supported"):
         ops.meta_heads_fwd(meta, [h], torch.zeros(4, 3, 1536, device="cuda"))
+
+
+def test_layernorm_bwd_postponed_reductions_in_one_launch():
+    """lnx_ln_bwd_args.defer + lnx_layernorm_bwd_flush (round 5): the column-sum second stages of several LayerNorm backward calls -- the
+    widths and row counts of a training step's launch-stream LayerNorms: RoPE blocks, downsample layers, the tail -- in ONE launch.  Nothing
+    reaches dw / db before the flush; afterwards they hold what the immediate path gives (float atomics over 64 slices either way: 1e-5), dx is
+    untouched by the switch, a flush on another stream is refused, discard forgets them, and a 17th pending call flushes the first 16 itself."""
+    import ctypes
+
+    gen = g(5)
+    cases = [(50944, 384), (13312, 768), (256, 768), (200704, 96), (12544, 384), (256, 384)]
+    packs = []
+    for M, C in cases:
+        x = (torch.randn(M, C, generator=gen) + 0.3).cuda()
+        dy = torch.randn(M, C, generator=gen).cuda().bfloat16()
+        w = (torch.rand(C, generator=gen) + 0.5).cuda()
+        packs.append((x, dy, w, x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()))
+
+    def run(defer):
+        outs = []
+        for x, dy, w, mean, rstd in packs:
+            M, C = x.shape
+            dx = torch.empty(M, C, device="cuda")
+            dw, db = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.5, device="cuda")
+            ws = torch.empty(2048 * 2 * C, device="cuda")
+            ops.layernorm_bwd(dy, x, w, mean, rstd, dx, dw=dw, db=db, ws=ws, defer=defer)
+            outs.append((dx, dw, db, ws))
+        return outs
+
+    now = run(False)
+    torch.cuda.synchronize()
+    later = run(True)
+    torch.cuda.synchronize()
+    for dx, dw, db, _ in later:  # nothing summed yet
+        assert torch.equal(dw, torch.full_like(dw, 0.5)) and torch.equal(db, torch.full_like(db, -0.5))
+    other = torch.cuda.Stream()
+    with pytest.raises(L.LnxError, match="another stream"):
+        L.check(L.lib().lnx_layernorm_bwd_flush(ctypes.c_void_p(other.cuda_stream)), "lnx_layernorm_bwd_flush")
+    ops.layernorm_bwd_flush()
+    torch.cuda.synchronize()
+    for (dx0, dw0, db0, _), (dx1, dw1, db1, _), (x, dy, w, mean, rstd) in zip(now, later, packs):
+        assert torch.equal(dx0, dx1)
+        scale = max(1.0, dw0.abs().max().item())
+        torch.testing.assert_close(dw1, dw0, rtol=1e-5, atol=1e-5 * scale)
+        torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-5 * max(1.0, db0.abs().max().item()))
+        xh = ((x - mean[:, None]) * rstd[:, None]).double()
+        torch.testing.assert_close((dw1 - 0.5).double(), (dy.double() * xh).sum(0), rtol=1e-4, atol=1e-4 * scale)
+    ops.layernorm_bwd_flush()  # nothing pending: a no-op
+    # discard: pending calls are forgotten, dw stays
+    x, dy, w, mean, rstd = packs[2]
+    dw, db = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+    ws = torch.empty(2048 * 2 * 768, device="cuda")
+    ops.layernorm_bwd(dy, x, w, mean, rstd, torch.empty_like(x), dw=dw, db=db, ws=ws, defer=True)
+    assert L.lib().lnx_layernorm_bwd_discard() == 1
+    ops.layernorm_bwd_flush()
+    torch.cuda.synchronize()
+    assert float(dw.abs().sum()) == 0.0
+    # seventeen pending calls: the 17th makes the library flush the first sixteen
+    many = []
+    for i in range(17):
+        dwi, dbi = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+        wsi = torch.empty(2048 * 2 * 768, device="cuda")
+        ops.layernorm_bwd(dy, x, w, mean, rstd, torch.empty_like(x), dw=dwi, db=dbi, ws=wsi, defer=True)
+        many.append((dwi, wsi, dbi))  # (everything a pending descriptor points at stays alive until the flush)
+    torch.cuda.synchronize()
+    assert all(float(m_[0].abs().sum()) > 0 for m_ in many[:16]) and float(many[16][0].abs().sum()) == 0.0
+    ops.layernorm_bwd_flush()
+    torch.cuda.synchronize()
+    for m_ in many:
+        torch.testing.assert_close(m_[0], many[0][0], rtol=1e-5, atol=1e-5 * max(1.0, many[0][0].abs().max().item()))
