@@ -1080,7 +1080,8 @@ int ln_bwd(const Ctx& c, int M, int C, const void* dy, int dydt, int64_t lddy, l
     // Launch-stream calls postpone their column-sum reduce to the segment's flush (ln_flush below): each takes a partial-sum region of
     // its own until then.  22 reduce launches of ~8 us per step become 4.
     lnx_plan* p = c.p;
-    if (p->ln_defer && !on_side && c.st != (void*)p->wgs && p->o_lnws_defer != 0 && (a.dw || a.db)) {
+    const bool on_wgs = p->wgs != nullptr && c.st == (void*)p->wgs;  // (the launch stream may be the null stream: compare only with streams that exist)
+    if (p->ln_defer && !on_side && !on_wgs && p->o_lnws_defer != 0 && (a.dw || a.db)) {
         if (p->ln_pending == LN_DEFER_SLOTS) {
             RUN(lnx_layernorm_bwd_flush(c.st));
             p->ln_pending = 0;
