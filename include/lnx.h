@@ -294,6 +294,16 @@ int lnx_rope_cos_table(const float* freqs /* [2,heads,32] */, int heads, int H, 
                        float* dsin_out /* optional [2][H*W,heads,32]: -t_x sin(theta), -t_y sin(theta) = d cos(theta) / d freqs[a] (what
                                           lnx_attn_bwd weights its pair gradients with) */,
                        void* stream);
+/* The same tables for several blocks in one launch (each RoPE block owns its freqs, rope_2d_mhsa.py:397-408; a plan fills the
+ * tables of all its blocks once per forward, off the main stream).  Entries as lnx_rope_cos_table's arguments. */
+#define LNX_ROPE_TABLES_MAX 24
+typedef struct {
+    const float* freqs; /* [2,heads,32] */
+    float* cos_out;     /* [H*W,heads,32] */
+    float* dsin_out;    /* optional [2][H*W,heads,32] */
+    int heads, H, W, pad_;
+} lnx_rope_table;
+int lnx_rope_cos_tables(const lnx_rope_table* tables, int n, void* stream);
 /* floats of lnx_attn_bwd's freqs-gradient workspace (one [2][32] partial per workgroup of its finest tiling) */
 int64_t lnx_attn_bwd_ws_floats(int B, int N, int heads);
 

@@ -1255,10 +1255,8 @@ extern "C" int lnx_dbg_attn_stamps(unsigned long long* out8) { return (int)hipMe
 // ---------------------------------------------------------------------------------
 // cos table and its backward to the learnable freqs
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out,
-                                                       float* __restrict__ dsin) {
+__device__ __forceinline__ void rope_cos_entry(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out, float* __restrict__ dsin, int i) {
     const int total = H * W * heads * 32;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int j = i & 31;
     const int h = (i >> 5) % heads;
@@ -1275,6 +1273,20 @@ __global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__
         dsin[i] = tx * ms;
         dsin[total + i] = ty * ms;
     }
+}
+
+__global__ __launch_bounds__(256) void rope_cos_kernel(const float* __restrict__ freqs, int heads, int H, int W, float* __restrict__ out,
+                                                       float* __restrict__ dsin) {
+    rope_cos_entry(freqs, heads, H, W, out, dsin, blockIdx.x * 256 + threadIdx.x);
+}
+
+// the tables of several blocks in one launch (every RoPE block of a plan has its own freqs): blockIdx.y picks the table
+struct RopeTabBatch {
+    lnx_rope_table t[LNX_ROPE_TABLES_MAX];
+};
+__global__ __launch_bounds__(256) void rope_cos_batch_kernel(const RopeTabBatch b) {
+    const lnx_rope_table& t = b.t[blockIdx.y];
+    rope_cos_entry(t.freqs, t.heads, t.H, t.W, t.cos_out, t.dsin_out, blockIdx.x * 256 + threadIdx.x);
 }
 
 // dfreqs[a, h, j] += sum over the workgroups of head h of their partial [a][j]   (fixed order: deterministic given the partials)
@@ -1323,6 +1335,24 @@ extern "C" int lnx_rope_cos_table(const float* freqs, int heads, int H, int W, f
     const int total = H * W * heads * 32;
     hipLaunchKernelGGL(rope_cos_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, freqs, heads, H, W, cos_out, dsin_out);
     LNX_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int lnx_rope_cos_tables(const lnx_rope_table* t, int n, void* stream) {
+    LNX_CHECK(t && n > 0, "lnx_rope_cos_tables: bad arguments");
+    for (int i = 0; i < n; ++i) LNX_CHECK(t[i].freqs && t[i].cos_out && t[i].heads > 0 && t[i].H > 0 && t[i].W > 0, "lnx_rope_cos_tables: bad table");
+    for (int i0 = 0; i0 < n; i0 += LNX_ROPE_TABLES_MAX) {
+        RopeTabBatch b{};
+        const int m = n - i0 < LNX_ROPE_TABLES_MAX ? n - i0 : LNX_ROPE_TABLES_MAX;
+        int most = 0;
+        for (int i = 0; i < m; ++i) {
+            b.t[i] = t[i0 + i];
+            const int total = t[i0 + i].H * t[i0 + i].W * t[i0 + i].heads * 32;
+            if (total > most) most = total;
+        }
+        hipLaunchKernelGGL(rope_cos_batch_kernel, dim3(cdiv(most, 256), m), dim3(256), 0, (hipStream_t)stream, b);
+        LNX_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -1324,7 +1324,6 @@ int rope_block_fwd(const Ctx& c, int s, int i, float* xout) {
     lnx_gemm_args g = gemm_base(c, M, 3 * C, C, c.at<void>(k.n1), C, c.wptr(k.qkv), k.qkv.ld, c.at<void>(k.qkvbuf), 3 * C, false);
     g.bias = p->P[k.qkvb];
     RUN(linear_fwd(c, g, k.qkv, p->o_a8, p->o_a8s));
-    RUN(lnx_rope_cos_table(p->P[k.freqs], heads, p->H[2 + s], p->W[2 + s], c.at<float>(k.cos), p->c.inference ? nullptr : c.at<float>(k.dsin), c.st));
     lnx_attn_args a;
     memset(&a, 0, sizeof a);
     a.dtype = c.dt; a.B = B; a.N = N; a.E = E; a.heads = heads;
@@ -1423,8 +1422,21 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
                 for (int m = 0; m < cf.n_meta; ++m) RUN(meta_head_fwd(cs, s2, m, meta, mw_all, c.at<float>(p->o_tok[s2]), s2 == 0 ? p->N2 : p->N3));
             }
         }
-        HIPRUN(hipEventRecord(p->ev_meta, mst));
     }
+    {   // the cos tables of every RoPE block in one launch (each block owns its freqs); beside the stem and the ConvNeXt stages when there
+        // is a side stream, which the RoPE stages join below.  A checkpointed block's re-forward reads the same tables.
+        std::vector<lnx_rope_table> tabs;
+        for (int s = 0; s < 2; ++s)
+            for (auto& k : p->rope[s]) {
+                lnx_rope_table t;
+                memset(&t, 0, sizeof t);
+                t.freqs = p->P[k.freqs]; t.heads = cf.rope_heads[s]; t.H = p->H[2 + s]; t.W = p->W[2 + s];
+                t.cos_out = c.at<float>(k.cos); t.dsin_out = cf.inference ? nullptr : c.at<float>(k.dsin);
+                tabs.push_back(t);
+            }
+        if (!tabs.empty()) RUN(lnx_rope_cos_tables(tabs.data(), (int)tabs.size(), mst ? (void*)mst : stream));
+    }
+    if (mst) HIPRUN(hipEventRecord(p->ev_meta, mst));
 
     // 1. stem: 4x4/4 patchify conv as im2col + GEMM, then channels-first LN (mFormerV1.py:145-148)
     const int M0 = B * p->HW[0];

@@ -230,6 +230,15 @@ def rope_cos_table(freqs, H, W, out=None, dsin=None):
     return out
 
 
+def rope_cos_tables(entries):
+    """The tables of several blocks in one launch: entries = [(freqs [2,heads,32], H, W, cos_out, dsin_out or None), ...]."""
+    arr = (L.RopeTable * len(entries))()
+    for t, (freqs, H, W, out, dsin) in zip(arr, entries):
+        t.freqs, t.cos_out, t.dsin_out = _p(freqs), _p(out), _p(dsin) if dsin is not None else None
+        t.heads, t.H, t.W = freqs.shape[1], H, W
+    L.check(L.lib().lnx_rope_cos_tables(arr, len(entries), _stream()), "lnx_rope_cos_tables")
+
+
 def attn_bwd_ws_floats(B, N, heads):
     fn = L.lib().lnx_attn_bwd_ws_floats
     fn.restype = C.c_int64

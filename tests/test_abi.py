@@ -50,6 +50,7 @@ def test_ctypes_mirrors_have_the_sizes_the_c_compiler_gives(tmp_path):
         "lnx_prep_desc": L.PrepDesc, "lnx_softce_args": L.SoftCEArgs, "lnx_mix_args": L.MixArgs, "lnx_adamw_desc": L.AdamWDesc,
         "lnx_adamw_hyper": L.AdamWHyper, "lnx_convmlp_args": L.ConvMlpArgs, "lnx_convmlp_bwd_args": L.ConvMlpBwdArgs,
         "lnx_mformer_cfg": _Cfg, "lnx_meta_head_args": L.MetaHeadArgs, "lnx_meta_head_bwd_args": L.MetaHeadBwdArgs,
+        "lnx_rope_table": L.RopeTable,
     }
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "lnx.h"\nint main(void) {\n' +

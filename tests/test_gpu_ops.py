@@ -186,6 +186,27 @@ def _attn_ref(qkv, freqs, B, N, E, heads, H, W, drop=None):
     return (a @ v).transpose(1, 2).reshape(B * N, C_)
 
 
+def test_rope_cos_tables_of_many_blocks_in_one_launch():
+    """lnx_rope_cos_tables (what a plan calls once per forward) writes, for each entry, exactly what lnx_rope_cos_table writes for
+    it alone: mixed grids and head counts, with and without the d-cos table, and more entries than one launch carries."""
+    shapes = [(6, 14, 14), (12, 7, 7), (3, 5, 9), (6, 14, 14)] * 7  # 28 > LNX_ROPE_TABLES_MAX (24): two launches
+    entries, want = [], []
+    for i, (heads, H, W) in enumerate(shapes):
+        freqs = O.seeded_fill(f"t.cos_tables.{i}", (2, heads, 32), 3 + i).cuda()
+        with_dsin = i % 3 != 1
+        out = torch.full((H * W, heads, 32), float("nan"), device="cuda")
+        dsin = torch.full((2, H * W, heads, 32), float("nan"), device="cuda") if with_dsin else None
+        entries.append((freqs, H, W, out, dsin))
+        d1 = torch.empty(2, H * W, heads, 32, device="cuda") if with_dsin else None
+        want.append((ops.rope_cos_table(freqs, H, W, dsin=d1), d1))
+    ops.rope_cos_tables(entries)
+    torch.cuda.synchronize()
+    for (_, _, _, out, dsin), (c1, d1) in zip(entries, want):
+        assert torch.equal(out, c1)
+        if dsin is not None:
+            assert torch.equal(dsin, d1)
+
+
 @pytest.mark.parametrize("B,heads,H,W,E", [(2, 2, 3, 5, 3), (1, 6, 14, 14, 3), (2, 4, 7, 7, 3), (1, 2, 12, 12, 4), (2, 1, 2, 2, 1), (1, 2, 24, 24, 4), (2, 2, 20, 20, 4)])
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
