@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"], help="fp8: bf16 plus MXFP8 forward products in the RoPE blocks (config 5)")
     ap.add_argument("--no-optim", action="store_true", help="time forward+backward only")
     ap.add_argument("--force-dp", action="store_true", help="single GPU rehearsal of the data-parallel path: RCCL world size 1, collectives issued")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="with --gpus N > 1 on a box with ONE GPU: all N ranks use cuda:0 and the collectives run over gloo (RCCL refuses two ranks on "
+                         "one device).  Exercises every line of the N > 1 path with real ranks; the line it prints is marked as a rehearsal and is "
+                         "NOT a throughput or scaling measurement")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW(fused=True) instead of linnaeus_amd.optim.FusedAdamW")
     ap.add_argument("--drop-in", action="store_true",
                     help="time the model the way the reference's train.py:147-176,279-316 drives it: torch cross_entropy per task, "
@@ -389,6 +393,9 @@ def main():
     legs = legs_for(2 if (args.force_dp and world == 1) else world, args.batch)  # --force-dp: the N > 1 legs rehearsed on one GPU
     if world == 1 and not args.force_dp and len(legs) > 1 and (args.arch != "sm" or args.img != 224 or args.host_input or args.flat_file or args.drop_in or args.recompute):
         legs = legs[:1]  # config3_n1 belongs to the headline workload only
+    rehearsal = bool(args.rehearse_one_gpu and world > 1)
+    if rehearsal:
+        local = 0  # every rank on the one card
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # stdout carries the one JSON line and nothing else: anything a library prints on the way (RCCL's version banner goes to
@@ -405,12 +412,20 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29544")
             dist.init_process_group("nccl", rank=0, world_size=1)
+        elif rehearsal:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl")
         # No device_id= here on purpose: binding the process group to the device at init (eager communicator creation) makes
         # EVERY step ~1 ms slower on this stack (13.6 -> 14.6 ms at batch 128, with no collective ever issued;
         # tools/bench_segments.py --pg [--lazy]); the lazily created communicator does not.  torch.cuda.set_device() above
         # tells RCCL which GPU this rank owns; barriers name it explicitly.
+
+    def barrier():
+        if rehearsal:
+            dist.barrier()  # (gloo takes no device_ids)
+        else:
+            dist.barrier(device_ids=[local])
 
     torch.manual_seed(42 + rank)
     cfg, model = make_model(args)
@@ -554,7 +569,7 @@ def main():
                 step()
                 torch.cuda.synchronize()
                 if dist:
-                    dist.barrier(device_ids=[local])
+                    barrier()
                 t = time.perf_counter()
                 for _ in range(n):
                     step()
@@ -590,7 +605,7 @@ def main():
             step()
         torch.cuda.synchronize()
         if dist:
-            dist.barrier(device_ids=[local])
+            barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -598,7 +613,7 @@ def main():
         host_dt = time.perf_counter() - t0  # the host's share: Python + launch calls, returned before the GPU has finished
         torch.cuda.synchronize()
         if dist:
-            dist.barrier(device_ids=[local])
+            barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist:
@@ -618,7 +633,7 @@ def main():
                 for _ in range(2):
                     step()
                 torch.cuda.synchronize()
-                dist.barrier(device_ids=[local])
+                barrier()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(k):
@@ -655,7 +670,7 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        dist.barrier(device_ids=[local])
+        barrier()
         net.telemetry = False
         dp_diag = {"buckets": net.bucket_report(), "stream_budget": net.stream_budget(),
                    "what": "buckets: bytes all-reduced per backward segment and the time from issue (the segment's kernels enqueued) to done (the collective's end "
@@ -673,7 +688,7 @@ def main():
     if dist:
         # every rank gets here before any communicator is torn down (rank 0 has just run its profiled steps alone)
         torch.cuda.synchronize()
-        dist.barrier(device_ids=[local])
+        barrier()
     for fn in cleanup:
         fn()
     if rank != 0:
@@ -744,6 +759,10 @@ def main():
     if args.flat_file:
         line["config"]["workload"] += ("; inputs read every step from a memory-mapped synthetic flat file by a loader thread, uint8 over PCIe through "
                                        "DevicePrefetcher, uint8 -> float NCHW on the device (PCIe- and reader-inclusive, NOT the headline)")
+    if rehearsal:
+        line["rehearsal"] = (f"{world} ranks sharing ONE GPU, collectives over gloo (--rehearse-one-gpu): exercises the N > 1 code path with real ranks; "
+                             "value / ms_per_step are NOT a throughput or scaling measurement")
+        line["config"]["workload"] = line["config"]["workload"].replace("RCCL gradient all-reduce", "gloo gradient all-reduce (REHEARSAL on one GPU)")
     if args.drop_in:
         line["config"]["workload"] = line["config"]["workload"].replace("forward + 4-task CE loss + backward", "DROP-IN: torch CE + loss.backward() + clip_grad_norm_ + torch.optim.AdamW (reference train.py glue)")
     sys.stdout.flush()

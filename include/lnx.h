@@ -612,8 +612,10 @@ typedef struct lnx_adamw_hyper {
     float omb1[LNX_ADAMW_MAX_GROUPS], omb2[LNX_ADAMW_MAX_GROUPS];       /* 1 - beta, rounded from double (1 - 0.999f loses 1e-5) */
 } lnx_adamw_hyper;
 int lnx_adamw_blocks(int64_t numel);
-/* out[0] = sum over all tensors of g^2 (zeroed by the call) */
-int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, void* stream);
+/* out[0] = sum over all tensors of g^2.  ws: total_blocks floats (one partial per workgroup, folded in a fixed order by a second
+ * launch): the same gradients give the same bits on every data-parallel rank, so the clip coefficient -- and with it the
+ * replicas' parameters -- cannot drift apart (clip_grad_norm_ of train.py:282-308 is deterministic in the same sense). */
+int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, float* ws, void* stream);
 /* sumsq == NULL or max_norm <= 0: no clipping */
 int lnx_adamw_step(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, const lnx_adamw_hyper* hyper, const float* sumsq, float max_norm,
                    void* stream);

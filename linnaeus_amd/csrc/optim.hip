@@ -2,8 +2,9 @@
 // Replaces, for the model's parameters: torch.optim.AdamW.step (decoupled weight decay, bias correction) as built
 // by linnaeus/optimizers/build.py, and the gradient-norm / clip passes of train.py:282-308
 // (clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)), gradients scaled by coef).
-// Two launches per step over a device descriptor table (one entry per parameter tensor): sum of squares of all
-// gradients, then the update, which reads the clip coefficient from that scalar.
+// Launches per step over a device descriptor table (one entry per parameter tensor): sum of squares of all gradients
+// (partials per workgroup + a fixed-order fold; only when clipping), then the update, which reads the clip coefficient
+// from that scalar.
 #include "common.hpp"
 #include "../../include/lnx.h"
 
@@ -21,7 +22,10 @@ __device__ __forceinline__ const lnx_adamw_desc& find_desc(const lnx_adamw_desc*
     return descs[lo];
 }
 
-__global__ __launch_bounds__(256) void grad_sumsq_kernel(const lnx_adamw_desc* __restrict__ descs, int ndesc, float* __restrict__ out) {
+// one partial per workgroup, folded in a fixed order by grad_sumsq_fold_kernel: the same gradients give the same bits on every
+// rank and every run.  (A float atomicAdd per workgroup did not: the clip coefficient then differs in its last bits between
+// data-parallel ranks that hold identical all-reduced gradients, and their parameters drift apart step by step.)
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const lnx_adamw_desc* __restrict__ descs, int ndesc, float* __restrict__ part) {
     __shared__ float red[4];
     const lnx_adamw_desc& d = find_desc(descs, ndesc, blockIdx.x);
     const int64_t base = (int64_t)(blockIdx.x - d.block_start) * OPT_ELEMS;
@@ -43,7 +47,29 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const lnx_adamw_desc* _
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(1024) void grad_sumsq_fold_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four independent chains per thread: loads in flight
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        s0 += part[i];
+        s1 += part[i + 1024];
+        s2 += part[i + 2048];
+        s3 += part[i + 3072];
+    }
+    for (; i < n; i += 1024) s0 += part[i];
+    float s = wave_sum((s0 + s1) + (s2 + s3));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k];
+        *out = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(const lnx_adamw_desc* __restrict__ descs, int ndesc, const lnx_adamw_hyper h, const float* __restrict__ sumsq,
@@ -114,11 +140,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const lnx_adamw_desc* __rest
 
 extern "C" int lnx_adamw_blocks(int64_t numel) { return (int)((numel + OPT_ELEMS - 1) / OPT_ELEMS); }
 
-extern "C" int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, void* stream) {
-    LNX_CHECK(descs_dev && ndesc > 0 && total_blocks > 0 && out, "lnx_grad_sumsq: bad arguments");
+extern "C" int lnx_grad_sumsq(const lnx_adamw_desc* descs_dev, int ndesc, int total_blocks, float* out, float* ws, void* stream) {
+    LNX_CHECK(descs_dev && ndesc > 0 && total_blocks > 0 && out && ws, "lnx_grad_sumsq: bad arguments (ws: total_blocks floats)");
     hipStream_t st = (hipStream_t)stream;
-    LNX_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
-    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(total_blocks), dim3(256), 0, st, descs_dev, ndesc, out);
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(total_blocks), dim3(256), 0, st, descs_dev, ndesc, ws);
+    hipLaunchKernelGGL(grad_sumsq_fold_kernel, dim3(1), dim3(1024), 0, st, ws, total_blocks, out);
     LNX_LAUNCH_CHECK();
     return 0;
 }

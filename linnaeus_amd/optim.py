@@ -1,6 +1,7 @@
 """Optimizer + step glue on device: `FusedAdamW` is a `torch.optim.Optimizer` whose
-`step()` is two HIP launches for the whole model -- the sum of squares of every gradient, then a multi-tensor AdamW
-update with the global-norm clip folded in (csrc/optim.hip) -- instead of `clip_grad_norm_` (the reference makes three
+`step()` is one HIP launch for the whole model, three with clipping -- the sum of squares of every gradient (per-workgroup
+partials + a fixed-order fold: bit-identical on every data-parallel rank), then a multi-tensor AdamW update with the
+global-norm clip folded in (csrc/optim.hip) -- instead of `clip_grad_norm_` (the reference makes three
 gradient passes with host syncs, train.py:282-308) followed by `torch.optim.AdamW.step`.
 
 Same update rule and `param_groups` / `state_dict` layout as `torch.optim.AdamW` (per-group `lr`, `betas`, `eps`,
@@ -27,6 +28,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = None
         self._key = None
         self._sumsq = None
+        self._sumsq_ws = None
 
     # ------------------------------------------------------------------ descriptor table
     def _build(self, items):
@@ -43,6 +45,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = (host.to(dev), len(items), blk)
         if self._sumsq is None or self._sumsq.device != dev:
             self._sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        if self._sumsq_ws is None or self._sumsq_ws.device != dev or self._sumsq_ws.numel() < blk:
+            self._sumsq_ws = torch.empty(blk, device=dev, dtype=torch.float32)  # one partial per workgroup (lnx_grad_sumsq: fixed-order fold)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -92,7 +96,8 @@ class FusedAdamW(torch.optim.Optimizer):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         if clip:
-            L.check(lib.lnx_grad_sumsq(C.c_void_p(table.data_ptr()), n, blocks, C.c_void_p(self._sumsq.data_ptr()), stream), "lnx_grad_sumsq")
+            L.check(lib.lnx_grad_sumsq(C.c_void_p(table.data_ptr()), n, blocks, C.c_void_p(self._sumsq.data_ptr()), C.c_void_p(self._sumsq_ws.data_ptr()), stream),
+                    "lnx_grad_sumsq")
         L.check(lib.lnx_adamw_step(C.c_void_p(table.data_ptr()), n, blocks, C.byref(h), C.c_void_p(self._sumsq.data_ptr()) if clip else None,
                                    C.c_float(self.max_grad_norm if clip else 0.0), stream), "lnx_adamw_step")
         return loss

@@ -96,7 +96,17 @@ def _worker(rank, world, port, q, batch):
             losses.append(float(loss))
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().flatten() for p in model.parameters()])
-        res["params_agree_after_steps"] = all(torch.equal(flat, o) for o in _gathered(flat, world))
+        others = _gathered(flat, world)
+        res["params_agree_after_steps"] = all(torch.equal(flat, o) for o in others)
+        if not res["params_agree_after_steps"]:  # say which tensors, for the failure message
+            off, bad = 0, []
+            for name, p in model.named_parameters():
+                n = p.numel()
+                d = max(float((flat[off:off + n] - o[off:off + n]).abs().max()) for o in others)
+                if d > 0:
+                    bad.append((name, d))
+                off += n
+            res["drifted"] = f"{len(bad)} tensors, e.g. {bad[:4]}"
         res["losses"] = losses
         res["streams"] = dp.stream_budget()["count"]
     except Exception as e:  # noqa: BLE001 -- reported to the parent, which fails the test with it
@@ -131,6 +141,6 @@ def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step():
         # bf16 plan, same batch twice: split-K partial order is fixed, the few float atomics (LayerScale / bias column sums) are not
         assert r["rel_err"] < 2e-3, r
         assert r["ranks_agree"], "ranks hold different gradients after the all-reduce"
-        assert r["params_agree_after_steps"], "parameters drifted apart over three optimizer steps"
+        assert r["params_agree_after_steps"], "parameters drifted apart over three clipped optimizer steps: " + r.get("drifted", "")
         assert all(b > 0 for b in r["buckets"]) and r["streams"] <= 4
     assert res[0]["losses"] != res[1]["losses"]  # (each rank reports the loss of its own batch)

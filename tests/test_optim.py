@@ -1,4 +1,4 @@
-"""Optimizer + step glue on device: FusedAdamW (two HIP launches: gradient sum of squares, multi-tensor
+"""Optimizer + step glue on device: FusedAdamW (gradient sum of squares in a fixed order, multi-tensor
 AdamW with the clip folded in) against clip_grad_norm_ + torch.optim.AdamW, and on the reference's train-step fixture."""
 import numpy as np
 import pytest
@@ -36,6 +36,26 @@ def test_fused_adamw_matches_torch(clip):
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["step"] == 4
     for a, b in zip(pa, pb):
         torch.testing.assert_close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def test_clip_norm_is_the_same_bits_every_time():
+    """Data-parallel replicas hold identical all-reduced gradients and must take identical steps: the gradient norm the clip
+    reads is folded in a fixed order (it was a float atomicAdd per workgroup: last-bit differences between ranks, replicas
+    drifting apart -- found by tests/test_gpu_ddp_two_ranks.py).  Many workgroups (6 M gradients), many repeats."""
+    from linnaeus_amd.optim import FusedAdamW
+
+    g = torch.Generator().manual_seed(3)
+    ps = [torch.randn(n, generator=g).cuda().requires_grad_(True) for n in (4_000_003, 1_500_000, 777, 4096 * 100 + 1)]
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).cuda() * 3e-2
+    want = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ps))
+    opt = FusedAdamW(ps, lr=0.0, weight_decay=0.0, max_grad_norm=1.0)  # (lr 0: the gradients and parameters stay as they are)
+    seen = set()
+    for _ in range(25):
+        opt.step()
+        seen.add(float(opt.grad_norm()))
+    assert len(seen) == 1, seen
+    assert abs(seen.pop() - float(want)) <= 2e-6 * float(want)
 
 
 def test_fused_step_on_reference_train_fixture(golden_dir):
