@@ -95,6 +95,17 @@ typedef struct lnx_gemm_args {
 
 int lnx_gemm_nt(const lnx_gemm_args* args, void* stream);
 
+/* Several small products in ONE launch (a wave per 32 x 32 output tile, operands straight from L2): what the model's tail needs for its
+ * classification heads (mFormerV1.py:536-541) -- the same M = batch product once per head, forward and data gradient.
+ *   accumulate == 0: n independent problems, each with its own A / W / C / bias / res / M / N / K (e.g. logits_t = feats . W_t^T + b_t);
+ *   accumulate == 1: C = bias + res + sum_j A_j . W_j^T in one accumulator chain (e.g. d feats = sum_t dlogits_t . W_t); M, N, C, ldc,
+ *                    bias, res are taken from problem 0, A / lda / W / ldw / K from every problem.
+ * bf16 operands, plain addressing, no activation / scales / second output; all problems the same out_f32.  lnx_gemm_nt_group_ok says
+ * (host side, no device work) whether a list qualifies; lnx_gemm_nt_group fails loudly on one that does not. */
+#define LNX_GEMM_GROUP_MAX 8
+int lnx_gemm_nt_group_ok(const lnx_gemm_args* problems, int n, int accumulate);
+int lnx_gemm_nt_group(const lnx_gemm_args* problems, int n, int accumulate, void* stream);
+
 /* Which kernel family the NT dispatchers (lnx_gemm_nt, lnx_gemm_nt_fp8, lnx_gemm_nt_mxfp8) chose (host-side bookkeeping, no device work): the parity tests use it to prove
  * that a shape really ran on the kernel it is meant to cover (e.g. the persistent gemm_nt_v7 at the benchmark's M = 50 944).
  * lnx_last_nt_kernel(): family of the most recent NT launch of this process (any stream), 0 before the first.

@@ -434,6 +434,35 @@ extern "C" int lnx_gemm_nt(const lnx_gemm_args* a, void* stream) {
     return 0;
 }
 
+extern "C" int lnx_gemm_nt_group_ok(const lnx_gemm_args* a, int n, int accumulate) {
+    if (!a || n < 1 || n > LNX_GEMM_GROUP_MAX) return 0;
+    for (int j = 0; j < n; ++j) {
+        const lnx_gemm_args& t = a[j];
+        if (t.dtype != LNX_BF16 || t.M <= 0 || t.N <= 0 || t.K <= 0 || t.K % 8 != 0 || !t.A || !t.W || t.lda % 8 != 0 || t.ldw % 8 != 0) return 0;
+        if ((((uintptr_t)t.A) & 15) != 0 || (((uintptr_t)t.W) & 15) != 0) return 0;
+        if (t.a_mode != LNX_ADDR_PLAIN || t.c_mode != LNX_ADDR_PLAIN || t.c_map.group > 0) return 0;
+        if (t.act != LNX_ACT_NONE || t.gamma || t.rowscale || t.aux || t.c2 || t.c8) return 0;
+        if (t.out_f32 != a[0].out_f32) return 0;
+        if (accumulate && j > 0) {
+            if (t.M != a[0].M || t.N != a[0].N || t.bias || t.res) return 0;  // (term 0 carries the output and its epilogue operands)
+        } else {
+            if (!t.C || (t.res && !t.out_f32) || (t.out_f32 && (((uintptr_t)t.C) & 15) != 0)) return 0;
+        }
+    }
+    return 1;
+}
+
+extern "C" int lnx_gemm_nt_group(const lnx_gemm_args* a, int n, int accumulate, void* stream) {
+    LNX_CHECK(lnx_gemm_nt_group_ok(a, n, accumulate), "lnx_gemm_nt_group: 1..%d bf16 problems with plain addressing, bias / fp32 residual epilogues only, K and "
+              "leading dimensions multiples of 8, 16-byte aligned operands; accumulate: same M, N and the output / bias / res in term 0", LNX_GEMM_GROUP_MAX);
+    GemmP ps[LNX_GEMM_GROUP_MAX];
+    for (int j = 0; j < n; ++j) fill_gemm_p(&a[j], ps[j]);
+    note_nt_kernel(LNX_NT_KERNEL_SKINNY);
+    launch_nt_skinny_group(ps, n, accumulate != 0, a[0].out_f32 != 0, (hipStream_t)stream);
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int lnx_gemm_tn(const lnx_wgrad_args* a, void* stream) {
     LNX_CHECK(a != nullptr, "lnx_gemm_tn: null args");
     LNX_CHECK(a->dtype == LNX_F32 || a->dtype == LNX_BF16, "lnx_gemm_tn: bad dtype %d", a->dtype);

@@ -471,6 +471,7 @@ void note_nt_kernel(int kind);
 // gemm_skinny.hip: M <= 256 (one wave per 32x32 output tile, operands straight from L2)
 bool nt_skinny_ok(const GemmP& p, int dtype, bool out_f32);
 int launch_nt_skinny(const GemmP& p, bool out_f32, hipStream_t st);
+int launch_nt_skinny_group(const GemmP* ps, int n, bool accumulate, bool out_f32, hipStream_t st);  // lnx_gemm_nt_group
 
 // gemm2.hip: 256x128 LDS-DMA pipelined kernels (bf16)
 int launch_nt_v2(const GemmP& p, bool out_f32, hipStream_t st);

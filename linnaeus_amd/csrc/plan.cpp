@@ -683,10 +683,9 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
         p->o_featsT = cv.take((int64_t)B * D[3] * esz);
         for (int i = 0; i < 6; ++i) p->o_tail[i] = cv.take((int64_t)B * D[3] * 4);
         for (int i = 0; i < 4; ++i) p->o_mtmp[i] = cv.take((int64_t)B * (D[3] > D[2] ? D[3] : D[2]) * 4);
-        int maxld = 8;
-        for (int t = 0; t < c.n_tasks; ++t)
-            if (p->logit_ld[t] > maxld) maxld = p->logit_ld[t];
-        p->o_dlT = cv.take((int64_t)B * maxld * esz);
+        // dlogits in storage type: every task's [B, ld_t] block at its logits offset (one cast for all heads; the heads' weight gradients
+        // read their blocks from the weight-gradient stream while the data gradient runs)
+        p->o_dlT = cv.take((p->logits_numel > 8 ? p->logits_numel : 8) * esz);
     }
     if (c.fp8) {
         int64_t mc = 0, mh = 0;
@@ -1017,6 +1016,31 @@ int gemm_nt_t(const Ctx& c, const lnx_gemm_args* a) {
     // kernel, partly on the side stream) are not counted
     Timed t(c, a->M >= 1024 ? 0 : -1, 2.0 * a->M * a->N * a->K, nt_bytes(c, a));
     return lnx_gemm_nt(a, c.st);
+}
+
+// The classification heads' products (M = batch rows): every head in one launch (lnx_gemm_nt_group) where the list qualifies -- bf16 plans --
+// otherwise one launch per head.  accumulate: C = res + sum_t A_t . W_t^T (the data gradient wrt the features); hg[0] carries C / res.
+int heads_nt(const Ctx& c, lnx_gemm_args* hg, int n, bool accumulate) {
+    static const bool off = getenv("LNX_HEADS_GROUP") != nullptr && atoi(getenv("LNX_HEADS_GROUP")) == 0;  // A/B switch
+    for (int t0 = 0; t0 < n; t0 += LNX_GEMM_GROUP_MAX) {
+        const int m = n - t0 < LNX_GEMM_GROUP_MAX ? n - t0 : LNX_GEMM_GROUP_MAX;
+        lnx_gemm_args* g = hg + t0;
+        if (accumulate && t0 > 0) {  // a second group adds onto what the first one wrote
+            g[0].C = hg[0].C; g[0].ldc = hg[0].ldc; g[0].res = (const float*)hg[0].C; g[0].ldres = hg[0].ldc;
+        }
+        if (!off && lnx_gemm_nt_group_ok(g, m, accumulate ? 1 : 0)) {
+            RUN(lnx_gemm_nt_group(g, m, accumulate ? 1 : 0, c.st));
+            continue;
+        }
+        for (int t = 0; t < m; ++t) {
+            lnx_gemm_args a = g[t];
+            if (accumulate && t > 0) {
+                a.C = g[0].C; a.ldc = g[0].ldc; a.res = (const float*)g[0].C; a.ldres = g[0].ldc;
+            }
+            RUN(gemm_nt_t(c, &a));
+        }
+    }
+    return 0;
 }
 
 lnx_gemm_args gemm_base(const Ctx& c, int M, int N, int K, const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, bool out_f32) {
@@ -1537,12 +1561,13 @@ extern "C" int lnx_plan_forward(lnx_plan* p, const float* x, const float* meta, 
         if (feats) HIPRUN(hipMemcpyAsync(feats, c.at<float>(p->o_feats), (size_t)B * C * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         if (cf.n_tasks > 0) {
             RUN(lnx_scale_cast(c.at<float>(p->o_feats), C, IDM, nullptr, 0, c.at<void>(p->o_featsT), cf.dtype, C, B, C, stream));
+            lnx_gemm_args hg[LNX_MAX_TASKS];
             for (int t = 0; t < cf.n_tasks; ++t) {
-                lnx_gemm_args g = gemm_base(c, B, cf.task_classes[t], C, c.at<void>(p->o_featsT), C, c.wptr(p->head_w[t]), p->head_w[t].ld,
-                                            logits + p->logit_off[t], p->logit_ld[t], true);
-                g.bias = p->P[p->head_b[t]];
-                RUN(gemm_nt_t(c, &g));
+                hg[t] = gemm_base(c, B, cf.task_classes[t], C, c.at<void>(p->o_featsT), C, c.wptr(p->head_w[t]), p->head_w[t].ld, logits + p->logit_off[t],
+                                  p->logit_ld[t], true);
+                hg[t].bias = p->P[p->head_b[t]];
             }
+            RUN(heads_nt(c, hg, cf.n_tasks, false));  // every head in one launch where the grouped kernel takes them
         }
     }
     p->fwd_done = true;
@@ -1906,26 +1931,34 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     if (all || segment == 0) {
         const int C = D[3];
         float* dfe = c.at<float>(p->o_tail[0]);  // d feats [B, C]
-        bool have = false;
+        bool have = false, heads_forked = false;
         if (dfeats) {
             HIPRUN(hipMemcpyAsync(dfe, dfeats, (size_t)B * C * 4, hipMemcpyDeviceToDevice, st));
             have = true;
         }
         if (cf.n_tasks > 0) {
             if (!dlogits) FAIL("lnx_plan_backward: dlogits is NULL");
+            // one cast of the whole dlogits buffer (task blocks are contiguous, padding columns included); the heads' weight gradients go to the
+            // weight-gradient stream (joined at the end of this segment), their data gradients are ONE accumulating launch
+            unsigned char* dl0 = c.at<unsigned char>(p->o_dlT);
+            RUN(lnx_scale_cast(dlogits, p->logits_numel, IDM, nullptr, 0, dl0, cf.dtype, p->logits_numel, 1, (int)p->logits_numel, stream));
+            const Ctx cw = wg_ctx(c);
+            RUN(wg_fork(c, 3));
+            lnx_gemm_args hg[LNX_MAX_TASKS];
             for (int t = 0; t < cf.n_tasks; ++t) {
                 const int ld = p->logit_ld[t], nc = cf.task_classes[t];
-                void* dl = c.at<void>(p->o_dlT);
-                RUN(lnx_scale_cast(dlogits + p->logit_off[t], ld, IDM, nullptr, 0, dl, cf.dtype, ld, B, ld, stream));
-                RUN(wgrad(c, B, nc, C, dl, ld, c.at<void>(p->o_featsT), C, p->head_w[t].param, p->head_b[t], C));
-                lnx_gemm_args a = gemm_base(c, B, C, ld, dl, ld, c.wtptr(p->head_w[t]), p->head_w[t].ld_t, dfe, C, true);
-                if (have) {
-                    a.res = dfe;
-                    a.ldres = C;
-                }
-                RUN(gemm_nt_t(c, &a));
-                have = true;
+                void* dl = dl0 + p->logit_off[t] * p->esz;
+                RUN(wgrad(cw, B, nc, C, dl, ld, c.at<void>(p->o_featsT), C, p->head_w[t].param, p->head_b[t], C));
+                hg[t] = gemm_base(c, B, C, ld, dl, ld, c.wtptr(p->head_w[t]), p->head_w[t].ld_t, dfe, C, true);
             }
+            RUN(wg_done(c, 3));
+            heads_forked = true;
+            if (have) {
+                hg[0].res = dfe;
+                hg[0].ldres = C;
+            }
+            RUN(heads_nt(c, hg, cf.n_tasks, true));
+            have = true;
         }
         if (!have) FAIL("lnx_plan_backward: neither dlogits nor dfeats given");
         // final_norm
@@ -1983,6 +2016,7 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
         // That holds for segment-wise callers too (segments run 0..3 in order): the gradients of the stage-4 metadata heads
         // are reported as final after segment 1, those of the stage-3 heads after segment 2 (lnx_plan_segment_params).
         RUN(ln_flush(c));
+        if (heads_forked) RUN(wg_join(c, 3));  // (the weight-gradient stream runs in order: every RoPE block's joins already imply this one)
     }
     if (all || segment == 1) {
         float* g2 = c.at<float>(p->o_g[2]);

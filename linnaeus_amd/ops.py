@@ -71,6 +71,23 @@ def gemm_nt(A, W, out, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     return out
 
 
+def gemm_nt_group(problems, accumulate=False):
+    """Several small bf16 products in one launch (lnx_gemm_nt_group).  problems: [(A, W, out, bias or None, res or None), ...];
+    accumulate: out_0 = bias_0 + res_0 + sum_j A_j . W_j^T (the outputs / epilogue operands of the other entries are ignored: pass None)."""
+    arr = (L.GemmArgs * len(problems))()
+    for a, (A, W, out, bias, res) in zip(arr, problems):
+        a.dtype = code_of(W)
+        a.M, a.N, a.K = A.shape[0], W.shape[0], W.shape[1]
+        a.A, a.lda, a.W, a.ldw = _p(A), A.stride(0), _p(W), W.stride(0)
+        ref = out if out is not None else problems[0][2]
+        a.C, a.ldc, a.out_f32 = _p(out), (out.stride(0) if out is not None else 0), int(ref.dtype == torch.float32)
+        a.bias = _p(bias)
+        a.res, a.ldres = _p(res), (res.stride(0) if res is not None else 0)
+    if not L.lib().lnx_gemm_nt_group_ok(arr, len(problems), int(accumulate)):
+        raise L.LnxError("lnx_gemm_nt_group: the problem list does not qualify")
+    L.check(L.lib().lnx_gemm_nt_group(arr, len(problems), int(accumulate), _stream()), "lnx_gemm_nt_group")
+
+
 def quantize_fp8(x, *, amax=None):
     """(x8, scale): x8 = e4m3fn(x * 448 / max|x|) as a torch.float8_e4m3fn tensor, scale = max|x| / 448 (device scalar).
     `amax`: a device scalar to use instead of this tensor's own maximum (delayed scaling)."""

@@ -119,8 +119,9 @@ def _worker(rank, world, port, q, batch):
             dist.destroy_process_group()
 
 
-def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step():
-    world, batch = 2, 8
+@pytest.mark.parametrize("batch", [8, 64])  # 64: 12 736 token rows, the persistent kernels and the weight-gradient stream under load
+def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step(batch):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -80,6 +80,61 @@ def test_nt_skinny_batch_rows(M, N, K, with_res):
         torch.testing.assert_close(out2.float(), (A.double() @ W.double().T).float(), rtol=8e-3, atol=8e-3)
 
 
+@pytest.mark.parametrize("M", [256, 128, 100, 7])
+def test_nt_group_heads_in_one_launch(M):
+    """lnx_gemm_nt_group, the two forms the model's tail uses (mFormerV1.py:536-541, four heads of 1000 / 300 / 80 / 20 classes on
+    768 features).  Independent problems: every head's logits block of one flat buffer (padded leading dimensions) is bit for
+    bit what lnx_gemm_nt writes for that head alone, and nothing outside the blocks' live columns is touched.  Accumulate: the
+    data gradient wrt the features, res + sum_t dlogits_t . W_t over the padded class rows, against fp64 and against the
+    head-by-head chain of single launches it replaces."""
+    from linnaeus_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(11 + M)
+    Cf, classes = 768, (1000, 300, 80, 20)
+    lds = [(c + 7) // 8 * 8 for c in classes]
+    feats = torch.randn(M, Cf, generator=g).cuda().bfloat16()
+    Ws = [(torch.randn(c, Cf, generator=g) / Cf**0.5).cuda().bfloat16() for c in classes]
+    bs = [torch.randn(c, generator=g).cuda() for c in classes]
+    flat = torch.full((M * sum(lds),), float("nan"), device="cuda")
+    flat1 = flat.clone()
+    views, views1, off = [], [], 0
+    for c, ld in zip(classes, lds):
+        views.append(flat[off:off + M * ld].view(M, ld)[:, :c])
+        views1.append(flat1[off:off + M * ld].view(M, ld)[:, :c])
+        off += M * ld
+    ops.gemm_nt_group([(feats, W, v, b, None) for W, v, b in zip(Ws, views, bs)])
+    for W, v, b in zip(Ws, views1, bs):
+        ops.gemm_nt(feats, W, v, bias=b)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(flat, nan=-7.0), torch.nan_to_num(flat1, nan=-7.0))  # same bits, same untouched padding
+    for W, v, b in zip(Ws, views, bs):
+        torch.testing.assert_close(v.double(), feats.double() @ W.double().T + b.double(), rtol=2e-5, atol=8e-5)
+
+    # accumulate: d feats = res + sum_t dl_t . Wt_t^T with Wt_t = W_t^T stored [Cf, ld_t] (zero padding columns, as the plan's arena holds them)
+    dls, Wts = [], []
+    for c, ld, W in zip(classes, lds, Ws):
+        d = torch.zeros(M, ld)
+        d[:, :c] = torch.randn(M, c, generator=g) / 30
+        dls.append(d.cuda().bfloat16())
+        wt = torch.zeros(Cf, ld, device="cuda", dtype=torch.bfloat16)
+        wt[:, :c] = W.T
+        Wts.append(wt)
+    res = torch.randn(M, Cf, generator=g).cuda()
+    want = res.double() + sum(d.double() @ wt.double().T for d, wt in zip(dls, Wts))
+    for with_res in (True, False):
+        out = torch.full((M, Cf), float("nan"), device="cuda")
+        probs = [(dls[0], Wts[0], out, None, res if with_res else None)] + [(d, wt, None, None, None) for d, wt in zip(dls[1:], Wts[1:])]
+        ops.gemm_nt_group(probs, accumulate=True)
+        torch.testing.assert_close(out.double(), want if with_res else want - res.double(), rtol=2e-5, atol=2e-5)
+    chain = res.clone()
+    for d, wt in zip(dls, Wts):
+        ops.gemm_nt(d, wt, chain, res=chain)
+    torch.testing.assert_close(out + res, chain, rtol=1e-5, atol=1e-5)  # (one accumulator chain against four fp32 round trips)
+
+    with pytest.raises(L.LnxError):  # fp32 operands: not this kernel's (the plan then launches head by head)
+        ops.gemm_nt_group([(feats.float(), Ws[0].float(), views[0], bs[0], None)])
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_nt_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches row/col swaps in the C write."""
