@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from linnaeus_amd import _lib as L  # noqa: E402
 
-NAMES = {1: "v1", 2: "v2", 3: "skinny", 4: "v4", 7: "v7", 9: "v9"}
+NAMES = {1: "v1", 2: "v2", 3: "skinny", 4: "v4", 7: "v7", 9: "v9", 15: "exp"}
 
 
 def ptr(t):
@@ -61,7 +61,7 @@ def make(M, N, K, form, rps):
     return (lambda: L.check(L.lib().lnx_gemm_nt(C.byref(a), st), "lnx_gemm_nt")), keep, A, W
 
 
-CFG = {"xl": (128 * 199, 1024, 4096, 199), "lg": (64 * 580, 768, 3072, 580), "sm": (256 * 199, 384, 1536, 199)}
+CFG = {"xl": (128 * 199, 1024, 4096, 199), "lg": (64 * 580, 768, 3072, 580), "sm": (256 * 199, 384, 1536, 199), "sm128": (128 * 199, 384, 1536, 199)}
 for name in (sys.argv[1:] or ["xl", "lg", "sm"]):
     M, C_, hid, rps = CFG[name]
     print(f"# {name}: M = {M}, C = {C_}, hidden = {hid}    TFLOP/s: in-model form | same shape, plain epilogue | vendor (torch.matmul)")

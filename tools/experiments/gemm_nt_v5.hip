@@ -31,13 +31,16 @@ __device__ __forceinline__ int key4r(int row) { return (row & 16) ? 3 : 0; }
 //   done) ; barrier ; 32 MFMAs.
 // WAR: stage (t+2)%3 was last read in iteration t-1 and every wave retired those reads (lgkmcnt(0)) before barrier t-1.
 // ------------------------------------------------------------------------------------
-constexpr int BM5 = 256, BN5 = 128;
-constexpr int STAGE5 = (BM5 + BN5) * ROWB4;   // 24 KiB
+// Round 5: BM5 = 128 as a second instantiation (LNX_V5_BM=128): a wave is then one 64x64 tile, a stage 16 KiB, and a product with N = 384
+// has 597 tiles at 128 images for the chip's 512 workgroup slots instead of 300 tiles of 256x128 for 256 CUs.
+constexpr int BN5 = 128;
 constexpr int NST5 = 3;
-constexpr int PIECES5 = STAGE5 / 1024 / 4;    // 1-KiB LDS-DMA instructions per wave per stage = 6
 
-template <bool OUT_F32, int F>
+template <bool OUT_F32, int F, int BM5>
 __global__ __launch_bounds__(256, 2) void gemm_nt_v5_kernel(const GemmP p) {
+    constexpr int STAGE5 = (BM5 + BN5) * ROWB4;   // 24 KiB (16 KiB at BM5 = 128)
+    constexpr int PIECES5 = STAGE5 / 1024 / 4;    // 1-KiB LDS-DMA instructions per wave per stage = 6 (4)
+    constexpr int WROWS = BM5 / 2;                // rows of a wave tile: 128 (two 64-row accumulator sets) or 64
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [NST5][A 256 rows | W 128 rows][64 B]
 
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v5_kernel(const GemmP p) {
     const int frag_row = (s >> 2) * 16 + (s & 3);
     const uint32_t chunk_off = (uint32_t)((g ^ (((s >> 2) & 1) * 3)) << 4);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const uint32_t a_off = (uint32_t)((wm * 128 + frag_row) * ROWB4) + chunk_off;
+    const uint32_t a_off = (uint32_t)((wm * WROWS + frag_row) * ROWB4) + chunk_off;
     const uint32_t w_off = (uint32_t)((BM5 + wn * 64 + frag_row) * ROWB4) + chunk_off;
 
     f32x4_t acc0[4][4], acc1[4][4];  // rows 0..63 / 64..127 of the wave tile
@@ -118,17 +121,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v5_kernel(const GemmP p) {
     }
     issue_stage(0, 0);
     issue_stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // own pieces of slice 0 have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES5) : "memory");  // own pieces of slice 0 have landed
     __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
         const uint32_t st = lds_base + (kt % NST5) * STAGE5;
         uint4 wf[4], af0[4], af1[4];
         DS4_READ4(wf, st + w_off);
         DS4_READ4(af0, st + a_off);
-        DS4_READ4(af1, st + a_off + 64 * ROWB4);
+        if constexpr (BM5 == 256) DS4_READ4(af1, st + a_off + 64 * ROWB4);
         if (kt + 2 < nk) {
             issue_stage(kt + 2, (kt + 2) % NST5);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES5) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -140,10 +143,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v5_kernel(const GemmP p) {
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc0[ni][mi], wf[ni], af0[mi]);
+        if constexpr (BM5 == 256) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
+                for (int mi = 0; mi < 4; ++mi) Mfma<T>::run(acc1[ni][mi], wf[ni], af1[mi]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -153,8 +158,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_v5_kernel(const GemmP p) {
 #ifdef V5_ABLATE  // diagnostic build (tools/build_v5_ablate.sh): stagger bit 16 = no epilogue (stores only if an accumulator holds a magic value)
     if ((p.stagger & (1 << 16)) && acc0[0][0][0] != 1.2345e30f && acc1[3][3][3] != 1.2345e30f) return;
 #endif
-    gemm_epilogue_fast<T, OUT_F32, F>(p, acc0, m0 + wm * 128, n0 + wn * 64, lane);
-    gemm_epilogue_fast<T, OUT_F32, F>(p, acc1, m0 + wm * 128 + 64, n0 + wn * 64, lane);
+    gemm_epilogue_fast<T, OUT_F32, F>(p, acc0, m0 + wm * WROWS, n0 + wn * 64, lane);
+    if constexpr (BM5 == 256) gemm_epilogue_fast<T, OUT_F32, F>(p, acc1, m0 + wm * 128 + 64, n0 + wn * 64, lane);
 #ifdef V5_ABLATE
     if (stamp && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,7 +174,8 @@ bool nt_v5_ok(const GemmP& p, int f) {
     return p.K % BK4 == 0 && p.K >= 2 * BK4;
 }
 
-int launch_nt_v5(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
+template <int BM5>
+static int launch_nt_v5_t(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     GemmP p = p0;
     p.tiles_m = cdiv(p.M, BM5);
     p.tiles_n = cdiv(p.N, BN5);
@@ -180,7 +186,7 @@ int launch_nt_v5(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     p.C8s = sp ? reinterpret_cast<unsigned char*>(strtoull(sp, nullptr, 10)) : nullptr;
 #endif
     const int grid5 = p.tiles_m * p.tiles_n;
-    size_t lds5 = NST5 * STAGE5;
+    size_t lds5 = NST5 * (BM5 + BN5) * ROWB4;
 #ifdef V5_ABLATE
     if (getenv("LNX_V5_ONE_WG")) lds5 = 100 * 1024;  // diagnostic: one workgroup per CU
 #endif
@@ -188,10 +194,10 @@ int launch_nt_v5(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     do {                                                                                                                             \
         static bool attr = false;                                                                                                    \
         if (!attr) {                                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v5_kernel<O, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_v5_kernel<O, FF, BM5>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
             attr = true;                                                                                                             \
         }                                                                                                                            \
-        hipLaunchKernelGGL((gemm_nt_v5_kernel<O, FF>), dim3(grid5), dim3(256), lds5, st, p);                                         \
+        hipLaunchKernelGGL((gemm_nt_v5_kernel<O, FF, BM5>), dim3(grid5), dim3(256), lds5, st, p);                                    \
     } while (0)
     if (out_f32) V5_LAUNCH(true, F_BIAS | F_RES);
     else if (f == 0) V5_LAUNCH(false, 0);
@@ -201,6 +207,12 @@ int launch_nt_v5(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
     else V5_LAUNCH(false, F_GELU_BWD);
 #undef V5_LAUNCH
     return 0;
+}
+
+int launch_nt_v5(const GemmP& p0, int f, bool out_f32, hipStream_t st) {
+    const char* bm = getenv("LNX_V5_BM");  // 128: the half-height tile (round 5)
+    if (bm && atoi(bm) == 128) return launch_nt_v5_t<128>(p0, f, out_f32, st);
+    return launch_nt_v5_t<256>(p0, f, out_f32, st);
 }
 
 }  // namespace lnxg
