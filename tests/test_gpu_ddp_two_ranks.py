@@ -47,7 +47,7 @@ def _gathered(t, world):
     return out
 
 
-def _worker(rank, world, port, q, batch):
+def _worker(rank, world, port, q, batch, mode="plain"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     res = {"rank": rank}
     try:
@@ -58,7 +58,9 @@ def _worker(rank, world, port, q, batch):
         from linnaeus_amd.optim import FusedAdamW
 
         model = _build("sm", rank)
-        dp = DataParallel(model)
+        if mode == "recompute":
+            model.use_checkpoint = True  # gradient checkpointing (TRAIN.GRADIENT_CHECKPOINTING): the recompute plan's segments
+        dp = DataParallel(model, compress_bf16=(mode == "compress"))
         flat = torch.cat([p.detach().flatten() for p in model.parameters()])
         res["broadcast"] = all(torch.equal(flat, o) for o in _gathered(flat, world))
 
@@ -93,7 +95,7 @@ def _worker(rank, world, port, q, batch):
             loss = multitask_cross_entropy(dp(x, meta), tg)
             loss.backward()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         torch.cuda.synchronize()
         flat = torch.cat([p.detach().flatten() for p in model.parameters()])
         others = _gathered(flat, world)
@@ -119,13 +121,15 @@ def _worker(rank, world, port, q, batch):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch", [8, 64])  # 64: 12 736 token rows, the persistent kernels and the weight-gradient stream under load
-def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step(batch):
+# 64 images: 12 736 token rows, the persistent kernels and the weight-gradient stream under load; recompute: the checkpointed plan's
+# backward segments; compress: bf16 buckets (the all-reduce runs on a scratch copy, the arena gets it back after the wait)
+@pytest.mark.parametrize("batch,mode", [(8, "plain"), (64, "plain"), (8, "recompute"), (8, "compress")])
+def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step(batch, mode):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, batch)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, batch, mode)) for r in range(world)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=540) for _ in range(world)]
@@ -140,7 +144,7 @@ def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step(batch):
         assert r["broadcast"], "parameters differ after the construction-time broadcast"
         assert r["local_differs"] > 0.05, "the ranks' batches should give different gradients"
         # bf16 plan, same batch twice: split-K partial order is fixed, the few float atomics (LayerScale / bias column sums) are not
-        assert r["rel_err"] < 2e-3, r
+        assert r["rel_err"] < (2e-2 if mode == "compress" else 2e-3), r  # (bf16 buckets: each rank's contribution rounded to 8 bits)
         assert r["ranks_agree"], "ranks hold different gradients after the all-reduce"
         assert r["params_agree_after_steps"], "parameters drifted apart over three clipped optimizer steps: " + r.get("drifted", "")
         assert all(b > 0 for b in r["buckets"]) and r["streams"] <= 4
