@@ -351,7 +351,13 @@ typedef struct lnx_attn_bwd_args {
     float drop_inv_keep;
     const float* dsin_tab; /* [2][(N-E), heads, 32] from lnx_rope_cos_table */
     float* dfreqs;         /* [2, heads, 32] fp32, accumulated into (dfreqs += ...) */
+    int defer_freqs;       /* 1: leave the fold of freq_ws into dfreqs to lnx_attn_bwd_flush (one launch for up to LNX_ATTN_DEFER_MAX calls of
+                              this thread on this stream; freq_ws and dfreqs must stay untouched and alive until then -- a plan gives every
+                              pending call its own freq_ws region and flushes at the end of each backward segment) */
 } lnx_attn_bwd_args;
+#define LNX_ATTN_DEFER_MAX 16
+int lnx_attn_bwd_flush(void* stream); /* folds every postponed call of this thread; refuses a stream other than theirs */
+int lnx_attn_bwd_discard(void);       /* forgets them without folding (error paths); returns how many were dropped */
 int lnx_attn_bwd(const lnx_attn_bwd_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------

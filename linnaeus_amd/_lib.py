@@ -128,7 +128,7 @@ EXPORTS = [
     "lnx_gemm_nt", "lnx_last_nt_kernel", "lnx_nt_kernel_launches", "lnx_nt_dispatch", "lnx_gemm_tn", "lnx_gemm_tn_flush", "lnx_gemm_tn_discard", "lnx_amax", "lnx_quantize_fp8", "lnx_gemm_nt_fp8", "lnx_quantize_mxfp8", "lnx_gemm_nt_mxfp8", "lnx_dropout_mul", "lnx_dropout_residual", "lnx_plan_dropout_bytes", "lnx_plan_set_dropout", "lnx_plan_attn_dropout_bytes", "lnx_plan_set_attn_dropout",
     "lnx_layernorm_fwd", "lnx_layernorm_bwd", "lnx_layernorm_bwd_flush", "lnx_layernorm_bwd_discard",
     "lnx_dwconv7_fwd", "lnx_dwconv7_wgrad",
-    "lnx_gemm_nt_group_ok", "lnx_gemm_nt_group", "lnx_rope_cos_table", "lnx_rope_cos_tables", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd",
+    "lnx_gemm_nt_group_ok", "lnx_gemm_nt_group", "lnx_rope_cos_table", "lnx_rope_cos_tables", "lnx_attn_bwd_ws_floats", "lnx_attn_fwd", "lnx_attn_bwd", "lnx_attn_bwd_flush", "lnx_attn_bwd_discard",
     "lnx_im2col_stem", "lnx_scale_cast", "lnx_layerscale_bwd", "lnx_layerscale_apply_wgrad", "lnx_fill_rows", "lnx_colsum_rows",
     "lnx_agg2_fwd", "lnx_agg2_bwd", "lnx_pack_meta", "lnx_meta_heads_supported", "lnx_meta_heads_fwd", "lnx_meta_heads_bwd", "lnx_meta_heads_bwd_part_floats", "lnx_prep_weights", "lnx_prep_blocks", "lnx_softce", "lnx_softce_multi", "lnx_stem_fwd", "lnx_stem_fwd_ok", "lnx_adamw_blocks", "lnx_grad_sumsq", "lnx_adamw_step",
     "lnx_mix_rows", "lnx_mix_meta",
@@ -233,7 +233,7 @@ class AttnBwdArgs(C.Structure):
         ("qkv", C.c_void_p), ("cos_tab", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
         ("d_o", C.c_void_p), ("dqkv", C.c_void_p), ("freq_ws", C.c_void_p), ("delta", C.c_void_p),
         ("drop_mask", C.c_void_p), ("drop_inv_keep", C.c_float),
-        ("dsin_tab", C.c_void_p), ("dfreqs", C.c_void_p),
+        ("dsin_tab", C.c_void_p), ("dfreqs", C.c_void_p), ("defer_freqs", C.c_int),
     ]
 
 

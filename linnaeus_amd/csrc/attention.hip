@@ -1318,6 +1318,67 @@ __global__ __launch_bounds__(1024) void rope_freqs_reduce_kernel(const float* __
     }
 }
 
+// the same fold for several attention backward calls in ONE launch (lnx_attn_bwd_args.defer_freqs + lnx_attn_bwd_flush): blockIdx.y picks
+// the call.  Every RoPE block owns its freqs, so a backward segment of a plan has one of these small folds per block.
+struct FreqEntry {
+    const float* fpart;
+    float* dfreqs;
+    int B, heads, per_bh, pad_;
+};
+struct FreqBatch {
+    FreqEntry e[LNX_ATTN_DEFER_MAX];
+};
+__global__ __launch_bounds__(1024) void rope_freqs_reduce_batch_kernel(const FreqBatch fb) {
+    __shared__ float red[16][64];
+    const FreqEntry& q = fb.e[blockIdx.y];
+    if ((int)blockIdx.x >= q.heads) return;  // (uniform per workgroup: the grid's width is the largest head count of the batch)
+    const float* __restrict__ fpart = q.fpart;
+    const int heads = q.heads, per_bh = q.per_bh;
+    const int h = blockIdx.x, t = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int n = q.B * per_bh;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    auto at = [&](int i) -> float {
+        const int ii = min(i, n - 1);
+        const int b = ii / per_bh, k = ii - b * per_bh;
+        const float v = fpart[(((int64_t)b * heads + h) * per_bh + k) * 64 + t];
+        return i < n ? v : 0.f;
+    };
+    for (int i = sl; i < n; i += 64) {  // (the order of rope_freqs_reduce_kernel: same bits)
+        a0 += at(i);
+        a1 += at(i + 16);
+        a2 += at(i + 32);
+        a3 += at(i + 48);
+    }
+    red[sl][t] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k][t];
+        q.dfreqs[((t >> 5) * heads + h) * 32 + (t & 31)] += acc;
+    }
+}
+
+// postponed folds of this thread's lnx_attn_bwd calls (raw pointers: the caller keeps partials and targets alive until the flush)
+thread_local FreqEntry g_freq_pending[LNX_ATTN_DEFER_MAX];
+thread_local int g_freq_n = 0;
+thread_local hipStream_t g_freq_stream = nullptr;
+
+int freq_flush(hipStream_t st) {
+    if (g_freq_n == 0) return 0;
+    LNX_CHECK(st == g_freq_stream, "lnx_attn_bwd_flush: the postponed folds belong to another stream");
+    FreqBatch fb{};
+    int most = 0;
+    for (int i = 0; i < g_freq_n; ++i) {
+        fb.e[i] = g_freq_pending[i];
+        if (fb.e[i].heads > most) most = fb.e[i].heads;
+    }
+    hipLaunchKernelGGL(rope_freqs_reduce_batch_kernel, dim3(most, g_freq_n), dim3(1024), 0, st, fb);
+    g_freq_n = 0;
+    LNX_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename K> void set_lds(K kernel, size_t bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
@@ -1426,8 +1487,18 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     const int grid = a->B * a->heads * p.qtiles;
     hipStream_t st = (hipStream_t)stream;
     // after the two kernels: the per-workgroup partials of the freqs gradient -> dfreqs (per_bh = workgroups per (sample, head))
+    if (a->defer_freqs && a->E < a->N) {  // checked before anything is launched
+        LNX_CHECK(g_freq_n == 0 || g_freq_stream == st, "lnx_attn_bwd: postponed freqs folds are pending on another stream (lnx_attn_bwd_flush them first)");
+        LNX_CHECK(g_freq_n < LNX_ATTN_DEFER_MAX, "lnx_attn_bwd: %d postponed freqs folds are pending; call lnx_attn_bwd_flush", LNX_ATTN_DEFER_MAX);
+    }
     auto reduce_freqs = [&](int per_bh) {
-        if (a->E < a->N) hipLaunchKernelGGL(rope_freqs_reduce_kernel, dim3(a->heads), dim3(1024), 0, st, p.fpart, a->B, a->heads, per_bh, a->dfreqs);
+        if (a->E >= a->N) return;
+        if (a->defer_freqs) {
+            g_freq_pending[g_freq_n++] = FreqEntry{p.fpart, a->dfreqs, a->B, a->heads, per_bh, 0};
+            g_freq_stream = st;
+            return;
+        }
+        hipLaunchKernelGGL(rope_freqs_reduce_kernel, dim3(a->heads), dim3(1024), 0, st, p.fpart, a->B, a->heads, per_bh, a->dfreqs);
     };
     if (a->drop_mask) {
         LNX_CHECK(a->drop_inv_keep >= 1.0f && (((uintptr_t)a->drop_mask) & 3) == 0, "lnx_attn_bwd: drop_inv_keep >= 1 and a 4-byte aligned mask");
@@ -1500,4 +1571,12 @@ extern "C" int lnx_attn_bwd(const lnx_attn_bwd_args* a, void* stream) {
     }
     LNX_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int lnx_attn_bwd_flush(void* stream) { return freq_flush((hipStream_t)stream); }
+
+extern "C" int lnx_attn_bwd_discard(void) {
+    const int n = g_freq_n;
+    g_freq_n = 0;
+    return n;
 }

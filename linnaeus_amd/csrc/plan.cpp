@@ -41,6 +41,7 @@ void lnx_set_error(const char* fmt, ...);
 namespace {
 
 constexpr int LN_DEFER_SLOTS = 16;  // == norm.hip's LN_BATCH: postponed LayerNorm-backward reductions per flush
+constexpr int FREQ_DEFER_SLOTS = 8;  // <= LNX_ATTN_DEFER_MAX: attention backward calls whose freqs fold waits for the segment's flush
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
@@ -136,6 +137,9 @@ struct lnx_plan {
     int64_t lnws_defer_floats = 0;
     int64_t o_lnws_defer = 0;  // LN_DEFER_SLOTS partial-sum regions of lnws_defer_floats each: LayerNorm backward calls whose second stage waits for the segment's flush
     int ln_pending = 0;        // ... how many of them are in use since the last flush
+    int64_t gcos_floats = 0;   // floats of one freqs-gradient partial region (o_gcos holds FREQ_DEFER_SLOTS of them)
+    int freq_pending = 0;      // attention backward calls whose freqs fold is postponed (lnx_attn_bwd_args.defer_freqs)
+    bool freq_defer = true;    // LNX_FREQ_DEFER=0: fold inside every lnx_attn_bwd call (A/B switch)
     bool ln_defer = true;      // LNX_LN_DEFER=0: every LayerNorm backward reduces its column partials at once (A/B)
     int64_t o_tnws = 0;  // split-K workspace of the weight-gradient GEMMs (main stream only)
     int64_t o_lsws = 0, lsws_floats = 0;  // S | T scratch of the z-free LayerScale gradient
@@ -351,6 +355,7 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
     p->esz = c.dtype == LNX_BF16 ? 2 : 4;
     p->meta_chain = !(getenv("LNX_META_CHAIN") && atoi(getenv("LNX_META_CHAIN")) == 0);
     p->ln_defer = !(getenv("LNX_LN_DEFER") && atoi(getenv("LNX_LN_DEFER")) == 0);
+    p->freq_defer = !(getenv("LNX_FREQ_DEFER") && atoi(getenv("LNX_FREQ_DEFER")) == 0);
     for (int s = 0; s < 2; ++s) p->chain_ok[s] = p->meta_chain && lnx_meta_heads_supported(c.dims[2 + s]) != 0;
     p->E = 1 + c.n_meta;
     p->H[0] = c.img_h / 4;
@@ -739,7 +744,8 @@ extern "C" int lnx_plan_create(const lnx_mformer_cfg* cfg, lnx_plan** out) {
             if (gsz > gmax) gmax = gsz;
             if (dsz > dmax) dmax = dsz;
         }
-        p->o_gcos = cv.take(gmax);
+        p->gcos_floats = gmax / 4;
+        p->o_gcos = cv.take(gmax * FREQ_DEFER_SLOTS);  // one region per attention backward whose freqs fold waits for the segment's flush
         p->o_delta = cv.take(dmax);
     }
     for (int s = 0; s < 2; ++s) {
@@ -1657,6 +1663,15 @@ int rope_block_bwd(const Ctx& c, int s, int i, float* g, bool have_dy) {
     ab.dtype = c.dt; ab.B = B; ab.N = N; ab.E = E; ab.heads = heads;
     ab.qkv = c.at<void>(k.qkvbuf); ab.cos_tab = c.at<float>(k.cos); ab.o = c.at<void>(k.o); ab.lse = c.at<float>(k.lse);
     ab.d_o = sD; ab.dqkv = sA; ab.freq_ws = c.at<float>(p->o_gcos); ab.delta = c.at<float>(p->o_delta);
+    if (p->freq_defer && E < N) {  // the fold into dfreqs: one launch per backward segment (ln_flush)
+        if (p->freq_pending == FREQ_DEFER_SLOTS) {
+            RUN(lnx_attn_bwd_flush(c.st));
+            p->freq_pending = 0;
+        }
+        ab.freq_ws = c.at<float>(p->o_gcos) + (int64_t)p->freq_pending * p->gcos_floats;
+        ab.defer_freqs = 1;
+        ++p->freq_pending;
+    }
     ab.dsin_tab = c.at<float>(k.dsin); ab.dfreqs = p->G[k.freqs];
     if (p->amask) {
         ab.drop_mask = p->amask + k.dm_attn; ab.drop_inv_keep = p->a_inv_keep;
@@ -1888,6 +1903,10 @@ int ln_flush(const Ctx& c) {
         RUN(lnx_layernorm_bwd_flush(c.st));
         p->ln_pending = 0;
     }
+    if (p->freq_pending > 0) {  // ... and the attention backwards' freqs folds
+        RUN(lnx_attn_bwd_flush(c.st));
+        p->freq_pending = 0;
+    }
     return 0;
 }
 
@@ -1913,11 +1932,14 @@ extern "C" int lnx_plan_backward(lnx_plan* p, const float* dlogits, const float*
     (void)lnx_gemm_tn_discard();
     (void)lnx_layernorm_bwd_discard();
     p->ln_pending = 0;
+    (void)lnx_attn_bwd_discard();
+    p->freq_pending = 0;
     struct TnGuard {
         lnx_plan* p;
         ~TnGuard() {
             (void)lnx_gemm_tn_discard();
             if (lnx_layernorm_bwd_discard() > 0) p->ln_pending = 0;  // (a successful call has flushed everything: nothing to drop)
+            if (lnx_attn_bwd_discard() > 0) p->freq_pending = 0;
         }
     } tn_guard{p};
     const lnx_mformer_cfg& cf = p->c;

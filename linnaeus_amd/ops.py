@@ -271,9 +271,10 @@ def attn_fwd(qkv, cos_tab, o, lse, B, N, E, heads, *, drop_mask=None, drop_rate=
     L.check(L.lib().lnx_attn_fwd(C.byref(a), _stream()), "lnx_attn_fwd")
 
 
-def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, delta, B, N, E, heads, *, dsin=None, dfreqs=None, drop_mask=None, drop_rate=0.0):
+def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, delta, B, N, E, heads, *, dsin=None, dfreqs=None, drop_mask=None, drop_rate=0.0, defer_freqs=False):
     """dq/dk/dv into dqkv; with image tokens (E < N) also dfreqs [2, heads, 32] += the gradient of the RoPE frequencies
-    (`dsin` = the second table of rope_cos_table)."""
+    (`dsin` = the second table of rope_cos_table).  defer_freqs: the fold into dfreqs waits for attn_bwd_flush(); the returned
+    workspace (and dfreqs) must be kept alive until then."""
     a = L.AttnBwdArgs()
     a.dtype, a.B, a.N, a.E, a.heads = code_of(qkv), B, N, E, heads
     a.qkv, a.cos_tab, a.o, a.lse = _p(qkv), _p(cos_tab), _p(o), _p(lse)
@@ -283,7 +284,14 @@ def attn_bwd(qkv, cos_tab, o, lse, d_o, dqkv, delta, B, N, E, heads, *, dsin=Non
         a.dsin_tab, a.dfreqs = _p(dsin), _p(dfreqs)
     if drop_mask is not None:
         a.drop_mask, a.drop_inv_keep = _p(drop_mask), 1.0 / (1.0 - drop_rate)
+    a.defer_freqs = int(bool(defer_freqs))
     L.check(L.lib().lnx_attn_bwd(C.byref(a), _stream()), "lnx_attn_bwd")
+    return ws
+
+
+def attn_bwd_flush():
+    """Fold every postponed freqs gradient of this thread (one launch)."""
+    L.check(L.lib().lnx_attn_bwd_flush(_stream()), "lnx_attn_bwd_flush")
 
 
 def im2col_stem(x, patches):

@@ -243,6 +243,54 @@ def test_attention_fwd_bwd(B, heads, H, W, E, dtype):
     torch.testing.assert_close(dfreqs.double().cpu(), fr.grad, rtol=tolb, atol=tolb * max(scale, 1.0))
 
 
+def test_attention_bwd_postponed_freqs_folds_in_one_launch():
+    """lnx_attn_bwd_args.defer_freqs + lnx_attn_bwd_flush (what a plan does with the RoPE blocks of a backward segment): the
+    freqs gradients of several calls -- different sequence lengths, head counts, kernels (resident, tiled, 8-wave tiled, fp32) --
+    folded by ONE launch are what each call folds on its own (same fold order; the partials agree run to run up to the rounding of
+    the kernels' LDS float atomics); nothing is written before the flush; a discard drops the pending folds."""
+    cases = [(2, 2, 3, 5, 3, L.BF16), (1, 3, 14, 14, 3, L.BF16), (1, 2, 24, 24, 4, L.BF16), (2, 6, 14, 14, 3, L.BF16), (1, 2, 7, 7, 4, L.F32)]
+    runs = []
+    for i, (B, heads, H, W, E, dtype) in enumerate(cases):
+        N, C_ = H * W + E, heads * 64
+        gen = g(100 + i)
+        qkv = torch.randn(B * N, 3 * C_, generator=gen).cuda().to(DT[dtype])
+        freqs = O.seeded_fill(f"t.attn.defer.{i}", (2, heads, 32), 7 + i).cuda()
+        dsin = torch.empty(2, H * W, heads, 32, device="cuda")
+        cos = ops.rope_cos_table(freqs, H, W, dsin=dsin)
+        o = torch.empty(B * N, C_, device="cuda", dtype=DT[dtype])
+        lse = torch.empty(B, heads, N, device="cuda")
+        ops.attn_fwd(qkv, cos, o, lse, B, N, E, heads)
+        d_o = torch.randn(B * N, C_, generator=gen).cuda().to(DT[dtype])
+        runs.append(dict(args=(qkv, cos, o, lse, d_o), shape=(B, N, E, heads), dsin=dsin))
+    for r in runs:  # each call alone
+        B, N, E, heads = r["shape"]
+        r["want"] = torch.ones(2, heads, 32, device="cuda")
+        ops.attn_bwd(*r["args"], torch.empty_like(r["args"][0]), torch.empty(B, heads, N, device="cuda"), B, N, E, heads, dsin=r["dsin"], dfreqs=r["want"])
+    keep = []
+    for r in runs:  # postponed
+        B, N, E, heads = r["shape"]
+        r["got"] = torch.ones(2, heads, 32, device="cuda")
+        dq, dl = torch.empty_like(r["args"][0]), torch.empty(B, heads, N, device="cuda")
+        keep.append((dq, dl, ops.attn_bwd(*r["args"], dq, dl, B, N, E, heads, dsin=r["dsin"], dfreqs=r["got"], defer_freqs=True)))
+    torch.cuda.synchronize()
+    assert all(bool((r["got"] == 1).all()) for r in runs)  # nothing folded yet
+    ops.attn_bwd_flush()
+    torch.cuda.synchronize()
+    for r in runs:
+        # (the per-workgroup partials themselves carry LDS float atomics: two runs of one call agree to rounding, not to the bit)
+        assert not bool((r["got"] == 1).all())
+        torch.testing.assert_close(r["got"], r["want"], rtol=1e-5, atol=1e-5 * float(r["want"].abs().max()))
+    # error path: pending folds are dropped, the targets stay as they are
+    B, N, E, heads = runs[0]["shape"]
+    t = torch.ones(2, heads, 32, device="cuda")
+    dq, dl = torch.empty_like(runs[0]["args"][0]), torch.empty(B, heads, N, device="cuda")
+    ws = ops.attn_bwd(*runs[0]["args"], dq, dl, B, N, E, heads, dsin=runs[0]["dsin"], dfreqs=t, defer_freqs=True)
+    assert L.lib().lnx_attn_bwd_discard() == 1
+    ops.attn_bwd_flush()  # nothing pending: no launch
+    torch.cuda.synchronize()
+    assert bool((t == 1).all()) and ws is not None
+
+
 @pytest.mark.parametrize("B,heads,H,W,E", [(2, 2, 3, 5, 3), (1, 3, 14, 14, 3), (1, 2, 24, 24, 4)])
 @pytest.mark.parametrize("dtype", [L.F32, L.BF16])
 def test_attention_probability_dropout(B, heads, H, W, E, dtype):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the shipped library against tools/ab/liblnx_prev.so (an older build: LNX_LIB_OLDER=1)
+# same-box A/B of the shipped library against tools/ab/liblnx_prev.so (an older build: LNX_LIB_OLDER=1); N alternations
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do
   for v in new prev; do
