@@ -144,3 +144,27 @@ def test_bench_line_loss_is_pinned_and_checked_against_the_oracle():
     n1 = line["config3_n1"]
     assert n1["per_gpu_batch"] == 128 and n1["ms_per_step"] > 0 and n1["images_per_sec"] > 0
     assert line["config"]["per_gpu_batch"] == 256 and line["roofline"] is None  # (--profile-steps 0)
+
+
+def test_bench_n2_path_with_two_real_ranks_on_one_gpu():
+    """`bench.py --gpus 2` end to end -- its own launcher (torch.distributed.run, one process per rank), barriers, max-over-ranks timing,
+    DataParallel with the bucket all-reduces, the no_sync leg, the telemetry steps and the N > 1 fields of the line -- with two real ranks.
+    RCCL refuses two ranks on one device, so `--rehearse-one-gpu` puts both on cuda:0 over gloo; the line says so and is not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--batch", "8", "--steps", "2", "--warmup", "1",
+                        "--profile-steps", "0", "--no-sched-calibration"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and "rehearsal" in line and line["scaling"] == "weak"
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["allreduce_of_ones"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert line["config"]["per_gpu_batch"] == 8 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert [b["bucket"] for b in line["rccl"]["buckets"]] == [0, 1, 2, 3] and all(b["bytes"] > 0 for b in line["rccl"]["buckets"])
+    assert line["rccl"]["stream_budget"]["count"] <= 4
+    dp = line["data_parallel"]
+    assert dp["ms_per_step_no_sync"] > 0 and dp["n1_equiv_images_per_sec"] > 0 and line["value"] > 0
