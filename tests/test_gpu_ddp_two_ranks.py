@@ -123,7 +123,7 @@ def _worker(rank, world, port, q, batch, mode="plain"):
 
 # 64 images: 12 736 token rows, the persistent kernels and the weight-gradient stream under load; recompute: the checkpointed plan's
 # backward segments; compress: bf16 buckets (the all-reduce runs on a scratch copy, the arena gets it back after the wait)
-@pytest.mark.parametrize("batch,mode", [(8, "plain"), (64, "plain"), (8, "recompute"), (8, "compress")])
+@pytest.mark.parametrize("batch,mode", [(64, "plain"), (8, "recompute"), (8, "compress")])
 def test_two_ranks_on_the_gpu_average_their_gradients_and_stay_in_step(batch, mode):
     world = 2
     ctx = mp.get_context("spawn")
