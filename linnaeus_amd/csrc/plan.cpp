@@ -1028,8 +1028,15 @@ int gemm_nt_t(const Ctx& c, const lnx_gemm_args* a) {
 // otherwise one launch per head.  accumulate: C = res + sum_t A_t . W_t^T (the data gradient wrt the features); hg[0] carries C / res.
 int heads_nt(const Ctx& c, lnx_gemm_args* hg, int n, bool accumulate) {
     static const bool off = getenv("LNX_HEADS_GROUP") != nullptr && atoi(getenv("LNX_HEADS_GROUP")) == 0;  // A/B switch
-    for (int t0 = 0; t0 < n; t0 += LNX_GEMM_GROUP_MAX) {
-        const int m = n - t0 < LNX_GEMM_GROUP_MAX ? n - t0 : LNX_GEMM_GROUP_MAX;
+    // a model with more heads than one launch carries goes in several groups; LNX_HEADS_GROUP_MAX (read per call: the tests flip it) makes
+    // the groups smaller so that a 4-head fixture walks that path too
+    int gmax = LNX_GEMM_GROUP_MAX;
+    if (const char* e = getenv("LNX_HEADS_GROUP_MAX")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < gmax) gmax = v;
+    }
+    for (int t0 = 0; t0 < n; t0 += gmax) {
+        const int m = n - t0 < gmax ? n - t0 : gmax;
         lnx_gemm_args* g = hg + t0;
         if (accumulate && t0 > 0) {  // a second group adds onto what the first one wrote
             g[0].C = hg[0].C; g[0].ldc = hg[0].ldc; g[0].res = (const float*)hg[0].C; g[0].ldres = hg[0].ldc;

@@ -244,6 +244,32 @@ def test_train_step_matches_reference(dtype, golden_dir):
             assert np.abs(cur - ref).max() <= 0.2 * np.abs(ref).max() + 1e-7, (k, cur, ref)
 
 
+def test_classification_heads_in_several_groups(golden_dir, monkeypatch):
+    """The plan issues every classification head in one grouped launch, forward and data gradient (lnx_gemm_nt_group); a model with more
+    heads than a launch carries (8) goes in several groups, the data-gradient groups accumulating onto each other.  LNX_HEADS_GROUP_MAX
+    (read per call) makes the groups smaller, so the sm fixture's four heads walk that path: groups of 3 + 1 and of 1 + 1 + 1 + 1 give
+    the same logits bit for bit (independent products) and the same gradients up to the rounding of the accumulator chain."""
+    spec, z, sd, x, meta, drops = load_case("sm", golden_dir)
+    model = build("sm", spec, sd, "bf16")
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = run(model, x, meta, drops, train=True)
+        sum((out[t].float() ** 2).mean() for t, _ in spec.heads).backward()
+        return {t: out[t].detach().clone() for t, _ in spec.heads}, {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    want_out, want_g = step()
+    for gmax in ("3", "1"):
+        monkeypatch.setenv("LNX_HEADS_GROUP_MAX", gmax)
+        got_out, got_g = step()
+        for t, _ in spec.heads:
+            assert torch.equal(got_out[t], want_out[t]), (gmax, t)
+        for k, g_ in want_g.items():
+            if k == "aggregate.bias":
+                continue  # (exactly zero in real arithmetic -- a constant shift in front of final_norm: what is compared would be rounding noise)
+            torch.testing.assert_close(got_g[k], g_, rtol=2e-4, atol=2e-4 * float(g_.abs().max()) + 1e-12, msg=lambda m, k=k: f"{k} (groups of {gmax}): {m}")
+
+
 def test_large_384_matches_oracle():
     """BASELINE config 4's shape: mFormerV1_lg (dims 192..1536, rope depths 10/2, heads 12/24) at 384x384, so
     N = 24*24 + 3 = 579 tokens in stage 2 (multi-tile attention path) and conv stages the fused C<=192 kernels only
